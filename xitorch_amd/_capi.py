@@ -1,0 +1,109 @@
+"""ctypes binding of libxitorch_amd.so — the C ABI declared in include/xitorch_amd.h.
+
+The product path has NO fallback: if the HIP library is missing or a call
+returns non-zero this raises.  PyTorch is only used for device memory and the
+current HIP stream (`torch.cuda.current_stream().cuda_stream`).
+"""
+import ctypes
+import os
+import re
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libxitorch_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "xitorch_amd.h")
+
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_long = ctypes.c_long
+c_double = ctypes.c_double
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the native library; raise loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                "xitorch_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def header_symbols():
+    """All function names declared in include/xitorch_amd.h (used by the CPU tests)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(xk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _declare(L):
+    P, I, Lg, D = c_void_p, c_int, c_long, c_double
+    sigs = {
+        "xk_abi_version": (I, []),
+        "xk_dense_mm_workspace_elems": (Lg, [I, I, I, I, I]),
+        "xk_dense_mm_f64": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),
+        "xk_dense_mm_f32": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),
+    }
+    sigs.update(_EXTRA_SIGS)
+    for name, (res, args) in sigs.items():
+        if not hasattr(L, name):
+            continue  # reported by the symbol test, and by check() at call time
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+
+
+_EXTRA_SIGS = {}
+
+
+def register_signatures(sigs):
+    """Other modules of the package add their entry points here before first load."""
+    _EXTRA_SIGS.update(sigs)
+    if _lib is not None:
+        _declare(_lib)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeLibraryError("xitorch_amd native call %s failed with code %d" % (what, rc))
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def suffix(dtype):
+    if dtype == torch.float64:
+        return "f64"
+    if dtype == torch.float32:
+        return "f32"
+    raise NativeLibraryError("xitorch_amd native kernels support float64/float32, got %s" % dtype)
+
+
+def require_device(t, what="tensor"):
+    if not t.is_cuda:
+        raise NativeLibraryError(
+            "xitorch_amd: %s must live on a HIP device (got %s); the native path has no CPU fallback"
+            % (what, t.device))
+
+
+def fn(name):
+    L = lib()
+    if not hasattr(L, name):
+        raise NativeLibraryError("xitorch_amd: symbol %s missing from %s" % (name, LIB_PATH))
+    return getattr(L, name)

@@ -1,0 +1,141 @@
+// xitorch_amd :: shared device helpers for the gfx950 (MI355X, CDNA4) kernels.
+//
+// Everything here is written for wave64 / gfx950 only.  No CUDA shims, no
+// dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define XK_WAVE 64
+
+// status codes returned over the C ABI (see include/xitorch_amd.h)
+#define XK_OK 0
+#define XK_ERR_ARG (-1)
+#define XK_ERR_UNSUPPORTED (-2)
+
+#define XK_LAUNCH_CHECK()                       \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+namespace xk {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// 16-byte vector type for an element type
+template <typename T> struct Vec16;
+template <> struct Vec16<double> { typedef d2 type; static constexpr int n = 2; };
+template <> struct Vec16<float> { typedef f4 type; static constexpr int n = 4; };
+
+// streaming (read-once) 16 B load: the operator matrix is touched exactly once
+// per panel product, so keep it out of the way of the L2-resident panel.
+template <typename V>
+__device__ __forceinline__ V ld_stream(const V* p) {
+  return __builtin_nontemporal_load(p);
+}
+
+__device__ __forceinline__ double shfl_xor_t(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl_xor_t(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// plain butterfly all-reduce (sum) over the 64 lanes of a wave
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_t(v, m);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    T o = shfl_xor_t(v, m);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Transposing wave reduction ("reduce-scatter over lanes").
+//
+// Each lane holds NV partial sums v[0..NV).  We want, for every i, the sum of
+// v[i] over the 64 lanes.  A plain butterfly costs 6*NV shuffles.  Instead, at
+// every stage where the live count is even, lanes pair up values: the lane
+// with the stage bit clear keeps the even-indexed value of each pair and ships
+// the odd one, its partner does the opposite; the live count halves.  When the
+// count becomes odd the remaining stages fall back to the plain butterfly.
+//
+// After the call, lane l holds in v[0..count) the full sums of original index
+//     orig(i, l) = i * 2^h + sum_{s<h} bit_s(l) * 2^s,  bit_s(l) = (l >> (5-s)) & 1
+// where h = number of halving stages performed (returned via template consts).
+// Lanes that differ only in the low (6-h) bits hold identical copies.
+// ---------------------------------------------------------------------------
+template <int NV> struct HalvingStages {
+  static constexpr int value = (NV % 2 == 0 && NV > 1) ? 1 + HalvingStages<NV / 2>::value : 0;
+};
+template <> struct HalvingStages<1> { static constexpr int value = 0; };
+template <> struct HalvingStages<0> { static constexpr int value = 0; };
+
+template <typename T, int NV>
+__device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane) {
+  constexpr int H0 = HalvingStages<NV>::value;
+  constexpr int H = H0 > 6 ? 6 : H0;
+  int cnt = NV;
+#pragma unroll
+  for (int s = 0; s < H; ++s) {
+    const int mask = 32 >> s;
+    const bool hi = (lane & mask) != 0;
+    const int half = cnt / 2;
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+      if (i < half) {
+        T keep = hi ? v[2 * i + 1] : v[2 * i];
+        T send = hi ? v[2 * i] : v[2 * i + 1];
+        v[i] = keep + shfl_xor_t(send, mask);
+      }
+    }
+    cnt = half;
+  }
+#pragma unroll
+  for (int s = H; s < 6; ++s) {
+    const int mask = 32 >> s;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i < (NV >> H)) v[i] += shfl_xor_t(v[i], mask);
+    }
+  }
+}
+
+// index bookkeeping for wave_reduce_scatter
+template <int NV>
+__device__ __forceinline__ int wave_rs_orig_index(int i, int lane) {
+  constexpr int H0 = HalvingStages<NV>::value;
+  constexpr int H = H0 > 6 ? 6 : H0;
+  int idx = i << H;
+#pragma unroll
+  for (int s = 0; s < H; ++s) idx += ((lane >> (5 - s)) & 1) << s;
+  return idx;
+}
+template <int NV>
+__device__ __forceinline__ bool wave_rs_is_writer(int lane) {
+  constexpr int H0 = HalvingStages<NV>::value;
+  constexpr int H = H0 > 6 ? 6 : H0;
+  return (lane & ((64 >> H) - 1)) == 0;
+}
+template <int NV> struct WaveRsCount {
+  static constexpr int H0 = HalvingStages<NV>::value;
+  static constexpr int H = H0 > 6 ? 6 : H0;
+  static constexpr int value = NV >> H;
+};
+
+// non-negative doubles/floats order like their bit patterns -> atomic max on ints
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
+  atomicMax(reinterpret_cast<unsigned long long*>(addr),
+            (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
+  atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+}  // namespace xk
