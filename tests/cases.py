@@ -1,0 +1,130 @@
+"""Shared definitions of the parity cases: names, sizes, options and INPUT generators.
+
+Inputs come from closed forms (xitorch_amd.synthetic) or from the CPU torch
+generator with a fixed seed, always generated on CPU in float64 and then moved
+to the device under test, so that the oracle, the reference (when the golden
+fixtures were made) and the HIP path see the very same numbers.
+Nothing here imports the reference.
+"""
+import math
+import torch
+from xitorch_amd import synthetic as syn
+
+f64 = torch.float64
+
+
+def probe_rows(n):
+    return [0, 1, n // 3, n // 2, n - 2, n - 1]
+
+
+# ------------------------------------------------------------------ eigensolver cases
+DAVIDSON_CASES = [
+    # the reference's own large-operator test (xitorch/_tests/test_linop_fcns.py:129-176)
+    dict(name="alarge1000_lowest", kind="alarge", n=1000, batch=(), neig=2, mode="lowest", min_eps=1e-8),
+    dict(name="alarge1000_uppest", kind="alarge", n=1000, batch=(), neig=2, mode="uppest", min_eps=1e-8),
+    dict(name="alarge600_b2_lowest", kind="alarge", n=600, batch=(2,), neig=2, mode="lowest", min_eps=1e-8),
+    # closed-form dense spectra of the benchmark
+    dict(name="s1_512_b2_lowest6", kind="S1", n=512, batch=(2,), neig=6, mode="lowest", min_eps=1e-8),
+    dict(name="s2_256_b3_uppest4", kind="S2", n=256, batch=(3,), neig=4, mode="uppest", min_eps=1e-8),
+    dict(name="s1_1024_b1_lowest6", kind="S1", n=1024, batch=(1,), neig=6, mode="lowest", min_eps=1e-8),
+    # config 1 of BASELINE.json: benchmarks_solve.py shape family, N=512, lowest 6
+    dict(name="c1_rand512_lowest6", kind="randsym", n=512, batch=(), neig=6, mode="lowest", min_eps=1e-8),
+]
+
+
+def random_symmetric(n, min_eival, max_eival, seed):
+    """Prescribed linspace spectrum in a seeded random orthogonal basis — restates what
+    xitorch/_utils/tensor.py:46-76 (create_random_square_matrix, hermitian branch) computes."""
+    ev = torch.linspace(min_eival, max_eival, n, dtype=f64)
+    g = torch.Generator().manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn((n, n), dtype=f64, generator=g))
+    mat = q.transpose(-2, -1) @ torch.diag_embed(ev) @ q
+    return (mat + mat.transpose(-2, -1)) * 0.5
+
+
+def davidson_matrix(case):
+    n, kind, batch = case["n"], case["kind"], tuple(case["batch"])
+    if kind == "alarge":
+        nb = 1
+        for d in batch:
+            nb *= d
+        mats = []
+        for b in range(nb):
+            m = torch.diag(torch.arange(n, dtype=f64) * (1.0 + 0.1 * b))
+            eye = torch.eye(n, dtype=f64)
+            m = m + 1e-3 * (torch.roll(eye, 1, 0) + torch.roll(eye, -1, 0))
+            mats.append(m)
+        return torch.stack(mats).reshape(*batch, n, n)
+    if kind in ("S1", "S2", "S3"):
+        return syn.dense_symmetric(batch[0], n, kind)
+    if kind == "randsym":
+        return random_symmetric(n, -1.0, 1.0, 123)
+    raise ValueError(kind)
+
+
+# ------------------------------------------------------------------ linear-solver cases
+SOLVE_CASES = [
+    dict(name="cg_sym100", method="cg", op="dense", hermitian=True, n=100, batch=(2,), ncols=3,
+         kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="cg_nonsym60_normal_eq", method="cg", op="dense", hermitian=False, n=60, batch=(2,), ncols=2,
+         kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="bicgstab_nonsym100", method="bicgstab", op="dense", hermitian=False, n=100, batch=(2,), ncols=3,
+         kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="bicgstab_banded1024", method="bicgstab", op="banded", hermitian=False, n=1024, batch=(2,),
+         ncols=1, kwargs=dict(rtol=1e-10, atol=1e-12, posdef=True)),
+    dict(name="gmres_nonsym60", method="gmres", op="dense", hermitian=False, n=60, batch=(2,), ncols=2,
+         kwargs=dict(rtol=1e-8, posdef=True, max_niter=60)),
+    dict(name="cg_sym_AEM", method="cg", op="dense", hermitian=True, n=80, batch=(2,), ncols=3, E=True, M=True,
+         kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="bicgstab_nonsym_AE", method="bicgstab", op="dense", hermitian=False, n=80, batch=(2,), ncols=3,
+         E=True, kwargs=dict(rtol=1e-8, posdef=True)),
+]
+
+
+def solve_inputs(case):
+    n, batch, nc = case["n"], tuple(case["batch"]), case["ncols"]
+    g = torch.Generator().manual_seed(12345)
+    if case["op"] == "banded":
+        A = syn.banded(batch[0], n, hb=63)
+        xs = syn.banded_rhs_solution(batch[0], n)
+        B = syn.banded_apply_reference(A, xs)
+    else:
+        R = torch.rand((*batch, n, n), dtype=f64, generator=g)
+        A = 0.1 * R + torch.eye(n, dtype=f64)
+        if case["hermitian"]:
+            A = (A + A.transpose(-2, -1)) * 0.5
+        B = torch.rand((*batch, n, nc), dtype=f64, generator=g)
+    E = M = None
+    if case.get("E"):
+        E = torch.rand((*batch, nc), dtype=f64, generator=g) * 0.3
+    if case.get("M"):
+        R2 = torch.rand((*batch, n, n), dtype=f64, generator=g)
+        M = 0.05 * (R2 + R2.transpose(-2, -1)) * 0.5 + torch.eye(n, dtype=f64)
+    return A, B, E, M
+
+
+# ------------------------------------------------------------------ root-finder cases
+def tanh_fcn(y, A):
+    # README.md:16-20 example: f(y) = tanh(A y + 0.1) + y/2
+    return torch.tanh(A @ y + 0.1) + y / 2.0
+
+
+def tanh_fcn_batched(y, A):
+    # config 4: per-batch dense A_b, y: (B, N)
+    return torch.tanh(torch.einsum("bij,bj->bi", A, y) + 0.1) + y / 2.0
+
+
+ROOT_CASES = [
+    dict(name="readme2", kind="readme", grad=True, kwargs=dict()),
+    dict(name="tanh_b4_n64", kind="tanh", nbatch=4, n=64, kwargs=dict(alpha=-1.0, max_rank=None, f_tol=1e-8)),
+    dict(name="tanh_b3_n96_rank8", kind="tanh", nbatch=3, n=96, kwargs=dict(alpha=-1.0, max_rank=8, f_tol=1e-8)),
+]
+
+
+def root_inputs(case):
+    if case["kind"] == "readme":
+        A = torch.tensor([[1.1, 0.4], [0.3, 0.8]], dtype=f64)
+        return tanh_fcn, torch.zeros((2, 1), dtype=f64), (A,)
+    A = syn.root_matrix(case["nbatch"], case["n"]) * 2.0   # eigenvalues in (0, 1]
+    y0 = torch.zeros((case["nbatch"], case["n"]), dtype=f64)
+    return tanh_fcn_batched, y0, (A,)

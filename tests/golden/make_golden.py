@@ -1,0 +1,176 @@
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are plain data (inputs are regenerated from closed forms / fixed CPU
+seeds, only reference OUTPUTS are stored).  It also cross-checks the oracle
+against the reference on every case (bit-for-bit on CPU) and refuses to write
+a fixture if they disagree.
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import warnings
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import xitorch  # noqa: E402  (the reference)
+from xitorch._impls.linalg import symeig as ref_symeig  # noqa: E402
+from xitorch._impls.linalg import solve as ref_solve  # noqa: E402
+from xitorch._impls.optimize.root import rootsolver as ref_root  # noqa: E402
+import xitorch.linalg  # noqa: E402
+import xitorch.optimize  # noqa: E402
+
+import oracle.ops as oops  # noqa: E402
+import oracle.symeig as osym  # noqa: E402
+import oracle.solve as osolve  # noqa: E402
+import oracle.rootfinder as oroot  # noqa: E402
+from tests import cases  # noqa: E402
+
+torch.set_num_threads(1)   # bit-reproducible reductions
+f64 = torch.float64
+
+
+def exact(a, b, what):
+    if not torch.equal(a, b):
+        err = (a - b).abs().max().item()
+        raise SystemExit("oracle != reference for %s (max abs diff %.3e)" % (what, err))
+
+
+class CountingRefOp(xitorch.LinearOperator):
+    """Reference-side wrapper that counts applies (to pin iteration counts)."""
+
+    def __init__(self, op):
+        super().__init__(shape=op.shape, is_hermitian=op.is_hermitian, dtype=op.dtype, device=op.device)
+        self.op = op
+        self.n = 0
+
+    def _mv(self, x):
+        self.n += 1
+        return self.op.mv(x)
+
+    def _mm(self, x):
+        self.n += 1
+        return self.op.mm(x)
+
+    def _rmv(self, x):
+        self.n += 1
+        return self.op.rmv(x)
+
+    def _rmm(self, x):
+        self.n += 1
+        return self.op.rmm(x)
+
+    def _getparamnames(self, prefix=""):
+        return []
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: tuple(np.shape(v)) for k, v in out.items()})
+
+
+# --------------------------------------------------------------------------- symeig / davidson
+def gen_davidson():
+    for case in cases.DAVIDSON_CASES:
+        name = case["name"]
+        mat = cases.davidson_matrix(case)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rop = CountingRefOp(xitorch.LinearOperator.m(mat, is_hermitian=True))
+        kw = dict(max_niter=case.get("max_niter", 1000), min_eps=case["min_eps"], v_init="randn")
+        ev_r, X_r = ref_symeig.davidson(rop, case["neig"], case["mode"], None, **kw)
+        tr = {}
+        oop = oops.DenseOp(mat, is_hermitian=True)
+        ev_o, X_o = osym.davidson(oop, case["neig"], case["mode"], None, trace=tr, **kw)
+        exact(ev_r, ev_o, name + " evals")
+        exact(X_r, X_o, name + " evecs")
+        assert tr["napply"] == rop.n, (tr["napply"], rop.n)
+        ev_x, _ = ref_symeig.exacteig(xitorch.LinearOperator.m(mat, is_hermitian=True), case["neig"], case["mode"], None)
+        resid = (torch.matmul(mat, X_r) - X_r * ev_r.unsqueeze(-2)).abs().max()
+        # store evecs only through a sign-free, small summary: |X|^T at a few probe rows
+        probe = cases.probe_rows(mat.shape[-1])
+        save("davidson_" + name, evals=ev_r, evals_exact=ev_x, napply=rop.n, niter=tr["niter"],
+             max_resid=resid, absX_probe=X_r.abs()[..., probe, :], probe=probe)
+
+
+# --------------------------------------------------------------------------- solve
+def gen_solve():
+    for case in cases.SOLVE_CASES:
+        name = case["name"]
+        A, B, E, M = cases.solve_inputs(case)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if case["op"] == "banded":
+                oA = oops.BandedOp(A, is_hermitian=False)
+                rA = CountingRefOp(xitorch.LinearOperator.m(oA.fullmatrix(), is_hermitian=False))
+                # the oracle must act like the dense matrix for bit-equality: use the same dense op
+                oA = oops.DenseOp(oA.fullmatrix(), is_hermitian=False)
+            else:
+                rA = CountingRefOp(xitorch.LinearOperator.m(A, is_hermitian=case["hermitian"]))
+                oA = oops.DenseOp(A, is_hermitian=case["hermitian"])
+            rM = xitorch.LinearOperator.m(M, is_hermitian=True) if M is not None else None
+            oM = oops.DenseOp(M, is_hermitian=True) if M is not None else None
+        kw = dict(case["kwargs"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fr = getattr(ref_solve, case["method"])
+            fo = getattr(osolve, case["method"])
+            X_r = fr(rA, B, E, rM, **kw)
+            tr = {}
+            X_o = fo(oA, B, E, oM, trace=tr, **kw)
+        exact(X_r, X_o, name)
+        assert oA.n_apply == rA.n, (name, oA.n_apply, rA.n)
+        X_x = osolve.exactsolve(oA, B, E, oM) if case["method"] != "gmres" or E is None else X_r
+        save("solve_" + name, X=X_r, X_exact=X_x, napply=rA.n, niter=tr["niter"], converged=tr["converged"])
+
+
+# --------------------------------------------------------------------------- rootfinder
+def gen_root():
+    for case in cases.ROOT_CASES:
+        name = case["name"]
+        fcn, y0, params = cases.root_inputs(case)
+        kw = dict(case["kwargs"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            nfev_r = [0]
+
+            def cfcn(y, *p):
+                nfev_r[0] += 1
+                return fcn(y, *p)
+            y_r = ref_root.broyden1(cfcn, y0, params, **kw)
+            tr = {}
+            y_o = oroot.broyden1(fcn, y0, params, trace=tr, **kw)
+        exact(y_r, y_o, name)
+        assert tr["nfev"] == nfev_r[0], (name, tr["nfev"], nfev_r[0])
+        out = dict(y=y_r, nfev=nfev_r[0], niter=tr["niter"], fnorm=fcn(y_r, *params).norm())
+        if case.get("grad"):
+            # full functional with implicit backward through the reference (README.md:16-32 flow)
+            ps = [p.clone().requires_grad_() for p in params]
+            yr = xitorch.optimize.rootfinder(fcn, y0, params=ps, method="broyden1", **kw)
+            g1 = torch.autograd.grad(yr.sum(), ps, create_graph=True)
+            g2 = torch.autograd.grad(sum(g.sum() for g in g1), ps)
+            for i, (a, b) in enumerate(zip(g1, g2)):
+                out["grad%d" % i] = a.detach()
+                out["gradgrad%d" % i] = b.detach()
+        save("root_" + name, **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["davidson", "solve", "root"]
+    if "davidson" in which:
+        gen_davidson()
+    if "solve" in which:
+        gen_solve()
+    if "root" in which:
+        gen_root()
+    print("golden fixtures written; reference =", xitorch.__version__, "torch", torch.__version__)
