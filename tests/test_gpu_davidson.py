@@ -1,0 +1,103 @@
+"""-m gpu: native HIP Davidson vs (a) the oracle on the same inputs, (b) the reference's golden outputs."""
+import os
+import numpy as np
+import pytest
+import torch
+from oracle import ops as oops, symeig as osym
+from tests import cases
+import xitorch_amd as xa
+from xitorch_amd.linalg import symeig
+from xitorch_amd.linalg.native_eig import davidson
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _check_pairs(mat, evals, evecs, ref_evals, min_eps, exact_evals=None):
+    # eigenvalues: 1e-10 (north_star tolerance), ascending order identical
+    scale = max(1.0, float(np.abs(ref_evals).max()))
+    assert np.all(np.diff(evals, axis=-1) >= -1e-12), "eigenvalues must be ascending"
+    assert np.abs(evals - ref_evals).max() <= 1e-10 * scale
+    if exact_evals is not None:
+        assert np.abs(evals - exact_evals).max() <= 1e-10 * scale
+    # residual identity A X = X E (reference test style, test_linop_fcns.py:174-176)
+    X = torch.from_numpy(evecs)
+    R = torch.matmul(mat, X) - X * torch.from_numpy(evals).unsqueeze(-2)
+    assert R.abs().max().item() <= 10 * min_eps
+    # orthonormality
+    G = torch.matmul(X.transpose(-2, -1), X)
+    assert (G - torch.eye(G.shape[-1], dtype=G.dtype)).abs().max().item() < 1e-9
+
+
+@pytest.mark.parametrize("case", cases.DAVIDSON_CASES, ids=[c["name"] for c in cases.DAVIDSON_CASES])
+def test_davidson_vs_golden_and_oracle(dev, case):
+    gold = np.load(os.path.join(GOLD, "davidson_%s.npz" % case["name"]))
+    mat = cases.davidson_matrix(case)
+    A = xa.LinearOperator.m(mat.to(dev), is_hermitian=True)
+    tr = {}
+    evals, evecs = davidson(A, case["neig"], case["mode"], None, min_eps=case["min_eps"], v_init="randn", trace=tr)
+    evals, evecs = evals.cpu().numpy(), evecs.cpu().numpy()
+    assert evals.shape == gold["evals"].shape
+    _check_pairs(mat, evals, evecs, gold["evals"], case["min_eps"], gold["evals_exact"])
+    # same iteration path as the reference: same start block, same algorithm -> same count (+-2 for
+    # rounding-level differences in the stopping test)
+    assert abs(tr["niter"] - int(gold["niter"])) <= 2, (tr["niter"], int(gold["niter"]))
+    # subspace parity: |X| at probe rows matches the reference's eigenvectors up to sign
+    probe = [int(i) for i in gold["probe"]]
+    sep_ok = np.abs(np.diff(gold["evals"], axis=-1)).min() > 1e-6 if gold["evals"].shape[-1] > 1 else True
+    if sep_ok:
+        assert np.abs(np.abs(evecs[..., probe, :]) - gold["absX_probe"]).max() < 1e-6
+    # the live oracle on the same inputs agrees with the fixture (oracle is the checker)
+    tr_o = {}
+    ev_o, _ = osym.davidson(oops.DenseOp(mat, True), case["neig"], case["mode"], None, min_eps=case["min_eps"], trace=tr_o)
+    assert np.abs(ev_o.numpy() - gold["evals"]).max() <= 1e-12 * max(1.0, np.abs(gold["evals"]).max())
+
+
+def test_symeig_frontend_davidson_and_custom_operator(dev):
+    # method="davidson" through the functional, on a user-defined implicit operator (ALarge of the reference tests)
+    n = 400
+
+    class ALarge(xa.LinearOperator):
+        def __init__(self, shape, dtype, device):
+            super().__init__(shape, is_hermitian=True, dtype=dtype, device=device)
+            self.b = torch.arange(shape[-1], dtype=dtype, device=device).repeat(*shape[:-2], 1)
+
+        def _mv(self, x):
+            return x * self.b + 1e-3 * (torch.roll(x, 1, -1) + torch.roll(x, -1, -1))
+
+        def _getparamnames(self, prefix=""):
+            return [prefix + "b"]
+
+    for shape in [(n, n), (2, n, n), (2, 3, n, n)]:
+        A = ALarge(shape, torch.float64, dev)
+        for mode in ("lowest", "uppermost"):
+            evals, evecs = symeig(A, neig=2, mode=mode, method="davidson", min_eps=1e-8)
+            assert list(evals.shape) == [*shape[:-2], 2] and list(evecs.shape) == [*shape[:-2], n, 2]
+            AX = A.mm(evecs)
+            assert torch.allclose(AX, evecs * evals.unsqueeze(-2), atol=1e-6)
+            if mode == "lowest":
+                assert evals.max().item() < 1.1 and evals.min().item() > -0.1
+            else:
+                assert evals.min().item() > n - 2.1
+
+
+def test_davidson_generalized_M(dev):
+    g = torch.Generator().manual_seed(3)
+    n = 120
+    R = torch.rand(2, n, n, dtype=torch.float64, generator=g)
+    Amat = (R + R.transpose(-2, -1)) * 0.5 + torch.diag(torch.arange(n, dtype=torch.float64) * 0.5)
+    R2 = torch.rand(2, n, n, dtype=torch.float64, generator=g)
+    Mmat = 0.02 * (R2 + R2.transpose(-2, -1)) + torch.eye(n, dtype=torch.float64)
+    ev_o, X_o = osym.exacteig(oops.DenseOp(Amat, True), 3, "lowest", oops.DenseOp(Mmat, True))
+    A = xa.LinearOperator.m(Amat.to(dev), True)
+    M = xa.LinearOperator.m(Mmat.to(dev), True)
+    ev, X = davidson(A, 3, "lowest", M, min_eps=1e-9)
+    assert torch.allclose(ev.cpu(), ev_o, atol=1e-9)
+    Xc = X.cpu()
+    assert torch.allclose(torch.matmul(Amat, Xc), torch.matmul(Mmat, Xc) * ev.cpu().unsqueeze(-2), atol=1e-7)
+
+
+def test_native_requires_device():
+    A = xa.LinearOperator.m(torch.eye(8, dtype=torch.float64), True)
+    with pytest.raises(RuntimeError):
+        davidson(A, 2, "lowest")

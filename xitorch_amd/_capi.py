@@ -53,6 +53,11 @@ def _declare(L):
         "xk_dense_mm_f64": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),
         "xk_dense_mm_f32": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),
     }
+    for sfx in ("f64", "f32"):
+        sigs["xk_lincomb_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, Lg, D, D, P])
+        sigs["xk_ritz_residual_" + sfx] = (I, [P, P, P, P, P, P, P, I, I, I, I] + [Lg] * 12 + [P])
+        sigs["xk_panel_chol_" + sfx] = (I, [P, P, P, I, I, Lg, Lg, P])
+        sigs["xk_panel_transform_" + sfx] = (I, [P, P, I, I, I, Lg, Lg, P])
     sigs.update(_EXTRA_SIGS)
     for name, (res, args) in sigs.items():
         if not hasattr(L, name):

@@ -1,0 +1,342 @@
+// xitorch_amd :: basis-maintenance kernels of the block eigensolver (K4/K5/K6).
+//
+// The reference recomputes, every Davidson iteration, T = V^T AV over the whole
+// basis, the Ritz rotations V Y / AV Y, the residual and a full CholeskyQR of
+// [V, t] (xitorch/_impls/linalg/symeig.py:170-223, _utils/tensor.py:8-19).
+// Here the basis is stored PANEL-MAJOR, (B, k, N) with every basis vector
+// contiguous, rows are appended in place, and each step is one fused pass:
+//
+//   xk_lincomb        Out[b,c,:] = beta*Out[b,c,:] + alpha * sum_a C[b,a,c] V[b,a,:]
+//   xk_ritz_residual  X = Y^T V, AX = Y^T AV, t = -(AX - lam*X), rmax[b] = max|AX - lam*X|
+//   xk_panel_chol     upper Cholesky of the p x p panel Gram + its inverse (CholeskyQR step)
+//   xk_panel_transform in-place t <- W^T t with W upper triangular
+//   xk_colnorm2 / xk_fill helpers
+//
+// All of them are HBM-bound streams over (k or p) x N panels: 16 B/lane
+// coalesced loads, coefficients are wave-uniform (scalar loads), no atomics
+// except the order-independent max.
+#include "xk_common.h"
+
+namespace xk {
+
+template <typename T, int P>
+__global__ __launch_bounds__(256) void lincomb_kernel(
+    const T* __restrict__ V, const T* __restrict__ C, T* __restrict__ Out,
+    int k, int N, long ldv, long sV, long sC, long sCa, long sCc, long ldo, long sO,
+    T alpha, T beta, int col_tiles) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  const int b = blockIdx.x / col_tiles;
+  const int ct = blockIdx.x - b * col_tiles;
+  const int j = (ct * 256 + threadIdx.x) * VN;
+  if (j >= N) return;
+  const T* Vb = V + (long)b * sV + j;
+  const T* Cb = C + (long)b * sC;
+  VT acc[P];
+#pragma unroll
+  for (int c = 0; c < P; ++c)
+#pragma unroll
+    for (int v = 0; v < VN; ++v) acc[c][v] = T(0);
+  int a = 0;
+  for (; a + 4 <= k; a += 4) {
+    VT v0 = *reinterpret_cast<const VT*>(Vb + (long)(a + 0) * ldv);
+    VT v1 = *reinterpret_cast<const VT*>(Vb + (long)(a + 1) * ldv);
+    VT v2 = *reinterpret_cast<const VT*>(Vb + (long)(a + 2) * ldv);
+    VT v3 = *reinterpret_cast<const VT*>(Vb + (long)(a + 3) * ldv);
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const T c0 = Cb[(long)(a + 0) * sCa + c * sCc], c1 = Cb[(long)(a + 1) * sCa + c * sCc];
+      const T c2 = Cb[(long)(a + 2) * sCa + c * sCc], c3 = Cb[(long)(a + 3) * sCa + c * sCc];
+#pragma unroll
+      for (int v = 0; v < VN; ++v) {
+        acc[c][v] += c0 * v0[v];
+        acc[c][v] += c1 * v1[v];
+        acc[c][v] += c2 * v2[v];
+        acc[c][v] += c3 * v3[v];
+      }
+    }
+  }
+  for (; a < k; ++a) {
+    VT v0 = *reinterpret_cast<const VT*>(Vb + (long)a * ldv);
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const T c0 = Cb[(long)a * sCa + c * sCc];
+#pragma unroll
+      for (int v = 0; v < VN; ++v) acc[c][v] += c0 * v0[v];
+    }
+  }
+  T* Ob = Out + (long)b * sO + j;
+#pragma unroll
+  for (int c = 0; c < P; ++c) {
+    VT o;
+    if (beta != T(0)) {
+      o = *reinterpret_cast<const VT*>(Ob + (long)c * ldo);
+#pragma unroll
+      for (int v = 0; v < VN; ++v) o[v] = beta * o[v] + alpha * acc[c][v];
+    } else {
+#pragma unroll
+      for (int v = 0; v < VN; ++v) o[v] = alpha * acc[c][v];
+    }
+    *reinterpret_cast<VT*>(Ob + (long)c * ldo) = o;
+  }
+}
+
+// fused Ritz rotation + residual + per-batch max-norm
+template <typename T, int P>
+__global__ __launch_bounds__(256) void ritz_residual_kernel(
+    const T* __restrict__ V, const T* __restrict__ AV, const T* __restrict__ Y,
+    const T* __restrict__ lam, T* __restrict__ X, T* __restrict__ Tn, T* __restrict__ rmax,
+    int k, int N, long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam,
+    long ldx, long sX, long ldt, long sT, int col_tiles) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  __shared__ T red[4];
+  const int b = blockIdx.x / col_tiles;
+  const int ct = blockIdx.x - b * col_tiles;
+  const int j = (ct * 256 + threadIdx.x) * VN;
+  const bool active = j < N;
+  T local_max = T(0);
+  if (active) {
+    const T* Vb = V + (long)b * sV + j;
+    const T* AVb = AV + (long)b * sAV + j;
+    const T* Yb = Y + (long)b * sY;
+    VT ax[P], xx[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+      for (int v = 0; v < VN; ++v) { ax[c][v] = T(0); xx[c][v] = T(0); }
+    int a = 0;
+    for (; a + 2 <= k; a += 2) {
+      VT v0 = *reinterpret_cast<const VT*>(Vb + (long)a * ldv);
+      VT v1 = *reinterpret_cast<const VT*>(Vb + (long)(a + 1) * ldv);
+      VT w0 = *reinterpret_cast<const VT*>(AVb + (long)a * ldav);
+      VT w1 = *reinterpret_cast<const VT*>(AVb + (long)(a + 1) * ldav);
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const T y0 = Yb[(long)a * sYa + c * sYc], y1 = Yb[(long)(a + 1) * sYa + c * sYc];
+#pragma unroll
+        for (int v = 0; v < VN; ++v) {
+          xx[c][v] += y0 * v0[v];
+          xx[c][v] += y1 * v1[v];
+          ax[c][v] += y0 * w0[v];
+          ax[c][v] += y1 * w1[v];
+        }
+      }
+    }
+    for (; a < k; ++a) {
+      VT v0 = *reinterpret_cast<const VT*>(Vb + (long)a * ldv);
+      VT w0 = *reinterpret_cast<const VT*>(AVb + (long)a * ldav);
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const T y0 = Yb[(long)a * sYa + c * sYc];
+#pragma unroll
+        for (int v = 0; v < VN; ++v) { xx[c][v] += y0 * v0[v]; ax[c][v] += y0 * w0[v]; }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const T l = lam[(long)b * sLam + c];
+      VT t;
+#pragma unroll
+      for (int v = 0; v < VN; ++v) {
+        const T r = ax[c][v] - l * xx[c][v];
+        t[v] = -r;
+        const T ar = r < T(0) ? -r : r;
+        local_max = ar > local_max ? ar : local_max;
+      }
+      *reinterpret_cast<VT*>(X + (long)b * sX + (long)c * ldx + j) = xx[c];
+      *reinterpret_cast<VT*>(Tn + (long)b * sT + (long)c * ldt + j) = t;
+    }
+  }
+  local_max = wave_max(local_max);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local_max;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T m = red[0];
+    m = red[1] > m ? red[1] : m;
+    m = red[2] > m ? red[2] : m;
+    m = red[3] > m ? red[3] : m;
+    // NaN never compares greater: make it visible as +inf so the host loop cannot "converge" on it
+    if (m != m) m = T(INFINITY);
+    atomic_max_nonneg(rmax + b, m);
+  }
+}
+
+// one thread per batch member: G = R^T R (upper R), W = R^-1.  P <= 32.
+// info[b] = index+1 of the first non-positive pivot (0 = ok) — mirrors the
+// reference, where torch.linalg.cholesky raises on a rank-deficient panel.
+template <typename T>
+__global__ void panel_chol_kernel(const T* __restrict__ G, T* __restrict__ W, int* __restrict__ info,
+                                  int B, int P, long ldg, long sG, long sW) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  T R[32][32];
+  const T* Gb = G + (long)b * sG;
+  int bad = 0;
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) R[i][j] = T(0);
+  for (int j = 0; j < P; ++j) {
+    for (int i = 0; i <= j; ++i) {
+      // symmetrised entry: G is mathematically symmetric, average the two computed halves
+      T s = T(0.5) * (Gb[(long)i * ldg + j] + Gb[(long)j * ldg + i]);
+      for (int m = 0; m < i; ++m) s -= R[m][i] * R[m][j];
+      if (i == j) {
+        if (!(s > T(0))) { if (!bad) bad = j + 1; s = T(1); }
+        R[j][j] = sqrt(s);
+      } else {
+        R[i][j] = s / R[i][i];
+      }
+    }
+  }
+  // W = R^-1 (upper triangular), column by column: R W = I
+  T* Wb = W + (long)b * sW;
+  for (int c = 0; c < P; ++c) {
+    T col[32];
+    for (int i = P - 1; i >= 0; --i) {
+      T s = (i == c) ? T(1) : T(0);
+      for (int m = i + 1; m <= c; ++m) s -= R[i][m] * col[m];
+      col[i] = (i <= c) ? s / R[i][i] : T(0);
+    }
+    for (int i = 0; i < P; ++i) Wb[(long)i * P + c] = col[i];
+  }
+  info[b] = bad;
+}
+
+// in-place t[c,:] <- sum_{a<=c} W[a,c] t[a,:], W upper triangular (B,P,P) row-major.
+// Processing c from high to low keeps the still-needed rows untouched.
+template <typename T>
+__global__ __launch_bounds__(256) void panel_transform_kernel(
+    T* __restrict__ Tp, const T* __restrict__ W, int P, int N, long ldt, long sT, long sW, int col_tiles) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  const int b = blockIdx.x / col_tiles;
+  const int ct = blockIdx.x - b * col_tiles;
+  const int j = (ct * 256 + threadIdx.x) * VN;
+  if (j >= N) return;
+  T* Tb = Tp + (long)b * sT + j;
+  const T* Wb = W + (long)b * sW;
+  for (int c = P - 1; c >= 0; --c) {
+    VT acc;
+#pragma unroll
+    for (int v = 0; v < VN; ++v) acc[v] = T(0);
+    for (int a = 0; a <= c; ++a) {
+      const T w = Wb[(long)a * P + c];
+      VT t = *reinterpret_cast<const VT*>(Tb + (long)a * ldt);
+#pragma unroll
+      for (int v = 0; v < VN; ++v) acc[v] += w * t[v];
+    }
+    *reinterpret_cast<VT*>(Tb + (long)c * ldt) = acc;
+  }
+}
+
+// Panels handed to these kernels must be PADDED: pitch ld a multiple of the 16 B vector width and
+// >= N rounded up to it, batch pitch likewise, base 16 B aligned, pad elements zero.  Lanes then
+// always move whole 16 B vectors; the (zero) pad lanes compute zeros.
+template <typename T>
+static bool vec_ok(int N, long ld, long s, const void* p) {
+  constexpr int VN = Vec16<T>::n;
+  const long npad = ((long)N + VN - 1) / VN * VN;
+  return (ld % VN == 0) && (ld >= npad || ld == 0) && (s % VN == 0) && (((uintptr_t)p & 15) == 0);
+}
+
+template <typename T>
+static int lincomb(const T* V, const T* C, T* Out, int B, int k, int N, int P, long ldv, long sV,
+                   long sC, long sCa, long sCc, long ldo, long sO, T alpha, T beta, hipStream_t st) {
+  constexpr int VN = Vec16<T>::n;
+  if (!vec_ok<T>(N, ldv, sV, V) || !vec_ok<T>(N, ldo, sO, Out)) return XK_ERR_UNSUPPORTED;
+  const int ct = (N + 256 * VN - 1) / (256 * VN);
+  int c0 = 0;
+  while (c0 < P) {
+    const int pc = (P - c0) >= 8 ? 8 : (P - c0);
+    const T* Cc = C + (long)c0 * sCc;
+    T* Oc = Out + (long)c0 * ldo;
+    switch (pc) {
+#define XK_CASE(PP)                                                                                   \
+  case PP:                                                                                            \
+    hipLaunchKernelGGL((lincomb_kernel<T, PP>), dim3((unsigned)((long)B * ct)), dim3(256), 0, st, V, \
+                       Cc, Oc, k, N, ldv, sV, sC, sCa, sCc, ldo, sO, alpha, beta, ct);                \
+    break;
+      XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
+#undef XK_CASE
+    }
+    XK_LAUNCH_CHECK();
+    c0 += pc;
+  }
+  return XK_OK;
+}
+
+template <typename T>
+static int ritz_residual(const T* V, const T* AV, const T* Y, const T* lam, T* X, T* Tn, T* rmax, int B,
+                         int k, int N, int P, long ldv, long sV, long ldav, long sAV, long sY, long sYa,
+                         long sYc, long sLam, long ldx, long sX, long ldt, long sT, hipStream_t st) {
+  constexpr int VN = Vec16<T>::n;
+  if (!vec_ok<T>(N, ldv, sV, V) || !vec_ok<T>(N, ldav, sAV, AV) || !vec_ok<T>(N, ldx, sX, X) ||
+      !vec_ok<T>(N, ldt, sT, Tn))
+    return XK_ERR_UNSUPPORTED;
+  const int ct = (N + 256 * VN - 1) / (256 * VN);
+  int c0 = 0;
+  while (c0 < P) {
+    const int pc = (P - c0) >= 8 ? 8 : (P - c0);
+    switch (pc) {
+#define XK_CASE(PP)                                                                                    \
+  case PP:                                                                                             \
+    hipLaunchKernelGGL((ritz_residual_kernel<T, PP>), dim3((unsigned)((long)B * ct)), dim3(256), 0,   \
+                       st, V, AV, Y + (long)c0 * sYc, lam + c0, X + (long)c0 * ldx, Tn + (long)c0 * ldt, \
+                       rmax, k, N, ldv, sV, ldav, sAV, sY, sYa, sYc, sLam, ldx, sX, ldt, sT, ct);       \
+    break;
+      XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
+#undef XK_CASE
+    }
+    XK_LAUNCH_CHECK();
+    c0 += pc;
+  }
+  return XK_OK;
+}
+
+}  // namespace xk
+
+extern "C" {
+
+#define XK_DEFINE_BASIS(SUF, T)                                                                          \
+  int xk_lincomb_##SUF(const T* V, const T* C, T* Out, int B, int k, int N, int P, long ldv, long sV,    \
+                       long sC, long sCa, long sCc, long ldo, long sO, double alpha, double beta,        \
+                       void* stream) {                                                                   \
+    if (B < 0 || k < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                             \
+    if (B == 0 || N == 0 || P == 0) return XK_OK;                                                        \
+    return xk::lincomb<T>(V, C, Out, B, k, N, P, ldv, sV, sC, sCa, sCc, ldo, sO, (T)alpha, (T)beta,      \
+                          (hipStream_t)stream);                                                          \
+  }                                                                                                      \
+  int xk_ritz_residual_##SUF(const T* V, const T* AV, const T* Y, const T* lam, T* X, T* Tn, T* rmax,    \
+                             int B, int k, int N, int P, long ldv, long sV, long ldav, long sAV,         \
+                             long sY, long sYa, long sYc, long sLam, long ldx, long sX, long ldt,        \
+                             long sT, void* stream) {                                                    \
+    if (B < 0 || k < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                             \
+    if (B == 0 || N == 0 || P == 0) return XK_OK;                                                        \
+    return xk::ritz_residual<T>(V, AV, Y, lam, X, Tn, rmax, B, k, N, P, ldv, sV, ldav, sAV, sY, sYa,     \
+                                sYc, sLam, ldx, sX, ldt, sT, (hipStream_t)stream);                       \
+  }                                                                                                      \
+  int xk_panel_chol_##SUF(const T* G, T* W, int* info, int B, int P, long ldg, long sG, void* stream) {  \
+    if (B < 0 || P < 0 || P > 32) return XK_ERR_ARG;                                                     \
+    if (B == 0 || P == 0) return XK_OK;                                                                  \
+    hipLaunchKernelGGL((xk::panel_chol_kernel<T>), dim3((B + 63) / 64), dim3(64), 0,                     \
+                       (hipStream_t)stream, G, W, info, B, P, ldg, sG, (long)P * P);                     \
+    XK_LAUNCH_CHECK();                                                                                   \
+    return XK_OK;                                                                                        \
+  }                                                                                                      \
+  int xk_panel_transform_##SUF(T* Tp, const T* W, int B, int P, int N, long ldt, long sT,                \
+                               void* stream) {                                                           \
+    if (B < 0 || P < 0 || N < 0) return XK_ERR_ARG;                                                      \
+    if (B == 0 || P == 0 || N == 0) return XK_OK;                                                        \
+    if (!xk::vec_ok<T>(N, ldt, sT, Tp)) return XK_ERR_UNSUPPORTED;                                       \
+    constexpr int VN = xk::Vec16<T>::n;                                                                  \
+    const int ct = (N + 256 * VN - 1) / (256 * VN);                                                      \
+    hipLaunchKernelGGL((xk::panel_transform_kernel<T>), dim3((unsigned)((long)B * ct)), dim3(256), 0,    \
+                       (hipStream_t)stream, Tp, W, P, N, ldt, sT, (long)P * P, ct);                      \
+    XK_LAUNCH_CHECK();                                                                                   \
+    return XK_OK;                                                                                        \
+  }
+
+XK_DEFINE_BASIS(f64, double)
+XK_DEFINE_BASIS(f32, float)
+
+}  // extern "C"

@@ -70,3 +70,64 @@ def dense_mm(A, X, out=None, trans=False, rows_hint=0, stagger=1):
         1 if trans else 0, rows_hint, stagger, stream_ptr())
     check(rc, "xk_dense_mm")
     return out
+
+
+# --------------------------------------------------------------------------- basis kernels
+def _cstrides(C, a_dim, c_dim):
+    """(batch, a, c) strides of a 3-D coefficient tensor whose `a` index is dim a_dim and `c` index dim c_dim."""
+    return C.stride(0), C.stride(a_dim), C.stride(c_dim)
+
+
+def lincomb(V, C, out, k, P, coef_layout="ac", alpha=1.0, beta=0.0):
+    """out[b,c,:] = beta*out[b,c,:] + alpha * sum_{a<k} C[b,a,c] * V[b,a,:]
+
+    V: (B, >=k, Npad) panel-major padded basis; out: (B, >=P, Npad) panel-major.
+    C: 3-D coefficients; coef_layout "ac" means C[b,a,c], "ca" means C[b,c,a] (e.g. a Gram block
+    straight out of dense_mm).  Replaces the Ritz rotations `V @ Y` (symeig.py:178,181) and the
+    projections of the block Gram-Schmidt step that stands in for tallqr (_utils/tensor.py:15-18).
+    """
+    require_device(V, "basis")
+    B, N = V.shape[0], V.shape[2]
+    ldv, sV = V.stride(1), V.stride(0)
+    ldo, sO = out.stride(1), out.stride(0)
+    if coef_layout == "ac":
+        sC, sCa, sCc = _cstrides(C, 1, 2)
+    else:
+        sC, sCa, sCc = _cstrides(C, 2, 1)
+    rc = fn("xk_lincomb_" + suffix(V.dtype))(ptr(V), ptr(C), ptr(out), B, k, N, P, ldv, sV, sC, sCa, sCc,
+                                              ldo, sO, float(alpha), float(beta), stream_ptr())
+    check(rc, "xk_lincomb")
+    return out
+
+
+def ritz_residual(V, AV, Y, lam, X, Tn, rmax, k, P):
+    """Fused K4/K5 (symeig.py:178-188): X = Y^T V, AX = Y^T AV, Tn = -(AX - lam X), rmax[b] = max|AX - lam X|.
+
+    Y: (B, k, >=P) eigenvector coefficients (any strides), lam: (B, >=P) with unit stride along P,
+    rmax: (B,) zero-initialised by the caller.
+    """
+    B, N = V.shape[0], V.shape[2]
+    if lam.stride(-1) != 1 and P > 1:
+        raise _capi.NativeLibraryError("lam must have unit stride along its last dim")
+    rc = fn("xk_ritz_residual_" + suffix(V.dtype))(
+        ptr(V), ptr(AV), ptr(Y), ptr(lam), ptr(X), ptr(Tn), ptr(rmax), B, k, N, P,
+        V.stride(1), V.stride(0), AV.stride(1), AV.stride(0), Y.stride(0), Y.stride(1), Y.stride(2),
+        lam.stride(0), X.stride(1), X.stride(0), Tn.stride(1), Tn.stride(0), stream_ptr())
+    check(rc, "xk_ritz_residual")
+
+
+def panel_chol(G, W, info, P):
+    """W[b] = R^-1 with G[b] = R^T R (upper R); info[b] != 0 flags a non-positive pivot.
+    G: (B, >=P, >=P) with unit stride along its last dim.  CholeskyQR step of tallqr (tensor.py:16-17)."""
+    B = G.shape[0]
+    rc = fn("xk_panel_chol_" + suffix(G.dtype))(ptr(G), ptr(W), ptr(info), B, P, G.stride(1), G.stride(0),
+                                                 stream_ptr())
+    check(rc, "xk_panel_chol")
+
+
+def panel_transform(Tp, W, P):
+    """In place Tp[b,c,:] <- sum_{a<=c} W[b,a,c] Tp[b,a,:]  (tensor.py:18, Q = V R^-1 for the new panel only)."""
+    B, N = Tp.shape[0], Tp.shape[2]
+    rc = fn("xk_panel_transform_" + suffix(Tp.dtype))(ptr(Tp), ptr(W), B, P, N, Tp.stride(1), Tp.stride(0),
+                                                      stream_ptr())
+    check(rc, "xk_panel_transform")

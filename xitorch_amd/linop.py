@@ -1,0 +1,666 @@
+"""LinearOperator — the batched implicit-operator contract, with MI355X-native dense and
+banded operators underneath.
+
+Drop-in for the reference's operator contract (xitorch/_core/linop.py:15-812): subclass,
+call ``super().__init__(shape, is_hermitian, dtype, device)``, implement ``_mv`` (mandatory) and
+optionally ``_mm/_rmv/_rmm/_fullmatrix/_getparamnames``; ``mv/mm/rmv/rmm/fullmatrix/H/matmul/
++ - *`` and ``check()`` behave as in the reference, including the error messages.
+
+What is different underneath: ``MatrixLinearOperator`` (what ``LinearOperator.m(mat)`` returns)
+and ``BandedLinearOperator`` apply themselves through the hand-written HIP kernels of
+libxitorch_amd.so whenever their tensors live on a HIP device (K1, xk_dense_mm / xk_banded_mm),
+wrapped in ``torch.autograd.Function`` so they stay differentiable to any order.  On a HIP
+device there is no fallback: a missing library raises.  Host (CPU) tensors are served by plain
+torch so that the operator algebra and the dense/exact methods remain usable for host-side
+checks; the native iterative methods refuse CPU operators.
+"""
+import traceback
+import warnings
+from abc import abstractmethod
+from contextlib import contextmanager
+import torch
+from xitorch_amd.editable import EditableModule
+from xitorch_amd.debug import is_debug_enabled
+from xitorch_amd._util import bcast_shape
+from xitorch_amd import kernels as _k
+
+__all__ = ["LinearOperator", "MatrixLinearOperator", "BandedLinearOperator"]
+
+_OPTIONAL = ("_mm", "_rmv", "_rmm", "_fullmatrix", "_getparamnames")
+
+
+class LinearOperator(EditableModule):
+    """Base class of operators of shape ``(*B, p, q)`` defined by their action.
+
+    See the module docstring; reference: xitorch/_core/linop.py:15-552.
+    """
+    _is_mv_implemented = False
+    _is_mm_implemented = False
+    _is_rmv_implemented = False
+    _is_rmm_implemented = False
+    _is_fullmatrix_implemented = False
+    _is_gpn_implemented = False
+
+    def __new__(cls, *args, **kwargs):
+        # detect once per concrete class which optional methods are overridden
+        if "_impl_checked_" not in cls.__dict__:
+            def overridden(name):
+                return getattr(cls, name) is not getattr(LinearOperator, name)
+            cls._is_mv_implemented = overridden("_mv")
+            cls._is_mm_implemented = overridden("_mm")
+            cls._is_rmv_implemented = overridden("_rmv")
+            cls._is_rmm_implemented = overridden("_rmm")
+            cls._is_fullmatrix_implemented = overridden("_fullmatrix")
+            cls._is_gpn_implemented = overridden("_getparamnames")
+            cls._impl_checked_ = True
+            if not cls._is_mv_implemented:
+                raise RuntimeError("LinearOperator must have at least _mv(self) method implemented")
+        return super(LinearOperator, cls).__new__(cls)
+
+    @classmethod
+    def m(cls, mat, is_hermitian=None):
+        """Wrap a (batched) matrix; ``is_hermitian=None`` checks the symmetry, ``True`` asserts it
+        (reference: linop.py:59-107)."""
+        if is_hermitian is None:
+            is_hermitian = mat.shape[-2] == mat.shape[-1] and _is_hermitian_matrix(mat)
+        elif is_hermitian:
+            if not _is_hermitian_matrix(mat):
+                raise RuntimeError("The linear operator is indicated to be hermitian, but the matrix is not")
+        return MatrixLinearOperator(mat, is_hermitian)
+
+    def __init__(self, shape, is_hermitian=False, dtype=None, device=None, _suppress_hermit_warning=False):
+        super(LinearOperator, self).__init__()
+        if len(shape) < 2:
+            raise RuntimeError("The shape must have at least 2 dimensions")
+        self._shape = shape
+        self._batchshape = list(shape[:-2])
+        self._is_hermitian = is_hermitian
+        self._dtype = dtype if dtype is not None else torch.float32
+        self._device = device if device is not None else torch.device("cpu")
+        if is_hermitian and shape[-1] != shape[-2]:
+            raise RuntimeError("The object is indicated as Hermitian, but the shape is not square")
+        if not _suppress_hermit_warning and is_hermitian and \
+                (self._is_rmv_implemented or self._is_rmm_implemented):
+            warnings.warn("The LinearOperator is Hermitian with implemented rmv or rmm. We will use the "
+                          "mv and mm methods instead", stacklevel=2)
+
+    def __repr__(self):
+        return "LinearOperator (%s) with shape %s, dtype = %s, device = %s" % \
+            (self.__class__.__name__, _shape2str(self.shape), self.dtype, self.device)
+
+    # ------------------------------------------------------------ to be implemented by subclasses
+    @abstractmethod
+    def _getparamnames(self, prefix=""):
+        return []
+
+    @abstractmethod
+    def _mv(self, x):
+        pass
+
+    def _rmv(self, x):
+        raise NotImplementedError()
+
+    def _mm(self, x):
+        raise NotImplementedError()
+
+    def _rmm(self, x):
+        raise NotImplementedError()
+
+    def _fullmatrix(self):
+        raise NotImplementedError()
+
+    # ------------------------------------------------------------ parameters
+    def getlinopparams(self):
+        return self.getuniqueparams("mm")
+
+    @contextmanager
+    def uselinopparams(self, *params):
+        # NOTE: swaps the attributes of this object in place (not re-entrant), exactly like the
+        # reference (linop.py:204-212); native operators therefore read their tensors at call time.
+        saved = self.getuniqueparams("mm")
+        try:
+            self.setuniqueparams("mm", *params)
+            yield self
+        finally:
+            self.setuniqueparams("mm", *saved)
+
+    def getparamnames(self, methodname, prefix=""):
+        if methodname in ("mv", "rmv", "mm", "rmm", "fullmatrix"):
+            return self._getparamnames(prefix=prefix)
+        raise KeyError("getparamnames for method %s is not implemented" % methodname)
+
+    # ------------------------------------------------------------ the operator actions
+    def _need_init(self):
+        if "_shape" not in self.__dict__:
+            raise RuntimeError("super().__init__ must be executed first")
+
+    def mv(self, x):
+        """``A x`` for ``x`` of shape ``(..., q)`` (batch dims broadcastable)."""
+        self._need_init()
+        if x.shape[-1] != self.shape[-1]:
+            raise RuntimeError("Cannot operate .mv on shape %s. Expected (...,%d)" %
+                               (str(tuple(x.shape)), self.shape[-1]))
+        return self._mv(x)
+
+    def mm(self, x):
+        """``A X`` for ``X`` of shape ``(..., q, r)``."""
+        self._need_init()
+        if x.shape[-2] != self.shape[-1]:
+            raise RuntimeError("Cannot operate .mm on shape %s. Expected (...,%d,*)" %
+                               (str(tuple(x.shape)), self.shape[-1]))
+        if self._is_mm_implemented:
+            return self._mm(x)
+        return self._columns_through(self._mv, x)
+
+    def rmv(self, x):
+        """``A^H x`` for ``x`` of shape ``(..., p)``."""
+        self._need_init()
+        if x.shape[-1] != self.shape[-2]:
+            raise RuntimeError("Cannot operate .rmv on shape %s. Expected (...,%d)" %
+                               (str(tuple(x.shape)), self.shape[-2]))
+        if self._is_hermitian:
+            return self._mv(x)
+        if not self._is_rmv_implemented:
+            return self._rmv_by_autograd(x)
+        return self._rmv(x)
+
+    def rmm(self, x):
+        """``A^H X`` for ``X`` of shape ``(..., p, r)``."""
+        self._need_init()
+        if x.shape[-2] != self.shape[-2]:
+            raise RuntimeError("Cannot operate .rmm on shape %s. Expected (...,%d,*)" %
+                               (str(tuple(x.shape)), self.shape[-2]))
+        if self._is_hermitian:
+            return self.mm(x)
+        if self._is_rmm_implemented:
+            return self._rmm(x)
+        return self._columns_through(self._rmv if self._is_rmv_implemented else self.rmv, x)
+
+    def _columns_through(self, vecfn, x):
+        # matrix product through the batched vector product: the column axis goes to the front
+        # as an extra batch dim (so `_mv` may see extra leading dims and strided input, Q13)
+        xb = list(x.shape[:-2])
+        if len(xb) < len(self._batchshape):
+            xb = [1] * (len(self._batchshape) - len(xb)) + xb
+        cols_first = x.reshape(1, *xb, *x.shape[-2:]).transpose(0, -1).squeeze(-1)   # (r, ..., q)
+        y = vecfn(cols_first)                                                        # (r, ..., p)
+        return y.unsqueeze(-1).transpose(0, -1).squeeze(0)
+
+    def _rmv_by_autograd(self, xt):
+        # A^H x as the vector-Jacobian product of x -> A x  (reference: linop.py:524-543)
+        bshape = bcast_shape(xt.shape[:-1], self.shape[:-2])
+        p, q = self.shape[-2:]
+        probe = torch.zeros((*bshape, q), dtype=xt.dtype, device=xt.device).requires_grad_()
+        with torch.enable_grad():
+            y = self.mv(probe)
+        return torch.autograd.grad(y, probe, grad_outputs=xt.contiguous().expand_as(y),
+                                   create_graph=torch.is_grad_enabled())[0]
+
+    def fullmatrix(self):
+        if self._is_fullmatrix_implemented:
+            return self._fullmatrix()
+        self._need_init()
+        eye = torch.eye(self._shape[-1], dtype=self._dtype, device=self._device)
+        return self.mm(eye)
+
+    def scipy_linalg_op(self):
+        from scipy.sparse.linalg import LinearOperator as _SpOp
+        tt = lambda v: torch.tensor(v, dtype=self.dtype, device=self.device)
+        npy = lambda t: t.detach().cpu().numpy()
+        return _SpOp(shape=self.shape,
+                     matvec=lambda v: npy(self.mv(tt(v))), rmatvec=lambda v: npy(self.rmv(tt(v))),
+                     matmat=lambda v: npy(self.mm(tt(v))), rmatmat=lambda v: npy(self.rmm(tt(v))))
+
+    # ------------------------------------------------------------ algebra
+    @property
+    def H(self):
+        """The adjoint operator."""
+        if self._is_hermitian:
+            return self
+        if isinstance(self, MatrixLinearOperator):
+            return LinearOperator.m(self.fullmatrix().transpose(-2, -1).conj())
+        return AdjointLinearOperator(self)
+
+    def matmul(self, b, is_hermitian=False):
+        """The operator ``self @ b``."""
+        if self.shape[-1] != b.shape[-2]:
+            raise RuntimeError("Mismatch shape of matmul operation: %s and %s" % (self.shape, b.shape))
+        if isinstance(self, MatrixLinearOperator) and isinstance(b, MatrixLinearOperator):
+            return LinearOperator.m(self.fullmatrix() @ b.fullmatrix(), is_hermitian=is_hermitian)
+        return MatmulLinearOperator(self, b, is_hermitian=is_hermitian)
+
+    def __add__(self, b):
+        assert isinstance(b, LinearOperator), "Only addition with another LinearOperator is supported"
+        if self.shape[-2:] != b.shape[-2:]:
+            raise RuntimeError("Mismatch shape of add operation: %s and %s" % (self.shape, b.shape))
+        if isinstance(self, MatrixLinearOperator) and isinstance(b, MatrixLinearOperator):
+            return LinearOperator.m(self.fullmatrix() + b.fullmatrix())
+        return AddLinearOperator(self, b)
+
+    def __sub__(self, b):
+        assert isinstance(b, LinearOperator), "Only subtraction with another LinearOperator is supported"
+        if self.shape[-2:] != b.shape[-2:]:
+            raise RuntimeError("Mismatch shape of add operation: %s and %s" % (self.shape, b.shape))
+        if isinstance(self, MatrixLinearOperator) and isinstance(b, MatrixLinearOperator):
+            return LinearOperator.m(self.fullmatrix() - b.fullmatrix())
+        return AddLinearOperator(self, b, -1)
+
+    def __rsub__(self, b):
+        return b.__sub__(self)
+
+    def __mul__(self, f):
+        if not isinstance(f, (int, float)):
+            raise TypeError("LinearOperator multiplication only supports integer or floating point")
+        if isinstance(self, MatrixLinearOperator):
+            return LinearOperator.m(self.fullmatrix() * f)
+        return MulLinearOperator(self, f)
+
+    def __rmul__(self, f):
+        return self.__mul__(f)
+
+    # ------------------------------------------------------------ properties
+    dtype = property(lambda self: self._dtype)
+    device = property(lambda self: self._device)
+    shape = property(lambda self: self._shape)
+    is_hermitian = property(lambda self: self._is_hermitian)
+    is_mv_implemented = property(lambda self: True)
+    is_mm_implemented = property(lambda self: self._is_mm_implemented)
+    is_rmv_implemented = property(lambda self: self._is_rmv_implemented)
+    is_rmm_implemented = property(lambda self: self._is_rmm_implemented)
+    is_fullmatrix_implemented = property(lambda self: self._is_fullmatrix_implemented)
+    is_getparamnames_implemented = property(lambda self: self._is_gpn_implemented)
+
+    # ------------------------------------------------------------ debugging
+    def check(self, warn=None):
+        """Exercise mv/mm/rmv/rmm on all the shapes the functionals may use and test linearity
+        (reference: linop.py:492-521, 710-802)."""
+        if warn is None:
+            warn = not is_debug_enabled()
+        if warn:
+            warnings.warn("The linear operator check is performed. This might slow down your program.",
+                          stacklevel=2)
+        checklinop(self)
+        print("Check linear operator done")
+
+
+# ------------------------------------------------------------------------ composed operators
+class AdjointLinearOperator(LinearOperator):
+    def __init__(self, obj):
+        super().__init__(shape=(*obj.shape[:-2], obj.shape[-1], obj.shape[-2]), is_hermitian=obj.is_hermitian,
+                         dtype=obj.dtype, device=obj.device, _suppress_hermit_warning=True)
+        self.obj = obj
+
+    def __repr__(self):
+        return "AdjointLinearOperator with shape %s of:\n - %s" % (_shape2str(self.shape), _indent(repr(self.obj), 3))
+
+    def _mv(self, x):
+        if not self.obj.is_rmv_implemented:
+            raise RuntimeError("The ._rmv of must be implemented to call .H.mv()")
+        return self.obj._rmv(x)
+
+    def _rmv(self, x):
+        return self.obj._mv(x)
+
+    def _getparamnames(self, prefix=""):
+        return self.obj._getparamnames(prefix=prefix + "obj.")
+
+    @property
+    def H(self):
+        return self.obj
+
+
+class MatmulLinearOperator(LinearOperator):
+    def __init__(self, a, b, is_hermitian=False):
+        super().__init__(shape=(*bcast_shape(a.shape[:-2], b.shape[:-2]), a.shape[-2], b.shape[-1]),
+                         is_hermitian=is_hermitian, dtype=a.dtype, device=a.device, _suppress_hermit_warning=True)
+        self.a, self.b = a, b
+
+    def __repr__(self):
+        return "MatmulLinearOperator with shape %s of:\n * %s\n * %s" % \
+            (_shape2str(self.shape), _indent(repr(self.a), 3), _indent(repr(self.b), 3))
+
+    def _mv(self, x):
+        return self.a._mv(self.b._mv(x))
+
+    def _rmv(self, x):
+        return self.b.rmv(self.a.rmv(x))
+
+    def _getparamnames(self, prefix=""):
+        return self.a._getparamnames(prefix=prefix + "a.") + self.b._getparamnames(prefix=prefix + "b.")
+
+
+class AddLinearOperator(LinearOperator):
+    def __init__(self, a, b, mul=1):
+        super().__init__(shape=(*bcast_shape(a.shape[:-2], b.shape[:-2]), a.shape[-2], b.shape[-1]),
+                         is_hermitian=a.is_hermitian and b.is_hermitian, dtype=a.dtype, device=a.device,
+                         _suppress_hermit_warning=True)
+        assert mul == 1 or mul == -1
+        self.a, self.b, self.mul = a, b, mul
+
+    def __repr__(self):
+        return "AddLinearOperator with shape %s of:\n * %s\n * %s" % \
+            (_shape2str(self.shape), _indent(repr(self.a), 3), _indent(repr(self.b), 3))
+
+    def _mv(self, x):
+        return self.a._mv(x) + self.mul * self.b._mv(x)
+
+    def _rmv(self, x):
+        return self.a.rmv(x) + self.mul * self.b.rmv(x)
+
+    def _getparamnames(self, prefix=""):
+        return self.a._getparamnames(prefix=prefix + "a.") + self.b._getparamnames(prefix=prefix + "b.")
+
+
+class MulLinearOperator(LinearOperator):
+    def __init__(self, a, f):
+        super().__init__(shape=a.shape, is_hermitian=a.is_hermitian, dtype=a.dtype, device=a.device,
+                         _suppress_hermit_warning=True)
+        self.a, self.f = a, f
+
+    def __repr__(self):
+        return "MulLinearOperator with shape %s of: \n * %s\n * %s" % \
+            (_shape2str(self.shape), _indent(repr(self.a), 3), _indent(repr(self.f), 3))
+
+    def _mv(self, x):
+        return self.a._mv(x) * self.f
+
+    def _rmv(self, x):
+        return self.a._rmv(x) * self.f
+
+    def _getparamnames(self, prefix=""):
+        return self.a._getparamnames(prefix=prefix + "a.")
+
+
+# ------------------------------------------------------------------------ native dense operator
+def _native_dtype(t):
+    return t.is_cuda and t.dtype in (torch.float64, torch.float32)
+
+
+def _sum_to_shape(t, shape):
+    """Reduce a broadcast gradient back to ``shape``."""
+    shape = tuple(shape)
+    if tuple(t.shape) == shape:
+        return t
+    lead = t.dim() - len(shape)
+    if lead > 0:
+        t = t.sum(dim=tuple(range(lead)))
+    dims = tuple(i for i, (a, b) in enumerate(zip(t.shape, shape)) if a != b)
+    if dims:
+        t = t.sum(dim=dims, keepdim=True)
+    return t
+
+
+def dense_apply(mat, x, trans=False):
+    """``mat @ x`` (or ``mat^T @ x``) through the K1 HIP kernel for HIP float tensors.
+
+    mat ``(*BA, M, N)``, x ``(*BX, n_in, r)`` with broadcastable batch dims.  Batch dims along
+    which only ``x`` varies are folded into the panel width so the operator is streamed once.
+    Never copies ``mat`` when it is contiguous or a transposed view of a contiguous matrix.
+    """
+    if mat.stride(-1) != 1 and mat.stride(-2) == 1 and mat.dim() >= 2:
+        mat, trans = mat.transpose(-2, -1), not trans      # a transposed view: flip the kernel
+    M, N = mat.shape[-2:]
+    n_in, n_out = (M, N) if trans else (N, M)
+    r = x.shape[-1]
+    BA, BX = list(mat.shape[:-2]), list(x.shape[:-2])
+    nb = max(len(BA), len(BX))
+    BAp = [1] * (nb - len(BA)) + BA
+    BXp = [1] * (nb - len(BX)) + BX
+    FB = bcast_shape(BAp, BXp)
+    keep = [d for d in range(nb) if BAp[d] == FB[d]]
+    fold = [d for d in range(nb) if BAp[d] != FB[d]]
+    nkeep = 1
+    for d in keep:
+        nkeep *= FB[d]
+    xe = x.reshape(*BXp, n_in, r).expand(*FB, n_in, r)
+    xp = xe.permute(*keep, *fold, nb + 1, nb).reshape(nkeep, -1, n_in)      # panel-major copy
+    if xp.stride(-1) != 1 or (xp.shape[1] > 1 and xp.stride(1) < n_in):
+        xp = xp.contiguous()
+    matf = mat.reshape(-1, M, N) if mat.is_contiguous() else mat.contiguous().reshape(-1, M, N)
+    y = _k.dense_mm(matf, xp, trans=trans)                                   # (nkeep, P, n_out)
+    y = y.reshape(*[FB[d] for d in keep], *[FB[d] for d in fold], r, n_out)
+    inv = [0] * (nb + 2)
+    for pos, d in enumerate(keep + fold + [nb + 1, nb]):
+        inv[d] = pos
+    return y.permute(*inv)
+
+
+class _DenseMM(torch.autograd.Function):
+    """Differentiable wrapper of the native dense apply (any order: backward re-enters itself)."""
+
+    @staticmethod
+    def forward(ctx, mat, x, trans):
+        ctx.save_for_backward(mat, x)
+        ctx.trans = trans
+        return dense_apply(mat, x, trans)
+
+    @staticmethod
+    def backward(ctx, gy):
+        mat, x = ctx.saved_tensors
+        gmat = gx = None
+        if ctx.needs_input_grad[1]:
+            gx = _sum_to_shape(_DenseMM.apply(mat, gy, not ctx.trans), x.shape)
+        if ctx.needs_input_grad[0]:
+            # the B*N^2 outer product is only materialised when the operator itself needs a gradient
+            outer = torch.matmul(x, gy.transpose(-2, -1)) if ctx.trans else torch.matmul(gy, x.transpose(-2, -1))
+            gmat = _sum_to_shape(outer, mat.shape)
+        return gmat, gx, None
+
+
+def _dense_mm(mat, x, trans):
+    if _native_dtype(mat) and x.dtype == mat.dtype:
+        if not x.is_cuda:
+            raise RuntimeError("operator lives on %s but the operand on %s" % (mat.device, x.device))
+        return _DenseMM.apply(mat, x, trans)
+    # host tensors / complex dtypes: plain torch (not the accelerated path)
+    op = mat.transpose(-2, -1).conj() if trans else mat
+    return torch.matmul(op, x)
+
+
+class MatrixLinearOperator(LinearOperator):
+    """Dense operator.  HIP float32/float64 matrices are applied by the K1 kernel
+    (replaces linop.py:676-708 of the reference)."""
+
+    def __init__(self, mat, is_hermitian):
+        super().__init__(shape=mat.shape, is_hermitian=is_hermitian, dtype=mat.dtype, device=mat.device,
+                         _suppress_hermit_warning=True)
+        self.mat = mat
+
+    def __repr__(self):
+        return "MatrixLinearOperator with shape %s:\n   %s" % (_shape2str(self.shape), _indent(repr(self.mat), 3))
+
+    def _mv(self, x):
+        return _dense_mm(self.mat, x.unsqueeze(-1), False).squeeze(-1)
+
+    def _mm(self, x):
+        return _dense_mm(self.mat, x, False)
+
+    def _rmv(self, x):
+        return _dense_mm(self.mat, x.unsqueeze(-1), True).squeeze(-1)
+
+    def _rmm(self, x):
+        return _dense_mm(self.mat, x, True)
+
+    def _fullmatrix(self):
+        return self.mat
+
+    def _getparamnames(self, prefix=""):
+        return [prefix + "mat"]
+
+
+# ------------------------------------------------------------------------ native banded operator
+def banded_apply_torch(band, x, trans=False):
+    """Reference semantics of the banded apply in plain torch (host tensors)."""
+    nd, n = band.shape[-2:]
+    hb = nd // 2
+    y = torch.zeros((*bcast_shape(band.shape[:-2], x.shape[:-2]), *x.shape[-2:]), dtype=x.dtype, device=x.device)
+    for d in range(nd):
+        off = d - hb
+        lo, hi = max(0, -off), min(n, n - off)
+        if hi <= lo:
+            continue
+        coef = band[..., d, lo:hi].unsqueeze(-1)
+        if not trans:
+            y[..., lo:hi, :] += coef * x[..., lo + off:hi + off, :]
+        else:
+            y[..., lo + off:hi + off, :] += coef.conj() * x[..., lo:hi, :]
+    return y
+
+
+class _BandedMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, band, x, trans):
+        ctx.save_for_backward(band, x)
+        ctx.trans = trans
+        return _banded_native(band, x, trans)
+
+    @staticmethod
+    def backward(ctx, gy):
+        band, x = ctx.saved_tensors
+        gband = gx = None
+        if ctx.needs_input_grad[1]:
+            gx = _sum_to_shape(_BandedMM.apply(band, gy, not ctx.trans), x.shape)
+        if ctx.needs_input_grad[0]:
+            # d/dband[d,i] = sum_c gy[i,c] x[i+off,c]  (trans: gy[i+off,c] x[i,c]) — one strided product per diagonal
+            nd, n = band.shape[-2:]
+            hb = nd // 2
+            rows = []
+            for d in range(nd):
+                off = d - hb
+                lo, hi = max(0, -off), min(n, n - off)
+                g = torch.zeros((*bcast_shape(gy.shape[:-2], x.shape[:-2]), n), dtype=gy.dtype, device=gy.device)
+                if hi > lo:
+                    if not ctx.trans:
+                        g[..., lo:hi] = (gy[..., lo:hi, :] * x[..., lo + off:hi + off, :]).sum(-1)
+                    else:
+                        g[..., lo:hi] = (gy[..., lo + off:hi + off, :] * x[..., lo:hi, :]).sum(-1)
+                rows.append(g)
+            gband = _sum_to_shape(torch.stack(rows, dim=-2), band.shape)
+        return gband, gx, None
+
+
+def _banded_native(band, x, trans):
+    nd, n = band.shape[-2:]
+    r = x.shape[-1]
+    BA, BX = list(band.shape[:-2]), list(x.shape[:-2])
+    nb = max(len(BA), len(BX))
+    BAp = [1] * (nb - len(BA)) + BA
+    BXp = [1] * (nb - len(BX)) + BX
+    FB = bcast_shape(BAp, BXp)
+    keep = [d for d in range(nb) if BAp[d] == FB[d]]
+    fold = [d for d in range(nb) if BAp[d] != FB[d]]
+    nkeep = 1
+    for d in keep:
+        nkeep *= FB[d]
+    xe = x.reshape(*BXp, n, r).expand(*FB, n, r)
+    xp = xe.permute(*keep, *fold, nb + 1, nb).reshape(nkeep, -1, n).contiguous()
+    bandf = band.contiguous().reshape(-1, nd, n)
+    y = _k.banded_mm(bandf, xp, trans=trans)
+    y = y.reshape(*[FB[d] for d in keep], *[FB[d] for d in fold], r, n)
+    inv = [0] * (nb + 2)
+    for pos, d in enumerate(keep + fold + [nb + 1, nb]):
+        inv[d] = pos
+    return y.permute(*inv)
+
+
+class BandedLinearOperator(LinearOperator):
+    """Square banded operator in DIA storage: ``band (*B, 2*hb+1, N)``, ``band[..., d, i] = A[i, i+d-hb]``
+    (entries outside the matrix are ignored).  Not present in the reference — there a user would
+    write the same thing as a custom ``_mv`` (cf. ``ALarge``, _tests/test_linop_fcns.py:129-150); it
+    is the operator of BASELINE.json configs[2] and is applied by the xk_banded_mm HIP kernel."""
+
+    def __init__(self, band, is_hermitian=False):
+        nd, n = band.shape[-2:]
+        if nd % 2 != 1:
+            raise RuntimeError("The band must have an odd number (2*hb+1) of diagonals")
+        super().__init__(shape=(*band.shape[:-2], n, n), is_hermitian=is_hermitian, dtype=band.dtype,
+                         device=band.device, _suppress_hermit_warning=True)
+        self.band = band
+
+    def _apply(self, x, trans):
+        if _native_dtype(self.band) and x.dtype == self.band.dtype:
+            return _BandedMM.apply(self.band, x, trans)
+        return banded_apply_torch(self.band, x, trans)
+
+    def _mv(self, x):
+        return self._apply(x.unsqueeze(-1), False).squeeze(-1)
+
+    def _mm(self, x):
+        return self._apply(x, False)
+
+    def _rmv(self, x):
+        return self._apply(x.unsqueeze(-1), True).squeeze(-1)
+
+    def _rmm(self, x):
+        return self._apply(x, True)
+
+    def _getparamnames(self, prefix=""):
+        return [prefix + "band"]
+
+
+# ------------------------------------------------------------------------ helpers
+def _is_hermitian_matrix(mat):
+    if mat.shape[-2] != mat.shape[-1]:
+        return False
+    if mat.numel() <= (1 << 24) or mat.dim() == 2:
+        return bool(torch.allclose(mat, mat.transpose(-2, -1).conj()))
+    # large batched matrices: one member at a time, to bound the temporaries
+    flat = mat.reshape(-1, *mat.shape[-2:])
+    for i in range(flat.shape[0]):
+        if not torch.allclose(flat[i], flat[i].transpose(-2, -1).conj()):
+            return False
+    return True
+
+
+def checklinop(linop):
+    """Shape / linearity / batching checks of an operator (reference: linop.py:710-802)."""
+    shape = linop.shape
+    p, q = shape[-2:]
+    bs = tuple(shape[:-2])
+
+    def runtest(name, xshape, yshape):
+        x = torch.rand(xshape, dtype=linop.dtype, device=linop.device)
+        fcn = getattr(linop, name)
+        try:
+            y = fcn(x)
+        except Exception:
+            raise RuntimeError("An error is raised from .%s with input shape: %s (linear operator shape: %s)\n"
+                               "--- full traceback ---\n%s" % (name, tuple(xshape), tuple(linop.shape),
+                                                               traceback.format_exc()))
+        assert list(y.shape) == list(yshape), \
+            "The output shape of .%s is not correct. Input: %s, expected output: %s, output: %s\n%s" % \
+            (name, tuple(x.shape), tuple(yshape), tuple(y.shape), str(linop))
+        x2 = 1.25 * x
+        y2 = fcn(x2)
+        assert torch.allclose(y2, 1.25 * y), "Linearity check fails\n%s\n" % str(linop)
+        assert torch.allclose(fcn(0 * x), y * 0), "Linearity check (with 0) fails\n" + str(linop)
+        both = fcn(torch.stack((x, x2), dim=0))
+        msg = "Batched test fails (expanding batches changes the results)" + str(linop)
+        assert torch.allclose(both[0], y), msg
+        assert torch.allclose(both[1], y2), msg
+
+    def shapes(inner, outer):
+        xs = [(inner,), (1, inner), (1, 1, inner), (*bs, inner), (1, *bs, inner)]
+        ys = [(*bs, outer), (*bs, outer) if len(bs) >= 1 else (1, outer),
+              (*bs, outer) if len(bs) >= 2 else (1, 1, outer), (*bs, outer), (1, *bs, outer)]
+        return zip(xs, ys)
+
+    r = 2
+    for xs, ys in shapes(q, p):
+        runtest("mv", xs, ys)
+        runtest("mm", (*xs, r), (*ys, r))
+    if not linop.is_rmv_implemented:
+        return
+    for xs, ys in shapes(p, q):
+        runtest("rmv", xs, ys)
+        runtest("rmm", (*xs, r), (*ys, r))
+
+
+def _indent(s, nspace):
+    pad = " " * nspace
+    lines = s.split("\n")
+    return "\n".join([lines[0]] + [pad + ln for ln in lines[1:]])
+
+
+def _shape2str(shape):
+    return "(%s)" % (", ".join(str(s) for s in shape))
