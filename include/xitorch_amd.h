@@ -54,6 +54,49 @@ int xk_dense_mm_f32(const float* A, const float* X, float* Y, float* ws, long ws
                     int B, int M, int N, int P, long lda, long sA, long ldx, long sX,
                     long ldy, long sY, int trans, int rows_hint, int stagger, void* stream);
 
+/* ---- basis maintenance of the block eigensolver (K2/K4/K5/K6) ------------------------------
+ * Panels must be PADDED: pitch a multiple of 16 B and >= N rounded up to 16 B, pads zero.
+ *
+ * xk_lincomb:  Out[b,c,:] = beta*Out[b,c,:] + alpha * sum_{a<k} C[b,a,c] V[b,a,:]
+ *   C element (b,a,c) at C[b*sC + a*sCa + c*sCc].  Replaces the Ritz rotations `V @ Y`
+ *   (xitorch/_impls/linalg/symeig.py:178,181) and the projection step standing in for the full
+ *   CholeskyQR `tallqr` (xitorch/_utils/tensor.py:15-18). */
+int xk_lincomb_f64(const double* V, const double* C, double* Out, int B, int k, int N, int P,
+                   long ldv, long sV, long sC, long sCa, long sCc, long ldo, long sO,
+                   double alpha, double beta, void* stream);
+int xk_lincomb_f32(const float* V, const float* C, float* Out, int B, int k, int N, int P,
+                   long ldv, long sV, long sC, long sCa, long sCc, long ldo, long sO,
+                   double alpha, double beta, void* stream);
+/* xk_ritz_residual (fused K4/K5, symeig.py:178-188,207):
+ *   X[b,c,:] = sum_a Y[b,a,c] V[b,a,:];  AX likewise from AV;  Tn[b,c,:] = -(AX - lam[b,c] X);
+ *   rmax[b] = max(rmax[b], max |AX - lam X|)  (caller zeroes rmax; NaN is reported as +inf). */
+int xk_ritz_residual_f64(const double* V, const double* AV, const double* Y, const double* lam,
+                         double* X, double* Tn, double* rmax, int B, int k, int N, int P,
+                         long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc,
+                         long sLam, long ldx, long sX, long ldt, long sT, void* stream);
+int xk_ritz_residual_f32(const float* V, const float* AV, const float* Y, const float* lam,
+                         float* X, float* Tn, float* rmax, int B, int k, int N, int P,
+                         long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc,
+                         long sLam, long ldx, long sX, long ldt, long sT, void* stream);
+/* xk_panel_chol: G[b] (P x P, pitch ldg) = R^T R, W[b] = R^-1 compact (B,P,P) row-major; info[b] =
+ *   1+index of the first non-positive pivot, 0 if none (tensor.py:16-17; P <= 32). */
+int xk_panel_chol_f64(const double* G, double* W, int* info, int B, int P, long ldg, long sG, void* stream);
+int xk_panel_chol_f32(const float* G, float* W, int* info, int B, int P, long ldg, long sG, void* stream);
+/* xk_panel_transform: in place Tp[b,c,:] <- sum_{a<=c} W[b,a,c] Tp[b,a,:]  (tensor.py:18). */
+int xk_panel_transform_f64(double* Tp, const double* W, int B, int P, int N, long ldt, long sT, void* stream);
+int xk_panel_transform_f32(float* Tp, const float* W, int B, int P, int N, long ldt, long sT, void* stream);
+
+/* ---- K3: batched small symmetric eigensolver (LDS-resident parallel Jacobi) -----------------
+ * Lowest (uppest=0) / uppermost (uppest=1) p eigenpairs of B symmetric k x k matrices (lower
+ * triangle read, pitch ldt, batch pitch sT), eigenvalues ascending: lam (B,p), Y (B,p,k) with
+ * Y[b,c,:] the c-th eigenvector.  Replaces torch.linalg.eigh + _take_eigpairs
+ * (symeig.py:174-175, 255-264).  k <= 128, p <= 16.  ws: xk_small_eigh_workspace_elems elements. */
+long xk_small_eigh_workspace_elems(int B, int k, int max_sweeps);
+int xk_small_eigh_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* sweeps,
+                      int B, int k, int p, int uppest, int max_sweeps, long ldt, long sT, void* stream);
+int xk_small_eigh_f32(const float* T, float* lam, float* Y, float* ws, long ws_elems, int* sweeps,
+                      int B, int k, int p, int uppest, int max_sweeps, long ldt, long sT, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,3 +63,43 @@ def test_dense_mm_autograd(dev):
         return LinearOperator.m(m, is_hermitian=False).mm(xx)
     assert torch.autograd.gradcheck(f, (mat, x))
     assert torch.autograd.gradgradcheck(f, (mat, x))
+
+
+@pytest.mark.parametrize("B,M,N,P", [(3, 20, 8192, 6), (2, 54, 16384, 6), (64, 12, 4096, 6), (1, 7, 32768, 1)])
+def test_gram_split_path_vs_oracle(dev, B, M, N, P):
+    # skinny row sweeps (basis Gram blocks G = V W^T) take the split-contraction path
+    g = torch.Generator().manual_seed(B + M + N)
+    V = torch.randn(B, M, N, dtype=torch.float64, generator=g)
+    W = torch.randn(B, P, N, dtype=torch.float64, generator=g)
+    ref = torch.matmul(W, V.transpose(-2, -1))            # (B, P, M)
+    G = K.dense_mm(V.to(dev), W.to(dev)).cpu()
+    assert (G - ref).abs().max().item() < 1e-11 * N ** 0.5
+
+
+@pytest.mark.parametrize("B,k,p,uppest,dtype", [(3, 12, 6, False, torch.float64), (2, 37, 4, True, torch.float64),
+                                                 (5, 108, 6, False, torch.float64), (2, 128, 16, True, torch.float64),
+                                                 (64, 54, 6, False, torch.float64), (2, 33, 3, False, torch.float32),
+                                                 (1, 1, 1, False, torch.float64), (2, 7, 7, False, torch.float64)])
+def test_small_eigh_vs_oracle(dev, B, k, p, uppest, dtype):
+    g = torch.Generator().manual_seed(k * 7 + p)
+    R = torch.randn(B, k, k, dtype=torch.float64, generator=g)
+    T = (R + R.transpose(-2, -1)) * 0.5 + torch.diag(torch.arange(k, dtype=torch.float64))
+    # embed in a larger buffer with garbage in the strict upper triangle: only the lower one may be read
+    cap = k + 5
+    Tbuf = torch.full((B, cap, cap), 777.0, dtype=torch.float64)
+    Tbuf[:, :k, :k] = torch.tril(T) + torch.triu(torch.full((k, k), 99.0, dtype=torch.float64), 1)
+    lam_ref, Y_ref = torch.linalg.eigh(T)                 # CPU LAPACK = what the oracle calls (symeig.py:174)
+    sl = slice(k - p, k) if uppest else slice(0, p)
+    lam, Y, sweeps = K.small_eigh(Tbuf.to(dev).to(dtype), k, p, uppest=uppest)
+    lam, Y = lam.cpu().double(), Y.cpu().double()
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    scale = lam_ref.abs().max().item()
+    assert (lam - lam_ref[:, sl]).abs().max().item() < tol * scale * 10
+    assert torch.all(lam[:, 1:] >= lam[:, :-1])
+    # eigenvector residual and orthonormality
+    Yc = Y.transpose(-2, -1)                              # (B, k, p)
+    res = torch.matmul(T, Yc) - Yc * lam.unsqueeze(-2)
+    assert res.abs().max().item() < tol * scale * 50
+    G = torch.matmul(Yc.transpose(-2, -1), Yc)
+    assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 100
+    assert int(sweeps.max()) < 16

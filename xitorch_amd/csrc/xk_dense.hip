@@ -35,7 +35,9 @@ template <typename T, int P, int R>
 __global__ __launch_bounds__(256) void dense_mm_rows(
     const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ Y,
     int M, int N, long lda, long sA, long ldx, long sX, long ldy, long sY,
-    int row_groups_per_batch, int stagger) {
+    int row_groups_per_batch, int stagger, int steps_per_split, long sSplit) {
+  // blockIdx.y = split of the contraction range (Gram blocks of a skinny basis: few long rows);
+  // split s accumulates steps [s*steps_per_split, (s+1)*steps_per_split) into Y + s*sSplit.
   typedef typename Vec16<T>::type V;
   constexpr int VN = Vec16<T>::n;
   const int lane = threadIdx.x & 63;
@@ -61,13 +63,17 @@ __global__ __launch_bounds__(256) void dense_mm_rows(
   for (int i = 0; i < R * P; ++i) acc[i] = T(0);
 
   const int step_cols = 64 * VN;
-  const int nsteps = (N + step_cols - 1) / step_cols;
-  int t0 = stagger ? (int)(((unsigned)rg * 29u + (unsigned)b * 13u) % (unsigned)nsteps) : 0;
+  const int nsteps_all = (N + step_cols - 1) / step_cols;
+  const int step_lo = blockIdx.y * steps_per_split;
+  int nsteps = nsteps_all - step_lo;
+  nsteps = nsteps < steps_per_split ? nsteps : steps_per_split;
+  if (nsteps < 0) nsteps = 0;
+  int t0 = (stagger && nsteps > 0) ? (int)(((unsigned)rg * 29u + (unsigned)b * 13u) % (unsigned)nsteps) : 0;
 
   for (int it = 0; it < nsteps; ++it) {
     int t = it + t0;
     t = t >= nsteps ? t - nsteps : t;
-    const int j = (t * 64 + lane) * VN;
+    const int j = ((step_lo + t) * 64 + lane) * VN;
     if (j < N) {  // N % VN == 0 is guaranteed by the launcher
       V xv[P];
 #pragma unroll
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256) void dense_mm_rows(
 
   wave_reduce_scatter<T, R * P>(acc, lane);
   if (wave_rs_is_writer<R * P>(lane)) {
-    T* Yb = Y + (long)b * sY;
+    T* Yb = Y + (long)blockIdx.y * sSplit + (long)b * sY;
 #pragma unroll
     for (int i = 0; i < WaveRsCount<R * P>::value; ++i) {
       const int idx = wave_rs_orig_index<R * P>(i, lane);
@@ -94,6 +100,22 @@ __global__ __launch_bounds__(256) void dense_mm_rows(
       if (row0 + r < M) Yb[(long)c * ldy + row0 + r] = acc[i];
     }
   }
+}
+
+// fold the split partials: Y[b,c,i] = sum_s W[s,b,c,i]   (fixed order -> deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void fold_splits(const T* __restrict__ W, T* __restrict__ Y, int M, int P,
+                                                    int nsplit, long ldy, long sY, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*P*M
+  if (idx >= total) return;
+  const long per_b = (long)P * M;
+  const long b = idx / per_b;
+  const long rem = idx - b * per_b;
+  const int c = (int)(rem / M);
+  const int i = (int)(rem - (long)c * M);
+  T s = T(0);
+  for (int k = 0; k < nsplit; ++k) s += W[(long)k * total + idx];
+  Y[b * sY + (long)c * ldy + i] = s;
 }
 
 // Scalar-load fallback for shapes the 16 B path cannot take (N % VN != 0 or
@@ -247,9 +269,24 @@ __global__ __launch_bounds__(256) void dense_rmm_cols_scalar(
 // ---------------------------------------------------------------------------
 template <typename T> static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// number of contraction splits for a (B, M, N) row-sweep: only skinny problems (few waves, long
+// rows) are split, so that the chip is filled; K1 proper (M = N) is never split.
+template <typename T>
+static int choose_nsplit(int B, int M, int N, int R) {
+  constexpr int VN = Vec16<T>::n;
+  const long waves = (long)B * ((M + R - 1) / R);
+  const int nsteps = (N + 64 * VN - 1) / (64 * VN);
+  if (waves >= 2048 || nsteps < 16) return 1;
+  long ns = (4096 + waves - 1) / waves;
+  const long max_ns = nsteps / 8 > 0 ? nsteps / 8 : 1;   // >= 8 steps per split
+  if (ns > max_ns) ns = max_ns;
+  if (ns > 64) ns = 64;
+  return ns < 1 ? 1 : (int)ns;
+}
+
 template <typename T, int P, int R>
-static int launch_rows(const T* A, const T* X, T* Y, int B, int M, int N, long lda, long sA,
-                       long ldx, long sX, long ldy, long sY, int stagger, hipStream_t st) {
+static int launch_rows(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int M, int N, long lda,
+                       long sA, long ldx, long sX, long ldy, long sY, int stagger, hipStream_t st) {
   constexpr int VN = Vec16<T>::n;
   const int rgpb = (M + 4 * R - 1) / (4 * R);
   const long nblk = (long)B * rgpb;
@@ -257,10 +294,25 @@ static int launch_rows(const T* A, const T* X, T* Y, int B, int M, int N, long l
   if (nblk > 0x7fffffffL) return XK_ERR_UNSUPPORTED;
   const bool vec_ok = (N % VN == 0) && (lda % VN == 0) && (sA % VN == 0) && (ldx % VN == 0) &&
                       (sX % VN == 0) && aligned16<T>(A) && aligned16<T>(X);
-  if (vec_ok)
-    hipLaunchKernelGGL((dense_mm_rows<T, P, R>), dim3((unsigned)nblk), dim3(256), 0, st, A, X, Y, M,
-                       N, lda, sA, ldx, sX, ldy, sY, rgpb, stagger);
-  else
+  if (vec_ok) {
+    const int nsteps = (N + 64 * VN - 1) / (64 * VN);
+    int nsplit = choose_nsplit<T>(B, M, N, R);
+    const long total = (long)B * P * M;
+    if (nsplit > 1 && (ws == nullptr || ws_elems < (long)nsplit * total)) nsplit = 1;
+    if (nsplit <= 1) {
+      hipLaunchKernelGGL((dense_mm_rows<T, P, R>), dim3((unsigned)nblk), dim3(256), 0, st, A, X, Y, M, N,
+                         lda, sA, ldx, sX, ldy, sY, rgpb, stagger, nsteps, 0L);
+    } else {
+      const int sps = (nsteps + nsplit - 1) / nsplit;
+      nsplit = (nsteps + sps - 1) / sps;
+      // partials are compact (nsplit, B, P, M)
+      hipLaunchKernelGGL((dense_mm_rows<T, P, R>), dim3((unsigned)nblk, (unsigned)nsplit), dim3(256), 0, st,
+                         A, X, ws, M, N, lda, sA, ldx, sX, (long)M, (long)P * M, rgpb, stagger, sps, total);
+      XK_LAUNCH_CHECK();
+      hipLaunchKernelGGL((fold_splits<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, Y, M,
+                         P, nsplit, ldy, sY, total);
+    }
+  } else
     hipLaunchKernelGGL((dense_mm_rows_scalar<T, P, R>), dim3((unsigned)nblk), dim3(256), 0, st, A, X,
                        Y, M, N, lda, sA, ldx, sX, ldy, sY, rgpb);
   XK_LAUNCH_CHECK();
@@ -273,24 +325,25 @@ template <typename T, int P> struct RowsFor {
 };
 
 template <typename T, int P>
-static int mm_rows_p(const T* A, const T* X, T* Y, int B, int M, int N, long lda, long sA, long ldx,
-                     long sX, long ldy, long sY, int rows_hint, int stagger, hipStream_t st) {
+static int mm_rows_p(const T* A, const T* X, T* Y, T* ws, long wsn, int B, int M, int N, long lda, long sA,
+                     long ldx, long sX, long ldy, long sY, int rows_hint, int stagger, hipStream_t st) {
   // rows_hint lets the tuning harness override R; 0 = default
   switch (rows_hint) {
-    case 4: return launch_rows<T, P, 4>(A, X, Y, B, M, N, lda, sA, ldx, sX, ldy, sY, stagger, st);
-    case 8: return launch_rows<T, P, 8>(A, X, Y, B, M, N, lda, sA, ldx, sX, ldy, sY, stagger, st);
+    case 4: return launch_rows<T, P, 4>(A, X, Y, ws, wsn, B, M, N, lda, sA, ldx, sX, ldy, sY, stagger, st);
+    case 8: return launch_rows<T, P, 8>(A, X, Y, ws, wsn, B, M, N, lda, sA, ldx, sX, ldy, sY, stagger, st);
     case 16:
-      if (P <= 4) return launch_rows<T, P, 16>(A, X, Y, B, M, N, lda, sA, ldx, sX, ldy, sY, stagger, st);
+      if (P <= 4)
+        return launch_rows<T, P, 16>(A, X, Y, ws, wsn, B, M, N, lda, sA, ldx, sX, ldy, sY, stagger, st);
       return XK_ERR_UNSUPPORTED;
     default:
-      return launch_rows<T, P, RowsFor<T, P>::value>(A, X, Y, B, M, N, lda, sA, ldx, sX, ldy, sY,
+      return launch_rows<T, P, RowsFor<T, P>::value>(A, X, Y, ws, wsn, B, M, N, lda, sA, ldx, sX, ldy, sY,
                                                      stagger, st);
   }
 }
 
 template <typename T>
-static int mm_rows(const T* A, const T* X, T* Y, int B, int M, int N, int P, long lda, long sA,
-                   long ldx, long sX, long ldy, long sY, int rows_hint, int stagger,
+static int mm_rows(const T* A, const T* X, T* Y, T* ws, long wsn, int B, int M, int N, int P, long lda,
+                   long sA, long ldx, long sX, long ldy, long sY, int rows_hint, int stagger,
                    hipStream_t st) {
   // panels wider than 8 are processed in column blocks of <= 8 (A is re-read
   // once per block; the MFMA wide-panel kernel takes over for P >= 16).
@@ -303,7 +356,7 @@ static int mm_rows(const T* A, const T* X, T* Y, int B, int M, int N, int P, lon
     switch (pc) {
 #define XK_CASE(PP)                                                                           \
   case PP:                                                                                    \
-    rc = mm_rows_p<T, PP>(A, Xc, Yc, B, M, N, lda, sA, ldx, sX, ldy, sY, rows_hint, stagger, st); \
+    rc = mm_rows_p<T, PP>(A, Xc, Yc, ws, wsn, B, M, N, lda, sA, ldx, sX, ldy, sY, rows_hint, stagger, st); \
     break;
       XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
 #undef XK_CASE
@@ -379,7 +432,17 @@ static int rmm_cols(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, i
 extern "C" {
 
 long xk_dense_mm_workspace_elems(int B, int M, int N, int P, int trans) {
-  if (!trans) return 0;
+  if (!trans) {
+    // split partials of skinny row sweeps (Gram blocks); upper bound over the R choices
+    const int pc = P > 8 ? 8 : P;
+    int ns = 1;
+    for (int R = 4; R <= 16; R += 4) {
+      const int n1 = xk::choose_nsplit<double>(B, M, N, R), n2 = xk::choose_nsplit<float>(B, M, N, R);
+      ns = n1 > ns ? n1 : ns;
+      ns = n2 > ns ? n2 : ns;
+    }
+    return ns > 1 ? (long)ns * B * pc * M : 0;
+  }
   // trans=1 slab partials: at most ceil(2048/(B*ct)) slabs of (P<=8, N) per batch member
   const int pc = P > 8 ? 8 : P;
   const int ct = (N + 511) / 512;
@@ -397,7 +460,7 @@ int xk_dense_mm_f64(const double* A, const double* X, double* Y, double* ws, lon
   if (B == 0 || P == 0 || M == 0 || N == 0) return XK_OK;
   hipStream_t st = (hipStream_t)stream;
   if (!trans)
-    return xk::mm_rows<double>(A, X, Y, B, M, N, P, lda, sA, ldx, sX, ldy, sY, rows_hint, stagger, st);
+    return xk::mm_rows<double>(A, X, Y, ws, ws_elems, B, M, N, P, lda, sA, ldx, sX, ldy, sY, rows_hint, stagger, st);
   return xk::rmm_cols<double>(A, X, Y, ws, ws_elems, B, M, N, P, lda, sA, ldx, sX, ldy, sY, st);
 }
 
@@ -408,7 +471,7 @@ int xk_dense_mm_f32(const float* A, const float* X, float* Y, float* ws, long ws
   if (B == 0 || P == 0 || M == 0 || N == 0) return XK_OK;
   hipStream_t st = (hipStream_t)stream;
   if (!trans)
-    return xk::mm_rows<float>(A, X, Y, B, M, N, P, lda, sA, ldx, sX, ldy, sY, rows_hint, stagger, st);
+    return xk::mm_rows<float>(A, X, Y, ws, ws_elems, B, M, N, P, lda, sA, ldx, sX, ldy, sY, rows_hint, stagger, st);
   return xk::rmm_cols<float>(A, X, Y, ws, ws_elems, B, M, N, P, lda, sA, ldx, sX, ldy, sY, st);
 }
 

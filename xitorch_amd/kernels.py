@@ -62,8 +62,8 @@ def dense_mm(A, X, out=None, trans=False, rows_hint=0, stagger=1):
         out = torch.empty((B, P, nout), dtype=X.dtype, device=X.device)
     ldy, sY = _panel_strides(out)
     ws, ws_n = None, 0
-    if trans:
-        ws_n = fn("xk_dense_mm_workspace_elems")(B, M, N, P, 1)
+    ws_n = fn("xk_dense_mm_workspace_elems")(B, M, N, P, 1 if trans else 0)
+    if ws_n > 0:
         ws = _workspace(ws_n, X.dtype, X.device)
     rc = fn("xk_dense_mm_" + suffix(X.dtype))(
         ptr(A), ptr(X), ptr(out), ptr(ws), ws_n, B, M, N, P, lda, sA, ldx, sX, ldy, sY,
@@ -131,3 +131,28 @@ def panel_transform(Tp, W, P):
     rc = fn("xk_panel_transform_" + suffix(Tp.dtype))(ptr(Tp), ptr(W), B, P, N, Tp.stride(1), Tp.stride(0),
                                                       stream_ptr())
     check(rc, "xk_panel_transform")
+
+
+# --------------------------------------------------------------------------- K3 small eigensolver
+SMALL_EIGH_MAX_K = 128
+SMALL_EIGH_MAX_P = 16
+
+
+def small_eigh(T, k, p, uppest=False, max_sweeps=16):
+    """Lowest / uppermost `p` eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower
+    triangle is read).  Returns lam (B, p) ascending and Y (B, p, k) with Y[b, c] the c-th eigenvector.
+    Native replacement of `torch.linalg.eigh` + `_take_eigpairs` (symeig.py:174-175)."""
+    require_device(T, "projected matrix")
+    B = T.shape[0]
+    if T.stride(2) != 1:
+        raise _capi.NativeLibraryError("T must have unit stride along its last dim")
+    lam = torch.empty((B, p), dtype=T.dtype, device=T.device)
+    Y = torch.empty((B, p, k), dtype=T.dtype, device=T.device)
+    sweeps = torch.empty((B,), dtype=torch.int32, device=T.device)
+    nws = fn("xk_small_eigh_workspace_elems")(B, k, max_sweeps)
+    ws = _workspace(nws, T.dtype, T.device)
+    rc = fn("xk_small_eigh_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(ws), nws, ptr(sweeps), B, k, p,
+                                                 1 if uppest else 0, max_sweeps, T.stride(1), T.stride(0),
+                                                 stream_ptr())
+    check(rc, "xk_small_eigh")
+    return lam, Y, sweeps

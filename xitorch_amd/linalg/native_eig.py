@@ -51,6 +51,10 @@ class _PanelOperator:
         self.A, self.bdims, self.B, self.N = A, list(bdims), B, N
         self.mat = None
         self.napply = 0
+        self.events = None          # when a list: (start, end) HIP events around every K1 launch
+        # a real symmetric matrix equals its transpose: use the column-oriented K1 variant (lanes own
+        # output columns, panel values are wave-uniform scalars) — measured 6.8 vs 6.3 TB/s at P = 6
+        self.trans = bool(getattr(A, "is_hermitian", False))
         if isinstance(A, MatrixLinearOperator) and A.mat.is_cuda and A.mat.dtype in (torch.float64, torch.float32):
             nA = 1
             for d in A.shape[:-2]:
@@ -63,7 +67,14 @@ class _PanelOperator:
         self.napply += 1
         N = self.N
         if self.mat is not None:
-            K.dense_mm(self.mat, X[:, :, :N], out=out[:, :, :N])
+            if self.events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                K.dense_mm(self.mat, X[:, :, :N], out=out[:, :, :N], trans=self.trans)
+                e1.record()
+                self.events.append((e0, e1, X.shape[1]))
+            else:
+                K.dense_mm(self.mat, X[:, :, :N], out=out[:, :, :N], trans=self.trans)
             return out
         p = X.shape[1]
         x = X[:, :, :N].transpose(-2, -1).reshape(*self.bdims, N, p)     # the reference's Fortran-order view
@@ -77,21 +88,28 @@ def _gram(Vrows, k, panel, p, N):
     return K.dense_mm(Vrows[:, :k, :N], panel[:, :p, :N])
 
 
-def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device):
+def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device="cpu"):
     if V0 is not None:
         if V0.shape[-2] != N:
             raise RuntimeError("V0 must have shape (*batch, %d, nguess), got %s" % (N, tuple(V0.shape)))
         V = V0.to(device=device, dtype=dtype).expand(*bdims, N, V0.shape[-1]).reshape(B, N, V0.shape[-1])
         return V.transpose(-2, -1)
     kind = v_init.lower()
-    # parity with the reference CPU path: draw from the CPU generator, seed 12421 (symeig.py:236-246)
+    if kind == "cos":
+        # (extension) RNG-free closed form generated on the device: V0[i,j] = cos(0.1 (i+1)(j+1) + 0.05 b)
+        from xitorch_amd import synthetic
+        return synthetic.start_block(B, N, nguess, dtype, device)
+    # seed 12421 on the global generators, like the reference (symeig.py:236-246, quirk Q5).
+    # rng_device="cpu" (default) draws from the CPU stream = the reference's CPU path (parity runs);
+    # rng_device="device" draws on the operator's device = what the reference does for a GPU operator.
     torch.manual_seed(12421)
+    rdev = torch.device("cpu") if rng_device == "cpu" else device
     if kind == "eye":
-        V = torch.eye(N, nguess, dtype=dtype).unsqueeze(0).repeat(B, 1, 1)
+        V = torch.eye(N, nguess, dtype=dtype, device=rdev).unsqueeze(0).repeat(B, 1, 1)
     elif kind == "randn":
-        V = torch.randn((*bdims, N, nguess), dtype=dtype).reshape(B, N, nguess)
+        V = torch.randn((*bdims, N, nguess), dtype=dtype, device=rdev).reshape(B, N, nguess)
     elif kind in ("rand", "random"):
-        V = torch.rand((*bdims, N, nguess), dtype=dtype).reshape(B, N, nguess)
+        V = torch.rand((*bdims, N, nguess), dtype=dtype, device=rdev).reshape(B, N, nguess)
     else:
         raise ValueError("Unknown v_init type: %s" % kind)
     return V.to(device).transpose(-2, -1)
@@ -99,7 +117,7 @@ def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device):
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
-             **unused):
+             rng_device="cpu", small_eigh="native", **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -112,13 +130,21 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         Number of start vectors (default ``neig``)
     v_init: str
         Mode of the initial guess (``"randn"``, ``"rand"``, ``"eye"``); drawn on the CPU generator
-        with seed 12421 like the reference's CPU path, then moved to the device
+        with seed 12421 like the reference's CPU path, then moved to the device.  ``"cos"``
+        (extension) is an RNG-free closed form generated on the device
     max_addition: int or None
         Accepted for compatibility; like in the reference it has no effect
     min_eps: float
         Stop when the largest residual element over all batches and columns is below this
     verbose: bool
         Print the progress
+    rng_device: str
+        (extension) ``"cpu"`` (default): the random start block comes from the CPU generator, i.e. the
+        reference's CPU path bit for bit; ``"device"``: drawn on the operator's device, which is what
+        the reference does for a GPU-resident operator
+    small_eigh: str
+        (extension) ``"native"`` (default): the Rayleigh–Ritz matrix is diagonalised by the LDS Jacobi
+        kernel while the basis has <= 128 vectors; ``"library"``: always ``torch.linalg.eigh``
     V0: tensor or None
         (extension) start block ``(*batch, na, nguess)`` replacing the random draw
     orth_passes: int
@@ -143,6 +169,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     N, Npad = na, _pad(na, dtype)
     p = neig
     opA = _PanelOperator(A, bdims, B, N)
+    if trace is not None and trace.get("k1_events") is not None:
+        opA.events = trace["k1_events"]         # bench.py: per-launch HIP events of the K1 kernel
     opM = _PanelOperator(M, bdims, B, N) if M is not None else None
 
     cap = min(N, nguess + 8 * p) if N > nguess else nguess
@@ -201,7 +229,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         T[:, :k0, k0:k0 + q] = Tn[:, :, :k0].transpose(-2, -1)
 
     # ---- start block -----------------------------------------------------------------------
-    V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device)       # (B, nguess, N)
+    V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device)       # (B, nguess, N)
     k = V0p.shape[1]
     grow(k + p)
     Vs[:, :k, :N].copy_(V0p)
@@ -222,9 +250,13 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     niter = 0
     for it in range(max_niter):
         niter = it + 1
-        lam_all, Y_all = torch.linalg.eigh(T[:, :k, :k])                       # K3 (small, k x k)
-        lam, Y = take_eigpairs(lam_all, Y_all, p, mode)
-        lam = lam.contiguous()
+        if small_eigh == "native" and k <= K.SMALL_EIGH_MAX_K and p <= K.SMALL_EIGH_MAX_P:
+            lam, Yt, _ = K.small_eigh(T, k, p, uppest=(mode != "lowest"))      # K3: LDS Jacobi kernel
+            Y = Yt.transpose(1, 2)                                             # (B, k, p) view
+        else:
+            lam_all, Y_all = torch.linalg.eigh(T[:, :k, :k])                   # large bases: library eigh
+            lam, Y = take_eigpairs(lam_all, Y_all, p, mode)
+            lam = lam.contiguous()
         grow(min(N, k + p))
         nadd = min(p, N - k)
         slot = 1 - best_slot if best_slot >= 0 else 0
