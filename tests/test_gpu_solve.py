@@ -1,0 +1,132 @@
+"""-m gpu: native HIP Krylov solvers + banded operator vs the oracle and the reference's golden outputs."""
+import os
+import warnings
+import numpy as np
+import pytest
+import torch
+from oracle import ops as oops, solve as osolve
+from tests import cases
+import xitorch_amd as xa
+from xitorch_amd import kernels as K
+from xitorch_amd.linalg import solve
+from xitorch_amd.linalg import native_krylov as nk
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("B,N,hb,C,dtype", [(2, 1024, 63, 1, torch.float64), (3, 777, 5, 3, torch.float64),
+                                            (1, 4096, 63, 8, torch.float64), (2, 1000, 20, 2, torch.float32),
+                                            (2, 50, 63, 2, torch.float64), (1, 513, 1, 1, torch.float64)])
+@pytest.mark.parametrize("trans", [False, True])
+def test_banded_mm_vs_oracle(dev, B, N, hb, C, dtype, trans):
+    g = torch.Generator().manual_seed(N + hb)
+    band = torch.randn(B, 2 * hb + 1, N, dtype=dtype, generator=g)      # out-of-matrix entries hold garbage
+    X = torch.randn(B, C, N, dtype=dtype, generator=g)
+    op = oops.BandedOp(band.double())
+    xo = X.double().transpose(-2, -1)
+    ref = (op._rmm(xo) if trans else op._mm(xo)).transpose(-2, -1)
+    Y = K.banded_mm(band.to(dev), X.to(dev), trans=trans).cpu().double()
+    tol = 1e-13 if dtype == torch.float64 else 2e-6
+    assert (Y - ref).abs().max().item() <= tol * (ref.abs().max().item() + 1) * 10
+
+
+def _operators(case, A, M, dev):
+    if case["op"] == "banded":
+        return xa.BandedLinearOperator(A.to(dev), is_hermitian=False), None, oops.BandedOp(A)
+    Aop = xa.LinearOperator.m(A.to(dev), is_hermitian=case["hermitian"])
+    Mop = xa.LinearOperator.m(M.to(dev), is_hermitian=True) if M is not None else None
+    return Aop, Mop, oops.DenseOp(A, case["hermitian"])
+
+
+@pytest.mark.parametrize("case", cases.SOLVE_CASES, ids=[c["name"] for c in cases.SOLVE_CASES])
+def test_krylov_vs_golden_and_oracle(dev, case):
+    gold = np.load(os.path.join(GOLD, "solve_%s.npz" % case["name"]))
+    A, B, E, M = cases.solve_inputs(case)
+    Aop, Mop, oA = _operators(case, A, M, dev)
+    fcn = getattr(nk, case["method"])
+    tr = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                   # a ConvergenceWarning would be a failure here
+        X = fcn(Aop, B.to(dev), E.to(dev) if E is not None else None, Mop, trace=tr, **case["kwargs"])
+    X = X.cpu()
+    assert list(X.shape) == list(gold["X"].shape)
+    # (1) the residual identity the reference tests assert (test_linop_fcns.py:467-468, 674-676)
+    oM = oops.DenseOp(M, True) if M is not None else None
+    AX = oA.mm(X)
+    if E is not None:
+        AX = AX - (oM.mm(X) if oM is not None else X) * E.unsqueeze(-2)
+    kw = case["kwargs"]
+    rtol, atol = kw.get("rtol", 1e-6), kw.get("atol", 1e-8)
+    if case["name"].startswith("cg_nonsym"):
+        pass      # normal equations: the stopping test is on A^T(AX - B); checked through X below
+    else:
+        lim = torch.max(rtol * B.norm(dim=-2), torch.tensor(atol, dtype=B.dtype))
+        assert torch.all((AX - B).norm(dim=-2) <= lim * 1.001)
+    # (2) against the reference's own output and the dense solution
+    Xg, Xe = torch.from_numpy(gold["X"]), torch.from_numpy(gold["X_exact"])
+    scale = Xe.abs().max().item()
+    assert (X - Xe).abs().max().item() <= max(1e-6, (Xg - Xe).abs().max().item() * 50) * scale
+    # (3) same iteration path as the reference (identical algorithm, rounding-level differences only)
+    assert abs(tr["niter"] - int(gold["niter"])) <= 2, (tr["niter"], int(gold["niter"]))
+    assert tr["converged"]
+
+
+def test_solve_frontend_defaults_and_backward(dev):
+    # implicit (non-matrix) Hermitian operator -> default method cg; general -> bicgstab; gradients vs dense
+    g = torch.Generator().manual_seed(11)
+    n = 48
+    R = torch.rand(2, n, n, dtype=torch.float64, generator=g)
+    Asym = ((R + R.transpose(-2, -1)) * 0.05 + torch.eye(n, dtype=torch.float64)).to(dev)
+    Agen = (0.1 * R + torch.eye(n, dtype=torch.float64)).to(dev)
+    Bm = torch.rand(2, n, 3, dtype=torch.float64, generator=g).to(dev)
+
+    class Wrapped(xa.LinearOperator):
+        def __init__(self, mat, herm):
+            super().__init__(mat.shape, is_hermitian=herm, dtype=mat.dtype, device=mat.device)
+            self.mat = mat
+
+        def _mv(self, x):
+            return torch.matmul(self.mat, x.unsqueeze(-1)).squeeze(-1)
+
+        def _rmv(self, x):
+            return torch.matmul(self.mat.transpose(-2, -1), x.unsqueeze(-1)).squeeze(-1)
+
+        def _getparamnames(self, prefix=""):
+            return [prefix + "mat"]
+
+    for mat, herm in ((Asym, True), (Agen, False)):
+        m1 = mat.clone().requires_grad_()
+        b1 = Bm.clone().requires_grad_()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # Hermitian + _rmv warning of the operator contract
+            op = Wrapped(m1, herm)
+        x = solve(op, b1, rtol=1e-12, atol=1e-14, posdef=True,
+                  bck_options=dict(rtol=1e-12, atol=1e-14, posdef=True))
+        xd = torch.linalg.solve(mat, Bm)
+        assert torch.allclose(x, xd, rtol=1e-8, atol=1e-9)
+        loss = (x ** 2).sum()
+        gm, gb = torch.autograd.grad(loss, (m1, b1))
+        m2 = mat.clone().requires_grad_()
+        b2 = Bm.clone().requires_grad_()
+        l2 = (torch.linalg.solve(m2, b2) ** 2).sum()
+        gm2, gb2 = torch.autograd.grad(l2, (m2, b2))
+        assert torch.allclose(gb, gb2, rtol=1e-6, atol=1e-8)
+        assert torch.allclose(gm, gm2, rtol=1e-6, atol=1e-8)
+
+
+def test_nonconvergence_warns_and_returns_best(dev):
+    g = torch.Generator().manual_seed(2)
+    n = 64
+    R = torch.rand(1, n, n, dtype=torch.float64, generator=g)
+    A = xa.LinearOperator.m((R + torch.eye(n)).to(dev), is_hermitian=False)
+    B = torch.rand(1, n, 2, dtype=torch.float64, generator=g).to(dev)
+    with pytest.warns(xa.ConvergenceWarning):
+        X = nk.bicgstab(A, B, max_niter=2, rtol=1e-14, atol=1e-16, posdef=True)
+    assert X.shape == (1, n, 2) and torch.isfinite(X).all()
+
+
+def test_zero_rhs_shortcut(dev):
+    A = xa.LinearOperator.m(torch.eye(8, dtype=torch.float64, device=dev) * 2, is_hermitian=True)
+    X = nk.cg(A, torch.zeros(8, 2, dtype=torch.float64, device=dev))
+    assert torch.all(X == 0)

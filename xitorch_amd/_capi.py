@@ -60,6 +60,17 @@ def _declare(L):
         sigs["xk_panel_transform_" + sfx] = (I, [P, P, I, I, I, Lg, Lg, P])
         sigs["xk_small_eigh_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, I, Lg, Lg, P])
     sigs["xk_small_eigh_workspace_elems"] = (Lg, [I, I, I])
+    sigs["xk_kry_max_partials"] = (I, [])
+    for sfx in ("f64", "f32"):
+        sigs["xk_banded_mm_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
+        sigs["xk_kry_dots_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, P])
+        sigs["xk_bicg_p_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])
+        sigs["xk_bicg_s_" + sfx] = (I, [P] * 6 + [I, I, Lg, I, D, P])
+        sigs["xk_bicg_final_" + sfx] = (I, [P] * 14 + [I, I, Lg, I, D, I, P])
+        sigs["xk_kry_resid_" + sfx] = (I, [P] * 6 + [I, I, Lg, I, P])
+        sigs["xk_cg_update_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])
+        sigs["xk_cg_p_" + sfx] = (I, [P] * 4 + [I, I, Lg, I, D, P])
+        sigs["xk_kry_status_" + sfx] = (I, [P] * 4 + [I, I, P])
     sigs.update(_EXTRA_SIGS)
     for name, (res, args) in sigs.items():
         if not hasattr(L, name):

@@ -156,3 +156,26 @@ def small_eigh(T, k, p, uppest=False, max_sweeps=16):
                                                  stream_ptr())
     check(rc, "xk_small_eigh")
     return lam, Y, sweeps
+
+
+# --------------------------------------------------------------------------- banded operator
+def banded_mm(band, X, out=None, trans=False):
+    """Y[b,c,:] = A_b X[b,c,:] for DIA-stored banded operators: band (B or 1, 2*hb+1, N),
+    band[b,d,i] = A_b[i, i+d-hb].  X, Y panel-major (B, C, N)."""
+    require_device(band, "band")
+    require_device(X, "panel")
+    B, C, N = X.shape
+    nd = band.shape[-2]
+    if band.shape[-1] != N or nd % 2 != 1:
+        raise _capi.NativeLibraryError("band shape %s does not match panel length %d" % (tuple(band.shape), N))
+    if not band.is_contiguous():
+        raise _capi.NativeLibraryError("band must be contiguous")
+    sBand = band.stride(0) if (band.dim() == 3 and band.shape[0] != 1) else 0
+    ldx, sX = _panel_strides(X)
+    if out is None:
+        out = torch.empty((B, C, N), dtype=X.dtype, device=X.device)
+    ldy, sY = _panel_strides(out)
+    rc = fn("xk_banded_mm_" + suffix(X.dtype))(ptr(band), ptr(X), ptr(out), B, N, nd // 2, C, sBand, ldx, sX,
+                                                ldy, sY, 1 if trans else 0, stream_ptr())
+    check(rc, "xk_banded_mm")
+    return out

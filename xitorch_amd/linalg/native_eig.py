@@ -26,6 +26,7 @@ import torch
 from xitorch_amd import kernels as K
 from xitorch_amd._capi import NativeLibraryError
 from xitorch_amd._util import bcast_shape
+from xitorch_amd.linalg._panel import PanelOperator, pad_len
 
 __all__ = ["davidson", "exacteig", "take_eigpairs"]
 
@@ -39,48 +40,10 @@ def take_eigpairs(evals, evecs, neig, mode):
 
 
 def _pad(n, dtype):
-    q = 8  # elements; keeps every basis vector 64 B aligned for f64 and f32
-    return (n + q - 1) // q * q
+    return pad_len(n)
 
 
-class _PanelOperator:
-    """Applies an operator to a panel-major block X (B, p, Npad) -> out (B, p, Npad)."""
-
-    def __init__(self, A, bdims, B, N):
-        from xitorch_amd.linop import MatrixLinearOperator
-        self.A, self.bdims, self.B, self.N = A, list(bdims), B, N
-        self.mat = None
-        self.napply = 0
-        self.events = None          # when a list: (start, end) HIP events around every K1 launch
-        # a real symmetric matrix equals its transpose: use the column-oriented K1 variant (lanes own
-        # output columns, panel values are wave-uniform scalars) — measured 6.8 vs 6.3 TB/s at P = 6
-        self.trans = bool(getattr(A, "is_hermitian", False))
-        if isinstance(A, MatrixLinearOperator) and A.mat.is_cuda and A.mat.dtype in (torch.float64, torch.float32):
-            nA = 1
-            for d in A.shape[:-2]:
-                nA *= d
-            if (nA == B or nA == 1) and (A.mat.is_contiguous() or A.mat.dim() == 2):
-                self.mat = A.mat.reshape(nA, N, N) if A.mat.dim() > 2 else A.mat
-        # a Hermitian dense operator may also be stored transposed; K1 handles both via `trans`
-
-    def apply(self, X, out):
-        self.napply += 1
-        N = self.N
-        if self.mat is not None:
-            if self.events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                K.dense_mm(self.mat, X[:, :, :N], out=out[:, :, :N], trans=self.trans)
-                e1.record()
-                self.events.append((e0, e1, X.shape[1]))
-            else:
-                K.dense_mm(self.mat, X[:, :, :N], out=out[:, :, :N], trans=self.trans)
-            return out
-        p = X.shape[1]
-        x = X[:, :, :N].transpose(-2, -1).reshape(*self.bdims, N, p)     # the reference's Fortran-order view
-        y = self.A.mm(x)
-        out[:, :, :N].copy_(y.expand(*self.bdims, N, p).reshape(self.B, N, p).transpose(-2, -1))
-        return out
+_PanelOperator = PanelOperator
 
 
 def _gram(Vrows, k, panel, p, N):

@@ -1,13 +1,25 @@
 """Linear solvers: dense `exactsolve` and the native (HIP) Krylov methods cg / bicgstab / gmres.
 
 Drop-in for the method functions of the reference (xitorch/_impls/linalg/solve.py): same names,
-signatures ``f(A, B, E, M, **options) -> X``, options, stopping rules, best-iterate return and
-``ConvergenceWarning`` behaviour.
+signatures ``f(A, B, E, M, **options) -> X``, options, stopping rule
+(``all(|r_col| < max(rtol |b_col|, atol))``), best-iterate return (quirk Q10), true-residual
+refresh every ``resid_calc_every`` iterations, ``_safedenom`` patching (Q9), normal-equation
+fallback for ``posdef=False`` and ``ConvergenceWarning`` on non-convergence.
+
+Every (batch member, column) pair is one *system*; all S = Bt*ncols systems advance in lock step.
+Vectors live in padded (Bt, ncols, ld) panels (== (S, ld) arrays); per-system scalars never leave
+the device; an iteration is a fixed sequence of fused kernels of libxitorch_amd.so
+(xk_bicg_*, xk_cg_*, xk_kry_*) around the operator applies (xk_dense_mm / xk_banded_mm for the
+native operators, the operator's own ``.mm`` otherwise) and ONE host sync (the stopping test).
+With per-column shifts ``E`` the reference moves the columns to a leading axis (solve.py:575-604,
+Q11); here the shift is simply a per-system scalar.
 """
 import warnings
 import torch
+from xitorch_amd import kernels as K
+from xitorch_amd._capi import NativeLibraryError, fn, ptr, stream_ptr, check, suffix
 from xitorch_amd._util import bcast_shape, pad_shapes, ConvergenceWarning
-from xitorch_amd._capi import NativeLibraryError
+from xitorch_amd.linalg._panel import PanelOperator, pad_len, to_panel, from_panel
 
 __all__ = ["exactsolve", "custom_exactsolve", "cg", "bicgstab", "gmres", "broyden1_solve", "get_batchdims"]
 
@@ -59,13 +71,512 @@ def custom_exactsolve(A, B, E=None, M=None, **options):
     return exactsolve(A, B, E, M)
 
 
-def _not_yet(name):
-    def f(*a, **k):
-        raise NotImplementedError("native %s is being wired in" % name)
-    return f
+# ------------------------------------------------------------------------------- problem set-up
+class _Problem:
+    """The linear problem in panel layout: apply(X) = A X - E * (M X), optionally the normal
+    equations (reference: _setup_linear_problem, solve.py:560-643)."""
+
+    def __init__(self, A, B, E, M, bdims, posdef, need_hermit):
+        dev = torch.device(A.device)
+        if dev.type != "cuda":
+            raise NativeLibraryError("xitorch_amd native solvers run on a HIP device only (operator is on %s); "
+                                     "there is no CPU fallback" % dev)
+        if A.dtype not in (torch.float64, torch.float32):
+            raise NativeLibraryError("xitorch_amd native solvers support float64/float32, got %s" % A.dtype)
+        self.dtype, self.device = A.dtype, dev
+        self.bdims = list(bdims)
+        self.N = A.shape[-1]
+        self.nc = B.shape[-1]
+        self.Bt = 1
+        for d in self.bdims:
+            self.Bt *= d
+        self.ld = pad_len(self.N)
+        self.S = self.Bt * self.nc
+        self.opA = PanelOperator(A, self.bdims, self.Bt, self.N)
+        self.opM = PanelOperator(M, self.bdims, self.Bt, self.N) if (M is not None and E is not None) else None
+        self.E = None
+        if E is not None:
+            self.E = E.to(self.dtype).expand(*self.bdims, self.nc).reshape(self.Bt, self.nc).contiguous()
+        self._tmp = None
+        self._tmp2 = None
+        rhs = to_panel(B.to(self.dtype), self.bdims, self.Bt, self.N)
+
+        hermit = A.is_hermitian and (M is None or M.is_hermitian)
+        if need_hermit and not hermit:
+            posdef = False                                            # solve.py:607-612
+        if posdef is None:
+            posdef = self._posdef_heuristic()
+        self.normal = not posdef
+        if self.normal:                                               # A -> A^H A, B -> A^H B (solve.py:637-643)
+            rhs2 = self.new()
+            self._apply1(rhs, rhs2, trans=True)
+            rhs = rhs2
+        self.rhs = rhs
+
+    def new(self, n=None):
+        return torch.zeros((self.Bt, self.nc if n is None else n, self.ld), dtype=self.dtype, device=self.device)
+
+    def _apply1(self, X, out, trans=False):
+        self.opA.apply(X, out, trans=trans)
+        if self.E is not None:
+            if self.opM is not None:
+                if self._tmp2 is None or self._tmp2.shape != X.shape:
+                    self._tmp2 = torch.zeros_like(X)
+                self.opM.apply(X, self._tmp2, trans=trans)
+                out.sub_(self._tmp2 * self.E.unsqueeze(-1))
+            else:
+                out.sub_(X * self.E.unsqueeze(-1))
+        return out
+
+    def apply(self, X, out):
+        if not self.normal:
+            return self._apply1(X, out)
+        if self._tmp is None or self._tmp.shape != X.shape:
+            self._tmp = torch.zeros_like(X)
+        self._apply1(X, self._tmp)
+        return self._apply1(self._tmp, out, trans=True)
+
+    @property
+    def napply(self):
+        return self.opA.napply
+
+    def _posdef_heuristic(self):
+        # reference solve.py:617-634 + _get_largest_eival (:645-663): power iterations from an
+        # (unseeded) random start; `largest` is a NORM, so this is "posdef unless the operator is 0" (Q8)
+        x0 = torch.randn((self.Bt, self.nc, self.ld), dtype=self.dtype, device=self.device)
+        x0[:, :, self.N:] = 0
+        x0 = x0 / x0.norm(dim=-1, keepdim=True)
+
+        def largest(fcn, x):
+            prev = None
+            for i in range(10):
+                y = self.new()
+                x = fcn(x, y)
+                xn = x.norm(dim=-1, keepdim=True)
+                if i > 0 and bool(torch.all(torch.abs(prev - xn) <= 1e-3 * xn + 1e-6)):
+                    break
+                prev = xn
+                if i < 9:
+                    x = x / xn
+            return xn
+        big = largest(lambda x, y: self._apply1(x, y), x0)
+        neg = big <= 0
+        if bool(torch.all(neg)):
+            return False
+        offset = torch.clamp(big, min=0.0)
+        mostneg = largest(lambda x, y: self._apply1(x, y).sub_(offset * x), x0)
+        return bool(torch.all(torch.logical_or(-mostneg <= offset, neg)).item())
+
+    def solution(self, Xp):
+        return from_panel(Xp, self.bdims, self.N)
 
 
-cg = _not_yet("cg")
-bicgstab = _not_yet("bicgstab")
-gmres = _not_yet("gmres")
-broyden1_solve = _not_yet("broyden1_solve")
+class _Kry:
+    """ctypes plumbing of the fused Krylov kernels on (S, ld) arrays."""
+
+    def __init__(self, prob):
+        self.S, self.N, self.ld = prob.S, prob.N, prob.ld
+        self.sfx = suffix(prob.dtype)
+        vn = 2 if prob.dtype == torch.float64 else 4
+        self.nblk = max(1, min(fn("xk_kry_max_partials")(), (prob.N + 256 * vn * 4 - 1) // (256 * vn * 4)))
+        self.dtype, self.device = prob.dtype, prob.device
+        self.status = torch.zeros((2,), dtype=torch.float64, device=prob.device)
+        self.rnorm = torch.zeros((prob.S,), dtype=prob.dtype, device=prob.device)
+
+    def partial(self):
+        return torch.zeros((self.S, 64), dtype=self.dtype, device=self.device)
+
+    def scalar(self, val=0.0):
+        return torch.full((self.S,), val, dtype=self.dtype, device=self.device)
+
+    def _c(self, name, *args):
+        check(fn("xk_%s_%s" % (name, self.sfx))(*args, stream_ptr()), "xk_" + name)
+
+    def dots(self, x1, y1, P1, x2=None, y2=None, P2=None):
+        self._c("kry_dots", ptr(x1), ptr(y1), ptr(x2), ptr(y2), ptr(None), ptr(None), ptr(P1), ptr(P2),
+                self.S, self.N, self.ld, self.nblk)
+
+    def bicg_p(self, r, p, v, Prho, rho_old, alpha, omega, rho_store, eps, first):
+        self._c("bicg_p", ptr(r), ptr(p), ptr(v), ptr(Prho), ptr(rho_old), ptr(alpha), ptr(omega),
+                ptr(rho_store), self.S, self.N, self.ld, self.nblk, float(eps), 1 if first else 0)
+
+    def bicg_s(self, r, v, s, rho, Pr0v, alpha, eps):
+        self._c("bicg_s", ptr(r), ptr(v), ptr(s), ptr(rho), ptr(Pr0v), ptr(alpha), self.S, self.N, self.ld,
+                self.nblk, float(eps))
+
+    def bicg_final(self, x, xout, yd, zd, s, t, r, r0, alpha, Pts, Ptt, omega, Prr, Prho, eps, skip_r):
+        self._c("bicg_final", ptr(x), ptr(xout), ptr(yd), ptr(zd), ptr(s), ptr(t), ptr(r), ptr(r0), ptr(alpha),
+                ptr(Pts), ptr(Ptt), ptr(omega), ptr(Prr), ptr(Prho), self.S, self.N, self.ld, self.nblk,
+                float(eps), 1 if skip_r else 0)
+
+    def resid(self, b, y, r, r0, Prr, Prho):
+        self._c("kry_resid", ptr(b), ptr(y), ptr(r), ptr(r0), ptr(Prr), ptr(Prho), self.S, self.N, self.ld,
+                self.nblk)
+
+    def cg_update(self, x, xout, p, Ap, r, Prz, PpAp, Prr, eps, skip_r):
+        self._c("cg_update", ptr(x), ptr(xout), ptr(p), ptr(Ap), ptr(r), ptr(Prz), ptr(PpAp), ptr(Prr),
+                self.S, self.N, self.ld, self.nblk, float(eps), 1 if skip_r else 0)
+
+    def cg_p(self, z, p, Prz_new, Prz_old, eps):
+        self._c("cg_p", ptr(z), ptr(p), ptr(Prz_new), ptr(Prz_old), self.S, self.N, self.ld, self.nblk,
+                float(eps))
+
+    def check_status(self, Prr, stop, process_group=None):
+        """-> (max residual norm over all systems, number of unconverged systems): the one host sync."""
+        check(fn("xk_kry_status_" + self.sfx)(ptr(Prr), ptr(stop), ptr(self.rnorm), ptr(self.status), self.S,
+                                              self.nblk, stream_ptr()), "xk_kry_status")
+        if process_group is not None:
+            # MAX over the ranks of both entries: max residual, and "someone is unconverged" (count > 0)
+            torch.distributed.all_reduce(self.status, op=torch.distributed.ReduceOp.MAX, group=process_group)
+        mx, nbad = self.status.tolist()
+        return mx, nbad
+
+
+def _zeros_like_solution(A, B, bdims):
+    return torch.zeros((*bdims, A.shape[-1], B.shape[-1]), dtype=A.dtype, device=A.device)
+
+
+def _stop_vector(prob, rtol, atol):
+    bnorm = prob.rhs.norm(dim=-1).reshape(-1)
+    return torch.max(rtol * bnorm, atol * torch.ones_like(bnorm)).contiguous()
+
+
+def _precond(P, prob):
+    if P is None:
+        return None
+    from xitorch_amd.linop import LinearOperator
+    if not isinstance(P, LinearOperator):
+        raise TypeError("precond can only be LinearOperator or None")
+    return PanelOperator(P, prob.bdims, prob.Bt, prob.N)
+
+
+class _XRing:
+    """Three rotating solution buffers: current, next, and whichever holds the best iterate —
+    best-iterate tracking (solve.py:157-160, 300-303) without copying."""
+
+    def __init__(self, prob):
+        self.bufs = [prob.new() for _ in range(3)]
+        self.cur, self.best = 0, 0
+
+    def next_index(self):
+        for i in range(3):
+            if i != self.cur and i != self.best:
+                return i
+        raise AssertionError
+
+
+# ------------------------------------------------------------------------------- BiCGStab
+def bicgstab(A, B, E=None, M=None, posdef=None, precond_l=None, precond_r=None, max_niter=None,
+             rtol=1e-6, atol=1e-8, eps=1e-12, verbose=False, resid_calc_every=10, process_group=None,
+             trace=None, **unused):
+    r"""
+    Solve the linear equations using the stabilized Biconjugate-Gradient method on HIP kernels.
+
+    Keyword arguments
+    -----------------
+    posdef: bool or None
+        Whether :math:`\mathbf{AX-MXE}` is positive definite for all columns and batches; ``None``
+        runs the reference's power-iteration heuristic; ``False`` solves the normal equations
+    precond_l, precond_r: LinearOperator or None
+        Left / right preconditioners
+    max_niter: int or None
+        Maximum number of iterations (default ``int(1.5 * A.shape[-1])``)
+    rtol, atol: float
+        Relative / absolute tolerance of the stopping condition w.r.t. the norm of B
+    eps: float
+        Replacement of exact zeros in denominators
+    resid_calc_every: int
+        Recompute the true residual with this period (0: never)
+    verbose: bool
+        Print the progress
+    process_group: torch.distributed group or None
+        (extension) batch-sharded multi-GPU run: the stopping test is all-reduced over the group
+    """
+    nr, ncols = B.shape[-2:]
+    if max_niter is None:
+        max_niter = int(1.5 * nr)
+    bdims = get_batchdims(A, B, E, M)
+    if torch.allclose(B, B * 0, rtol=rtol, atol=atol):
+        return _zeros_like_solution(A, B, bdims)
+    prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=False)
+    kr = _Kry(prob)
+    pl, pr = _precond(precond_l, prob), _precond(precond_r, prob)
+    stop = _stop_vector(prob, rtol, atol)
+
+    r = prob.rhs.clone()                      # x0 = 0  ->  r = B - A 0 = B (solve.py:262)
+    r0 = r.clone()
+    p, v, s, t = prob.new(), prob.new(), prob.new(), prob.new()
+    y = prob.new() if pr is not None else p
+    z = prob.new() if pr is not None else s
+    Kt = prob.new() if pl is not None else t
+    Ks = prob.new() if pl is not None else s
+    tmp = prob.new()
+    ring = _XRing(prob)
+    Prho, Pr0v, Pts, Ptt, Prr = (kr.partial() for _ in range(5))
+    rho = [kr.scalar(), kr.scalar()]
+    alpha, omega = kr.scalar(1.0), kr.scalar(1.0)
+
+    kr.dots(r, r, Prr, r0, r, Prho)
+    best, _ = kr.check_status(Prr, stop, process_group)
+    converged = False
+    niter = 0
+    for k in range(1, max_niter + 1):
+        niter = k
+        kr.bicg_p(r, p, v, Prho, rho[(k + 1) % 2], alpha, omega, rho[k % 2], eps, first=(k == 1))
+        if pr is not None:
+            pr.apply(p, y)
+        prob.apply(y, v)
+        kr.dots(r0, v, Pr0v)
+        kr.bicg_s(r, v, s, rho[k % 2], Pr0v, alpha, eps)
+        if pr is not None:
+            pr.apply(s, z)
+        prob.apply(z, t)
+        if pl is not None:
+            pl.apply(t, Kt)
+            pl.apply(s, Ks)
+        kr.dots(Ks, Kt, Pts, Kt, Kt, Ptt)
+        refresh = resid_calc_every != 0 and k % resid_calc_every == 0
+        nxt = ring.next_index()
+        kr.bicg_final(ring.bufs[ring.cur], ring.bufs[nxt], y, z, s, t, r, r0, alpha, Pts, Ptt, omega, Prr, Prho,
+                      eps, skip_r=refresh)
+        ring.cur = nxt
+        if refresh:                                                # solve.py:290-291
+            prob.apply(ring.bufs[nxt], tmp)
+            kr.resid(prob.rhs, tmp, r, r0, Prr, Prho)
+        mx, nbad = kr.check_status(Prr, stop, process_group)
+        if mx < best:
+            best, ring.best = mx, nxt
+        if verbose and (k < 10 or k % 10 == 0):
+            print("%4d: |dy|=%.3e" % (k, mx))
+        if nbad == 0:
+            converged = True
+            break
+    if trace is not None:
+        trace.update(niter=niter, napply=prob.napply, converged=converged, best_resid=best)
+    if not converged:
+        warnings.warn(ConvergenceWarning("Convergence is not achieved after %d iterations. "
+                                         "Max norm of resid: %.3e" % (max_niter, best)))
+    return prob.solution(ring.bufs[ring.best])
+
+
+# ------------------------------------------------------------------------------- CG
+def cg(A, B, E=None, M=None, posdef=None, precond=None, max_niter=None, rtol=1e-6, atol=1e-8, eps=1e-12,
+       resid_calc_every=10, verbose=False, process_group=None, trace=None, **unused):
+    r"""
+    Solve the linear equations using the Conjugate-Gradient (CG) method on HIP kernels.
+
+    Keyword arguments
+    -----------------
+    posdef: bool or None
+        Whether :math:`\mathbf{AX-MXE}` is positive definite for all columns and batches; ``None``
+        runs the reference's power-iteration heuristic; ``False`` (forced for non-Hermitian
+        operators) solves the normal equations
+    precond: LinearOperator or None
+        Preconditioner
+    max_niter: int or None
+        Maximum number of iterations (default ``int(1.5 * A.shape[-1])``)
+    rtol, atol: float
+        Relative / absolute tolerance of the stopping condition w.r.t. the norm of B
+    eps: float
+        Replacement of exact zeros in denominators
+    resid_calc_every: int
+        Recompute the true residual with this period (0: never)
+    verbose: bool
+        Print the progress
+    process_group: torch.distributed group or None
+        (extension) batch-sharded multi-GPU run: the stopping test is all-reduced over the group
+    """
+    nr = A.shape[-1]
+    ncols = B.shape[-1]
+    if max_niter is None:
+        max_niter = int(1.5 * nr)
+    bdims = get_batchdims(A, B, E, M)
+    if torch.allclose(B, B * 0, rtol=rtol, atol=atol):
+        return _zeros_like_solution(A, B, bdims)
+    prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=True)
+    kr = _Kry(prob)
+    pre = _precond(precond, prob)
+    stop = _stop_vector(prob, rtol, atol)
+
+    r = prob.rhs.clone()
+    z = prob.new() if pre is not None else r
+    if pre is not None:
+        pre.apply(r, z)
+    p = z.clone()
+    Ap, tmp = prob.new(), prob.new()
+    ring = _XRing(prob)
+    Prz = [kr.partial(), kr.partial()]
+    PpAp, Prr = kr.partial(), kr.partial()
+    kr.dots(r, r, Prr, r, z, Prz[0])
+    best, _ = kr.check_status(Prr, stop, process_group)
+    converged = False
+    cur = 0
+    niter = 0
+    for k in range(1, max_niter + 1):
+        niter = k
+        prob.apply(p, Ap)
+        kr.dots(p, Ap, PpAp)
+        refresh = resid_calc_every != 0 and k % resid_calc_every == 0
+        nxt = ring.next_index()
+        kr.cg_update(ring.bufs[ring.cur], ring.bufs[nxt], p, Ap, r, Prz[cur], PpAp, Prr, eps, skip_r=refresh)
+        ring.cur = nxt
+        if refresh:                                                # solve.py:148-149
+            prob.apply(ring.bufs[nxt], tmp)
+            kr.resid(prob.rhs, tmp, r, None, Prr, None)
+        mx, nbad = kr.check_status(Prr, stop, process_group)
+        if mx < best:
+            best, ring.best = mx, nxt
+        if verbose and (k < 10 or k % 10 == 0):
+            print("%4d: |dy|=%.3e" % (k, mx))
+        if nbad == 0:
+            converged = True
+            break
+        if pre is not None:
+            pre.apply(r, z)
+        kr.dots(r, z, Prz[1 - cur])
+        kr.cg_p(z, p, Prz[1 - cur], Prz[cur], eps)
+        cur = 1 - cur
+    if trace is not None:
+        trace.update(niter=niter, napply=prob.napply, converged=converged, best_resid=best)
+    if not converged:
+        warnings.warn(ConvergenceWarning("Convergence is not achieved after %d iterations. "
+                                         "Max norm of best resid: %.3e" % (max_niter, best)))
+    return prob.solution(ring.bufs[ring.best])
+
+
+# ------------------------------------------------------------------------------- GMRES
+def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-8, eps=1e-12,
+          process_group=None, trace=None, **unused):
+    r"""
+    Solve the linear equations using the Generalised minimal residual method on HIP kernels.
+
+    The Krylov basis of every system is kept panel-major on the device and grows by one vector
+    per iteration (the reference preallocates ``max_niter`` vectors, solve.py:384, Q12);
+    orthogonalisation is classical Gram–Schmidt applied twice through the K1 / xk_lincomb
+    kernels; the small Hessenberg least-squares problems are updated with Givens rotations, whose
+    residual estimate drives the same stopping rule; the true residual is verified once at the end.
+
+    Keyword arguments
+    -----------------
+    posdef: bool or None
+        As for :func:`bicgstab`
+    max_niter: int or None
+        Maximum number of iterations (default ``A.shape[-1]``)
+    rtol, atol: float
+        Relative / absolute tolerance of the stopping condition w.r.t. the norm of B
+    eps: float
+        Replacement of exact zeros in denominators
+    """
+    nr, ncols = A.shape[-1], B.shape[-1]
+    if max_niter is None:
+        max_niter = int(nr)
+    max_niter = min(max_niter, nr)
+    bdims = get_batchdims(A, B, E, M)
+    if torch.allclose(B, B * 0, rtol=rtol, atol=atol):
+        return _zeros_like_solution(A, B, bdims)
+    prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=False)
+    S, N, ld = prob.S, prob.N, prob.ld
+    dtype, dev = prob.dtype, prob.device
+    stop = _stop_vector(prob, rtol, atol).double().cpu()
+    r = prob.rhs.reshape(S, 1, ld)
+    beta = r.norm(dim=-1).reshape(S)
+    cap = min(max_niter + 1, 32)
+    Q = torch.zeros((S, cap, ld), dtype=dtype, device=dev)
+    Q[:, 0] = (r / torch.where(beta == 0, torch.full_like(beta, eps), beta).reshape(S, 1, 1))[:, 0]
+    w = torch.zeros((S, 1, ld), dtype=dtype, device=dev)
+    # host-side Givens state per system
+    H = torch.zeros((S, max_niter + 1, max_niter), dtype=torch.float64)
+    cs = torch.zeros((S, max_niter), dtype=torch.float64)
+    sn = torch.zeros((S, max_niter), dtype=torch.float64)
+    g = torch.zeros((S, max_niter + 1), dtype=torch.float64)
+    g[:, 0] = beta.double().cpu()
+    converged = False
+    niter = 0
+    kdim = 0
+    est = g[:, 0].abs()
+    for k in range(max_niter):
+        niter = k + 1
+        if k + 2 > cap:                                           # grow the basis storage
+            newcap = min(max_niter + 1, 2 * cap)
+            Qn = torch.zeros((S, newcap, ld), dtype=dtype, device=dev)
+            Qn[:, :cap].copy_(Q)
+            Q, cap = Qn, newcap
+        prob.apply(Q[:, k].reshape(prob.Bt, prob.nc, ld), w.reshape(prob.Bt, prob.nc, ld))
+        hcol = torch.zeros((S, k + 1), dtype=dtype, device=dev)
+        for _ in range(2):                                        # CGS2
+            c = K.dense_mm(Q[:, :k + 1, :N], w[:, :, :N])          # (S, 1, k+1): <q_j, w>
+            K.lincomb(Q, c, w, k + 1, 1, coef_layout="ca", alpha=-1.0, beta=1.0)
+            hcol += c[:, 0]
+        hn = w.norm(dim=-1).reshape(S)
+        Q[:, k + 1] = (w / torch.where(hn == 0, torch.full_like(hn, 1.0), hn).reshape(S, 1, 1))[:, 0]
+        col = torch.cat([hcol.double(), hn.double().unsqueeze(-1)], dim=-1).cpu()      # host sync
+        # apply the previous rotations, create the new one (per system, vectorised over S)
+        for j in range(k):
+            a, b2 = col[:, j].clone(), col[:, j + 1].clone()
+            col[:, j] = cs[:, j] * a + sn[:, j] * b2
+            col[:, j + 1] = -sn[:, j] * a + cs[:, j] * b2
+        a, b2 = col[:, k], col[:, k + 1]
+        den = torch.sqrt(a * a + b2 * b2)
+        den = torch.where(den == 0, torch.ones_like(den), den)
+        cs[:, k], sn[:, k] = a / den, b2 / den
+        col[:, k] = cs[:, k] * a + sn[:, k] * b2
+        col[:, k + 1] = 0.0
+        H[:, :k + 2, k] = col
+        g[:, k + 1] = -sn[:, k] * g[:, k]
+        g[:, k] = cs[:, k] * g[:, k]
+        kdim = k + 1
+        est = g[:, k + 1].abs()
+        flags = torch.tensor([float(est.max()), float((~(est < stop)).sum())], dtype=torch.float64)
+        if process_group is not None:
+            fl = flags.to(dev)
+            torch.distributed.all_reduce(fl, op=torch.distributed.ReduceOp.MAX, group=process_group)
+            flags = fl.cpu()
+        if flags[1] == 0:
+            converged = True
+            break
+    # back substitution R y = g on the host, x = Q y on the device
+    ycoef = torch.zeros((S, kdim), dtype=torch.float64)
+    for i in range(kdim - 1, -1, -1):
+        acc = g[:, i].clone()
+        for j in range(i + 1, kdim):
+            acc -= H[:, i, j] * ycoef[:, j]
+        d = H[:, i, i]
+        ycoef[:, i] = acc / torch.where(d == 0, torch.full_like(d, eps), d)
+    x = torch.zeros((S, 1, ld), dtype=dtype, device=dev)
+    yc = ycoef.to(dtype).to(dev).unsqueeze(1).contiguous()          # (S, 1, kdim): "ca" layout
+    K.lincomb(Q, yc, x, kdim, 1, coef_layout="ca", alpha=1.0, beta=0.0)
+    xs = x.reshape(prob.Bt, prob.nc, ld)
+    # true residual (reference computes it every iteration, solve.py:414)
+    tmp = prob.new()
+    prob.apply(xs, tmp)
+    rn = (prob.rhs - tmp).norm(dim=-1).reshape(-1).double().cpu()
+    best = float(rn.max())
+    converged = converged and bool(torch.all(rn < stop * (1 + 1e-6) + 1e-300))
+    if trace is not None:
+        trace.update(niter=niter, napply=prob.napply, converged=converged, best_resid=best)
+    if not converged:
+        warnings.warn(ConvergenceWarning("Convergence is not achieved after %d iterations. "
+                                         "Max norm of resid: %.3e" % (max_niter, best)))
+    return prob.solution(xs)
+
+
+# ------------------------------------------------------------------------------- root-finder based
+def broyden1_solve(A, B, E=None, M=None, **options):
+    """Solve ``A X - M X E = B`` as a root-finding problem with Broyden's first method
+    (reference: broyden1_solve/_rootfinder_solve, solve.py:447-478)."""
+    from xitorch_amd.optimize.native_root import broyden1
+    nr = A.shape[-1]
+    ncols = B.shape[-1]
+
+    def residual(xi):
+        x = xi.reshape(*xi.shape[:-1], nr, ncols)
+        y = A.mm(x) - B
+        if E is not None:
+            MX = M.mm(x) if M is not None else x
+            y = y - MX * E.unsqueeze(-2)
+        return y.reshape(*xi.shape[:-1], -1)
+
+    bdims = get_batchdims(A, B, E, M)
+    x0 = torch.zeros((*bdims, nr * ncols), dtype=A.dtype, device=A.device)
+    x = broyden1(residual, x0, **options)
+    return x.reshape(*x.shape[:-1], nr, ncols)
