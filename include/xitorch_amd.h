@@ -97,6 +97,74 @@ int xk_small_eigh_f64(const double* T, double* lam, double* Y, double* ws, long 
 int xk_small_eigh_f32(const float* T, float* lam, float* Y, float* ws, long ws_elems, int* sweeps,
                       int B, int k, int p, int uppest, int max_sweeps, long ldt, long sT, void* stream);
 
+/* ---- banded operator (DIA storage) -------------------------------------------------------------
+ * band (B, 2*hb+1, N), band[b,d,i] = A_b[i, i+d-hb]; entries outside the matrix are ignored.
+ * trans=0: Y[b,c,i] = sum_d band[b,d,i] X[b,c,i+d-hb];  trans=1: the transposed operator.
+ * sBand = 0 broadcasts one operator over the batch.  Operator of BASELINE configs[2]; in the
+ * reference a user writes it as a custom `_mv` (cf. ALarge, xitorch/_tests/test_linop_fcns.py:129-150). */
+int xk_banded_mm_f64(const double* band, const double* X, double* Y, int B, int N, int hb, int C,
+                     long sBand, long ldx, long sX, long ldy, long sY, int trans, void* stream);
+int xk_banded_mm_f32(const float* band, const float* X, float* Y, int B, int N, int hb, int C,
+                     long sBand, long ldx, long sX, long ldy, long sY, int trans, void* stream);
+
+/* ---- fused Krylov-loop kernels (K7-K9, K11; xitorch/_impls/linalg/solve.py:143-180, 272-314) ----
+ * Vectors are (S, ld) arrays: S systems (batch member x column), pitch ld (16 B multiple, pads 0).
+ * P* are partial-sum buffers (S, xk_kry_max_partials()); nblk <= that many blocks per system.
+ * Per-system scalars (rho, alpha, omega) are device arrays of S elements.  eps = the reference's
+ * `_safedenom` replacement of exact zeros (solve.py:437-439). */
+int xk_kry_max_partials(void);
+/* P1[s] <- partials of <x1,y1>, P2[s] (optional) <- <x2,y2>; if E != NULL first y1 -= E[s]*shiftz */
+int xk_kry_dots_f64(const double* x1, double* y1, const double* x2, const double* y2, const double* shiftz,
+                    const double* E, double* P1, double* P2, int S, int N, long ld, int nblk, void* stream);
+int xk_kry_dots_f32(const float* x1, float* y1, const float* x2, const float* y2, const float* shiftz,
+                    const float* E, float* P1, float* P2, int S, int N, long ld, int nblk, void* stream);
+/* p = r + beta (p - omega v), beta = rho_new/safe(rho_old) * alpha/safe(omega); rho_store <- rho_new
+ * (rho_old and rho_store must be different arrays); first=1: p = r  (solve.py:273-276) */
+int xk_bicg_p_f64(const double* r, double* p, const double* v, const double* Prho_new, const double* rho_old,
+                  const double* alpha, const double* omega, double* rho_store, int S, int N, long ld,
+                  int nblk, double eps, int first, void* stream);
+int xk_bicg_p_f32(const float* r, float* p, const float* v, const float* Prho_new, const float* rho_old,
+                  const float* alpha, const float* omega, float* rho_store, int S, int N, long ld,
+                  int nblk, double eps, int first, void* stream);
+/* s = r - alpha v, alpha = rho / safe(<r0,v>)  (solve.py:279,282) */
+int xk_bicg_s_f64(const double* r, const double* v, double* s, const double* rho, const double* Pr0v,
+                  double* alpha_store, int S, int N, long ld, int nblk, double eps, void* stream);
+int xk_bicg_s_f32(const float* r, const float* v, float* s, const float* rho, const float* Pr0v,
+                  float* alpha_store, int S, int N, long ld, int nblk, double eps, void* stream);
+/* omega = <Kt,Ks>/safe(<Kt,Kt>); xout = x + alpha*yd + omega*zd; unless skip_r: r = s - omega t and
+ * Prr <- |r|^2, Prho <- <r0,r>  (solve.py:286-297) */
+int xk_bicg_final_f64(const double* x, double* xout, const double* yd, const double* zd, const double* s,
+                      const double* t, double* r, const double* r0, const double* alpha, const double* Pts,
+                      const double* Ptt, double* omega_store, double* Prr, double* Prho, int S, int N,
+                      long ld, int nblk, double eps, int skip_r, void* stream);
+int xk_bicg_final_f32(const float* x, float* xout, const float* yd, const float* zd, const float* s,
+                      const float* t, float* r, const float* r0, const float* alpha, const float* Pts,
+                      const float* Ptt, float* omega_store, float* Prr, float* Prho, int S, int N,
+                      long ld, int nblk, double eps, int skip_r, void* stream);
+/* r = b - y; Prr <- |r|^2; Prho (optional) <- <r0,r> (or |r|^2 when r0 is NULL)  (solve.py:148-149, 290-291) */
+int xk_kry_resid_f64(const double* b, const double* y, double* r, const double* r0, double* Prr,
+                     double* Prho, int S, int N, long ld, int nblk, void* stream);
+int xk_kry_resid_f32(const float* b, const float* y, float* r, const float* r0, float* Prr, float* Prho,
+                     int S, int N, long ld, int nblk, void* stream);
+/* alpha = <r,z>/safe(<p,Ap>); xout = x + alpha p; unless skip_r: r -= alpha Ap, Prr <- |r|^2  (solve.py:144-155) */
+int xk_cg_update_f64(const double* x, double* xout, const double* p, const double* Ap, double* r,
+                     const double* Prz, const double* PpAp, double* Prr, int S, int N, long ld, int nblk,
+                     double eps, int skip_r, void* stream);
+int xk_cg_update_f32(const float* x, float* xout, const float* p, const float* Ap, float* r, const float* Prz,
+                     const float* PpAp, float* Prr, int S, int N, long ld, int nblk, double eps, int skip_r,
+                     void* stream);
+/* p = z + beta p, beta = <r,z>_new / safe(<r,z>_old)  (solve.py:171-173) */
+int xk_cg_p_f64(const double* z, double* p, const double* Prz_new, const double* Prz_old, int S, int N,
+                long ld, int nblk, double eps, void* stream);
+int xk_cg_p_f32(const float* z, float* p, const float* Prz_new, const float* Prz_old, int S, int N, long ld,
+                int nblk, double eps, void* stream);
+/* rnorm[s] = sqrt(sum Prr[s,:]); status[0] = max_s rnorm (NaN -> +inf), status[1] = #{s: !(rnorm < stop[s])}
+ * (the stopping test of solve.py:157,166,301,310 — read back once per iteration) */
+int xk_kry_status_f64(const double* Prr, const double* stop, double* rnorm, double* status, int S, int nblk,
+                      void* stream);
+int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double* status, int S, int nblk,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

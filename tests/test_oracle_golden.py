@@ -1,0 +1,64 @@
+"""not-gpu: the oracle (CPU restatement) against the golden outputs of the REAL reference.
+
+The fixtures under tests/golden/ were produced by tests/golden/make_golden.py, which imports the
+reference from /root/reference and also asserts bit-equality with the oracle at generation time.
+Here (no reference available) the oracle must still reproduce them.
+"""
+import os
+import warnings
+import numpy as np
+import pytest
+import torch
+from oracle import ops as oops, symeig as osym, solve as osolve, rootfinder as oroot
+from tests import cases
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FAST_DAVIDSON = [c for c in cases.DAVIDSON_CASES if c["n"] <= 600 or c["kind"] != "alarge"]
+
+
+@pytest.mark.parametrize("case", FAST_DAVIDSON, ids=[c["name"] for c in FAST_DAVIDSON])
+def test_oracle_davidson(case):
+    gold = np.load(os.path.join(GOLD, "davidson_%s.npz" % case["name"]))
+    mat = cases.davidson_matrix(case)
+    tr = {}
+    ev, X = osym.davidson(oops.DenseOp(mat, True), case["neig"], case["mode"], min_eps=case["min_eps"], trace=tr)
+    scale = max(1.0, np.abs(gold["evals"]).max())
+    assert np.abs(ev.numpy() - gold["evals"]).max() <= 1e-11 * scale
+    assert np.abs(ev.numpy() - gold["evals_exact"]).max() <= 1e-10 * scale
+    assert abs(tr["niter"] - int(gold["niter"])) <= 1       # bit-equal on the generating machine
+    assert (torch.matmul(mat, X) - X * ev.unsqueeze(-2)).abs().max().item() <= 10 * case["min_eps"]
+
+
+@pytest.mark.parametrize("case", cases.SOLVE_CASES, ids=[c["name"] for c in cases.SOLVE_CASES])
+def test_oracle_solve(case):
+    gold = np.load(os.path.join(GOLD, "solve_%s.npz" % case["name"]))
+    A, B, E, M = cases.solve_inputs(case)
+    oA = oops.DenseOp(oops.BandedOp(A).fullmatrix(), False) if case["op"] == "banded" else \
+        oops.DenseOp(A, case["hermitian"])
+    oM = oops.DenseOp(M, True) if M is not None else None
+    tr = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        X = getattr(osolve, case["method"])(oA, B, E, oM, trace=tr, **case["kwargs"])
+    assert np.abs(X.numpy() - gold["X"]).max() <= 1e-9 * max(1.0, np.abs(gold["X"]).max())
+    assert abs(tr["niter"] - int(gold["niter"])) <= 1
+
+
+@pytest.mark.parametrize("case", cases.ROOT_CASES, ids=[c["name"] for c in cases.ROOT_CASES])
+def test_oracle_root(case):
+    gold = np.load(os.path.join(GOLD, "root_%s.npz" % case["name"]))
+    fcn, y0, params = cases.root_inputs(case)
+    tr = {}
+    y = oroot.broyden1(fcn, y0, params, trace=tr, **case["kwargs"])
+    assert np.abs(y.numpy() - gold["y"]).max() <= 1e-10
+    assert tr["nfev"] == int(gold["nfev"])
+
+
+def test_banded_op_matches_dense():
+    from xitorch_amd import synthetic as syn
+    band = syn.banded(2, 300, hb=7)
+    op = oops.BandedOp(band)
+    full = op.fullmatrix()
+    x = torch.randn(2, 300, 3, dtype=torch.float64)
+    assert torch.allclose(op._mm(x), torch.matmul(full, x))
+    assert torch.allclose(op._rmm(x), torch.matmul(full.transpose(-2, -1), x))

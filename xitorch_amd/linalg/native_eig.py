@@ -27,6 +27,7 @@ from xitorch_amd import kernels as K
 from xitorch_amd._capi import NativeLibraryError
 from xitorch_amd._util import bcast_shape
 from xitorch_amd.linalg._panel import PanelOperator, pad_len
+from xitorch_amd.dist import allreduce_max_
 
 __all__ = ["davidson", "exacteig", "take_eigpairs"]
 
@@ -237,8 +238,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
             K.lincomb(Vs, Y, X, k, p, coef_layout="ac", alpha=1.0, beta=0.0)
         status[0] = rmax.max()
         status[1] = info.max()
-        if process_group is not None:
-            torch.distributed.all_reduce(status, op=torch.distributed.ReduceOp.MAX, group=process_group)
+        allreduce_max_(status, process_group)
         max_resid, bad = status.tolist()                                       # the one host sync
         if bad != 0:
             raise RuntimeError("xitorch_amd davidson: the panel Gram matrix is not positive definite "

@@ -20,6 +20,7 @@ from xitorch_amd import kernels as K
 from xitorch_amd._capi import NativeLibraryError, fn, ptr, stream_ptr, check, suffix
 from xitorch_amd._util import bcast_shape, pad_shapes, ConvergenceWarning
 from xitorch_amd.linalg._panel import PanelOperator, pad_len, to_panel, from_panel
+from xitorch_amd.dist import allreduce_max_
 
 __all__ = ["exactsolve", "custom_exactsolve", "cg", "bicgstab", "gmres", "broyden1_solve", "get_batchdims"]
 
@@ -225,9 +226,8 @@ class _Kry:
         """-> (max residual norm over all systems, number of unconverged systems): the one host sync."""
         check(fn("xk_kry_status_" + self.sfx)(ptr(Prr), ptr(stop), ptr(self.rnorm), ptr(self.status), self.S,
                                               self.nblk, stream_ptr()), "xk_kry_status")
-        if process_group is not None:
-            # MAX over the ranks of both entries: max residual, and "someone is unconverged" (count > 0)
-            torch.distributed.all_reduce(self.status, op=torch.distributed.ReduceOp.MAX, group=process_group)
+        # MAX over the ranks of both entries: max residual, and "someone is unconverged" (count > 0)
+        allreduce_max_(self.status, process_group)
         mx, nbad = self.status.tolist()
         return mx, nbad
 
@@ -528,9 +528,7 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
         est = g[:, k + 1].abs()
         flags = torch.tensor([float(est.max()), float((~(est < stop)).sum())], dtype=torch.float64)
         if process_group is not None:
-            fl = flags.to(dev)
-            torch.distributed.all_reduce(fl, op=torch.distributed.ReduceOp.MAX, group=process_group)
-            flags = fl.cpu()
+            flags = allreduce_max_(flags.to(dev), process_group).cpu()
         if flags[1] == 0:
             converged = True
             break

@@ -1,1 +1,3 @@
-__all__ = []
+from xitorch_amd.optimize.rootfinder import rootfinder
+
+__all__ = ["rootfinder"]
