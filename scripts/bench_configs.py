@@ -1,0 +1,97 @@
+"""Secondary BASELINE.json configs on one GPU (parity cases measured, not the headline bench line).
+    python scripts/bench_configs.py c3 c4 c5     -> one JSON line per config
+"""
+import json, math, os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import xitorch_amd as xa
+from xitorch_amd import synthetic as syn
+from xitorch_amd.linalg import symeig
+from xitorch_amd.linalg import native_krylov as nk
+from xitorch_amd.linalg._panel import PanelOperator
+from xitorch_amd.optimize import rootfinder
+
+dev = torch.device("cuda:0")
+
+
+def ev_ms(events):
+    return [a.elapsed_time(b) for (a, b, p) in events]
+
+
+def c3(B=256, N=65536, hb=63):
+    band = syn.banded(B, N, hb=hb, device=dev)
+    xs = syn.banded_rhs_solution(B, N, device=dev)
+    A = xa.BandedLinearOperator(band)
+    Bm = A.mm(xs)
+    # time the operator apply alone
+    op = PanelOperator(A, [B], B, N)
+    X = torch.zeros(B, 1, N, dtype=torch.float64, device=dev); X[:, 0] = xs[..., 0]
+    Y = torch.zeros_like(X)
+    op.apply(X, Y); torch.cuda.synchronize()
+    op.events = []
+    for _ in range(5):
+        op.apply(X, Y)
+    torch.cuda.synchronize()
+    ap = sum(ev_ms(op.events)) / 5
+    bytes_apply = B * (2 * hb + 1) * N * 8 + 2 * B * N * 8
+    tr = {}
+    nk.bicgstab(A, Bm, rtol=1e-10, atol=1e-12, posdef=True)           # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        Xs = nk.bicgstab(A, Bm, rtol=1e-10, atol=1e-12, posdef=True, trace=tr)
+    torch.cuda.synchronize(); t = time.perf_counter() - t0
+    err = (Xs - xs).abs().max().item()
+    return {"config": "c3 bicgstab banded", "B": B, "N": N, "hb": hb, "solve_ms": t * 1e3, "niter": tr["niter"],
+            "napply": tr["napply"], "max_err_vs_xstar": err, "banded_apply_ms": ap,
+            "banded_apply_GBps": bytes_apply / ap / 1e6, "frac_of_8TBps": bytes_apply / ap / 1e6 / 8000,
+            "solves_per_s": B / t}
+
+
+def c4(B=64, N=4096):
+    A = syn.root_matrix(B, N, device=dev) * 2.0
+    y0 = torch.zeros(B, N, dtype=torch.float64, device=dev)
+    dm = xa.linop.dense_apply
+
+    def fcn(y, A_):
+        return torch.tanh(xa.LinearOperator.m(A_, is_hermitian=False).mv(y) + 0.1) + y / 2.0
+    Ad = A.clone().requires_grad_()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    y = rootfinder(fcn, y0, params=(Ad,), method="broyden1", alpha=-1.0, max_rank=32, f_tol=1e-8,
+                   bck_options=dict(method="bicgstab", posdef=True, rtol=1e-10))
+    torch.cuda.synchronize(); tf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g, = torch.autograd.grad(y.sum(), (Ad,))
+    torch.cuda.synchronize(); tb = time.perf_counter() - t0
+    return {"config": "c4 rootfinder broyden1 tanh(A y)", "B": B, "N": N, "fwd_ms": tf * 1e3, "bwd_ms": tb * 1e3,
+            "fnorm": fcn(y, Ad).norm().item(), "grad_finite": bool(torch.isfinite(g).all())}
+
+
+def c5(B=16, N=32768, p=6):
+    mat = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    syn.dense_symmetric(B, N, "S1", dtype=torch.float32, device=dev, out=mat)
+    A = xa.MatrixLinearOperator(mat, True)
+    ev = []
+    for i in range(2):
+        tr = {"k1_events": ev if i == 1 else None}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.no_grad():
+            evals, _ = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=2e-3, rng_device="device",
+                              max_niter=60, trace=tr)
+        torch.cuda.synchronize(); t = time.perf_counter() - t0
+    ms = [a.elapsed_time(b) for (a, b, pc) in ev if pc == p]
+    k1b = B * N * N * 4 + 2 * B * N * p * 4
+    exact = syn.spectrum("S1", N, device=dev)[:p]
+    return {"config": "c5 symeig fp32 per-GPU shard (16 x 32768^2)", "B": B, "N": N, "ms": t * 1e3, "niter": tr["niter"],
+            "eigpairs_per_s": B * p / t, "k1_ms": sum(ms) / len(ms), "k1_GBps": k1b / (sum(ms) / len(ms)) / 1e6,
+            "max_eval_err": (evals.double() - exact).abs().max().item()}
+
+
+if __name__ == "__main__":
+    for name in sys.argv[1:] or ["c3", "c4", "c5"]:
+        try:
+            r = {"c3": c3, "c4": c4, "c5": c5}[name]()
+        except Exception as e:      # keep going: this is a measurement script
+            r = {"config": name, "error": repr(e)}
+        print(json.dumps(r), flush=True)
+        torch.cuda.empty_cache()
