@@ -54,6 +54,18 @@ int xk_dense_mm_f32(const float* A, const float* X, float* Y, float* ws, long ws
                     int B, int M, int N, int P, long lda, long sA, long ldx, long sX,
                     long ldy, long sY, int trans, int rows_hint, int stagger, void* stream);
 
+/* ---- K1s: the same product for EXACTLY symmetric storage, reading only the upper triangle ------
+ * Y[b,c,:] = A_b X[b,c,:] with A_b == A_b^T bit for bit (the caller's promise): every tile on or
+ * above the diagonal is streamed once and feeds both y_I += A_IJ x_J and y_J += A_IJ^T x_I, i.e.
+ * about half the HBM traffic of xk_dense_mm.  Used for the eigensolver panel product
+ * (xitorch/_impls/linalg/symeig.py:163,221; symeig requires a Hermitian operator, linalg/symeig.py:103).
+ * N must be a multiple of the 16 B vector width; ws: xk_dense_symm_workspace_elems(B,N,P,sizeof(T)). */
+long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size);
+int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, long ws_elems, int B,
+                      int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,
+                      int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+
 /* ---- basis maintenance of the block eigensolver (K2/K4/K5/K6) ------------------------------
  * Panels must be PADDED: pitch a multiple of 16 B and >= N rounded up to 16 B, pads zero.
  *

@@ -103,3 +103,25 @@ def test_small_eigh_vs_oracle(dev, B, k, p, uppest, dtype):
     G = torch.matmul(Yc.transpose(-2, -1), Yc)
     assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 100
     assert int(sweeps.max()) < 16
+
+
+@pytest.mark.parametrize("B,N,P,dtype", [(2, 2048, 6, torch.float64), (3, 1536, 4, torch.float64),
+                                         (2, 1000, 6, torch.float64), (1, 512, 1, torch.float64),
+                                         (2, 130, 3, torch.float64), (1, 3072, 7, torch.float64),
+                                         (2, 2, 2, torch.float64), (2, 4096, 6, torch.float32),
+                                         (1, 1100, 5, torch.float32)])
+def test_dense_symm_vs_oracle(dev, B, N, P, dtype):
+    # symmetric-storage K1s (upper triangle only) against the oracle's full dense product
+    g = torch.Generator().manual_seed(N + P)
+    R = torch.randn(B, N, N, dtype=dtype, generator=g)
+    A = R + R.transpose(-2, -1)                                   # exactly symmetric
+    assert torch.equal(A, A.transpose(-2, -1))
+    X = torch.randn(B, P, N, dtype=dtype, generator=g)
+    ref = oops.DenseOp(A.double(), True)._mm(X.double().transpose(-2, -1)).transpose(-2, -1)
+    Y = K.dense_symm(A.to(dev), X.to(dev)).cpu().double()
+    tol = 1e-13 if dtype == torch.float64 else 3e-6
+    assert (Y - ref).abs().max().item() / ref.abs().max().item() < tol * N ** 0.5
+    # the lower triangle must never be read: poison it
+    Ap = torch.triu(A) + torch.tril(torch.full_like(A, float("nan")), -1)
+    Y2 = K.dense_symm(Ap.to(dev), X.to(dev)).cpu().double()
+    assert torch.equal(Y2, Y) or (Y2 - Y).abs().max().item() < tol * ref.abs().max().item()

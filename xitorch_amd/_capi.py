@@ -61,6 +61,9 @@ def _declare(L):
         sigs["xk_small_eigh_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, I, Lg, Lg, P])
     sigs["xk_small_eigh_workspace_elems"] = (Lg, [I, I, I])
     sigs["xk_kry_max_partials"] = (I, [])
+    sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
+    for sfx in ("f64", "f32"):
+        sigs["xk_dense_symm_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):
         sigs["xk_banded_mm_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
         sigs["xk_kry_dots_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, P])

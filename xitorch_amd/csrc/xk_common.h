@@ -77,6 +77,30 @@ template <int NV> struct HalvingStages {
 template <> struct HalvingStages<1> { static constexpr int value = 0; };
 template <> struct HalvingStages<0> { static constexpr int value = 0; };
 
+// gfx950 half-exchange primitives: v_permlane32_swap swaps lanes 32-63 of `a` with lanes 0-31 of `b`;
+// v_permlane16_swap swaps the odd 16-lane rows of `a` with the even rows of `b`.  After the swap
+// a' + b' is, in the low half (even rows), the pair-sum of the ORIGINAL a and, in the high half
+// (odd rows), the pair-sum of the original b — exactly one stage of the transposing reduction with
+// no select and no LDS-crossbar traffic.
+__device__ __forceinline__ double swap_add32(double a, double b) {
+  auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ float swap_add32(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <typename T, int NV>
 __device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane) {
   constexpr int H0 = HalvingStages<NV>::value;
@@ -85,6 +109,17 @@ __device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane) {
 #pragma unroll
   for (int s = 0; s < H; ++s) {
     const int mask = 32 >> s;
+    if (s < 2) {
+      // stages with masks 32 and 16: half-exchange swaps (lane with the stage bit clear ends up with
+      // the pair-sum of the even-indexed value, its partner with that of the odd-indexed one)
+      const int half0 = cnt / 2;
+#pragma unroll
+      for (int i = 0; i < NV / 2; ++i) {
+        if (i < half0) v[i] = (s == 0) ? swap_add32(v[2 * i], v[2 * i + 1]) : swap_add16(v[2 * i], v[2 * i + 1]);
+      }
+      cnt = half0;
+      continue;
+    }
     const bool hi = (lane & mask) != 0;
     const int half = cnt / 2;
 #pragma unroll

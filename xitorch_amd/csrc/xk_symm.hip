@@ -1,0 +1,303 @@
+// xitorch_amd :: K1s — operator-panel product for EXACTLY symmetric dense storage, reading only the
+// upper triangle:   Y[b,c,:] = A_b X[b,c,:],  A_b = A_b^T.
+//
+// The general K1 (xk_dense.hip) streams all N^2 elements per panel product.  A symmetric matrix
+// carries every off-diagonal value twice, so here each tile on/above the diagonal is read ONCE
+// and used for both of its contributions
+//        y_I += A_IJ x_J      (row part)          y_J += A_IJ^T x_I     (column part)
+// which halves the HBM traffic of the eigensolver's panel product (symeig operators are always
+// Hermitian: xitorch/linalg/symeig.py:103).  Opt-in: the caller asserts exact symmetry of the
+// storage (MatrixLinearOperator(..., symmetric_storage=True)); for merely "allclose" symmetric
+// input (LinearOperator.m's check, linop.py:97-105) the general kernel keeps the reference's
+// full-matrix semantics.
+//
+// Mapping.  Tiles of TRH=1024 rows x 1024 columns (fp64; 2048 columns fp32).  One 256-thread block
+// per tile; the 4 waves own 4 x 256 columns (lane: two 16 B vectors, so each load instruction is a
+// contiguous 1 KB and the cross-lane reduction is amortised over twice the data), and walk down the
+// tile's rows in chunks of 4:
+//   * column part: per-lane register accumulators acc_col[P][VN] over the whole tile (panel
+//     values x_I are wave-uniform scalar loads);
+//   * row part: per-lane products a[r]*x_J (x_J held in registers for the tile), folded across
+//     the 64 lanes by the transposing wave reduction, then added into an LDS accumulator
+//     rowacc[1024][P] (ds_add_f64; 48 KB for P=6);
+//   * tile results go to partial buffers  rowP[J][c][i]  /  colP[I][c][j]  (one slot per column slab /
+//     row tile) and a fold kernel adds, for every output element, exactly the slots that exist:
+//        y[c][n] = sum_{J >= 2*(n>>10)} rowP[J][c][n] + sum_{I <= n>>10} colP[I][c][n].
+//   Tiles crossing the diagonal mask the strictly-lower elements (and count the diagonal once).
+//
+// Traffic per launch: B*N^2*s/2 (+6 % for the crossing tiles) + 2 * B*(NS+NT)*P*N*s of partials
+// (7 %) — vs B*N^2*s for the general kernel.
+#include "xk_common.h"
+
+namespace xk {
+
+constexpr int SYMM_TRH = 1024;   // rows per tile
+
+constexpr int SYMM_NU = 2;      // 16 B vectors per lane per row: a wave spans 2 x 64 x VN columns
+constexpr int SYMM_R = 4;       // rows per chunk (8 loads = 8 KB in flight per wave)
+
+// one chunk = SYMM_R rows x (SYMM_NU*64*VN) columns per wave
+template <typename T, int P, bool CROSSING, bool TAIL>
+__device__ __forceinline__ void symm_chunk(
+    const T* __restrict__ Ab, const T* __restrict__ Xb, long lda, long ldx, int N, int i0, int i_end,
+    const int (&jj)[SYMM_NU], const bool (&colok)[SYMM_NU], int row_tile0,
+    typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
+    T* rowacc, int lane) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int R = SYMM_R, NU = SYMM_NU;
+  VT a[R][NU];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int row = i0 + r;
+    if (TAIL) row = row < N ? row : N - 1;          // clamped duplicate rows are masked below
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (colok[u]) {
+        a[r][u] = ld_stream(reinterpret_cast<const VT*>(Ab + (long)row * lda + jj[u]));
+      } else {                                       // lanes past the last column still join the reduction
+#pragma unroll
+        for (int v = 0; v < VN; ++v) a[r][u][v] = T(0);
+      }
+    }
+  }
+  T prow[R * P];
+#pragma unroll
+  for (int h = 0; h < R / 2; ++h) {
+    // panel values of 2 rows: wave-uniform scalar loads, a small batch at a time (SGPR budget)
+    T xi[P][2];
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int row = i0 + 2 * h + q;
+        if (TAIL) row = row < N ? row : N - 1;
+        xi[c][q] = Xb[(long)c * ldx + row];
+      }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 2 * h + q;
+      const int row = i0 + r;
+      T s[P];
+#pragma unroll
+      for (int c = 0; c < P; ++c) s[c] = T(0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        VT ar = a[r][u], ac = a[r][u];
+        if (CROSSING) {
+#pragma unroll
+          for (int v = 0; v < VN; ++v) {
+            if (jj[u] + v < row) { ar[v] = T(0); ac[v] = T(0); }   // strictly lower: the mirror tile's job
+            if (jj[u] + v == row) ac[v] = T(0);                    // diagonal: counted once (row part)
+          }
+        }
+        if (TAIL) {
+          if (row >= i_end) {
+#pragma unroll
+            for (int v = 0; v < VN; ++v) { ar[v] = T(0); ac[v] = T(0); }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < P; ++c)
+#pragma unroll
+          for (int v = 0; v < VN; ++v) {
+            acc_col[u][c][v] += ac[v] * xi[c][q];
+            s[c] += ar[v] * xJ[u][c][v];
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < P; ++c) prow[r * P + c] = s[c];
+    }
+  }
+  // fold the 64 lanes (half-exchange swaps), then the owning lanes add into the LDS row accumulator
+  wave_reduce_scatter<T, R * P>(prow, lane);
+  if (wave_rs_is_writer<R * P>(lane)) {
+#pragma unroll
+    for (int w = 0; w < WaveRsCount<R * P>::value; ++w) {
+      const int idx = wave_rs_orig_index<R * P>(w, lane);      // = r*P + c
+      const int r = idx / P, c = idx - r * P;
+      const int lrow = i0 + r - row_tile0;
+      if (!TAIL || i0 + r < i_end)
+        __hip_atomic_fetch_add(&rowacc[lrow * P + c], prow[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+template <typename T, int P, bool CROSSING>
+__device__ __forceinline__ void symm_tile_rows(
+    const T* __restrict__ Ab, const T* __restrict__ Xb, long lda, long ldx, int N, int i_begin, int i_end,
+    const int (&jj)[SYMM_NU], const bool (&colok)[SYMM_NU], int row_tile0,
+    typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
+    T* rowacc, int lane) {
+  const int full_end = i_begin + ((i_end - i_begin) / SYMM_R) * SYMM_R;
+  for (int i0 = i_begin; i0 < full_end; i0 += SYMM_R)
+    symm_chunk<T, P, CROSSING, false>(Ab, Xb, lda, ldx, N, i0, i_end, jj, colok, row_tile0, acc_col, xJ, rowacc, lane);
+  if (full_end < i_end)
+    symm_chunk<T, P, CROSSING, true>(Ab, Xb, lda, ldx, N, full_end, i_end, jj, colok, row_tile0, acc_col, xJ, rowacc, lane);
+}
+
+template <typename T, int P>
+__global__ __launch_bounds__(256) void dense_symm_tiles(
+    const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int ntiles,
+    int N, long lda, long sA, long ldx, long sX, int NS, int NT) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int NU = SYMM_NU;
+  constexpr int WCOLS = NU * 64 * VN;          // columns per wave
+  constexpr int SLAB = 4 * WCOLS;              // columns per block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
+  const int b = blockIdx.x / ntiles;
+  const int tix = blockIdx.x - b * ntiles;
+  // tile list in row-tile-major order: row tile I owns the column slabs J >= (I*TRH)/SLAB
+  int I = 0, J = 0;
+  {
+    int rem = tix;
+    for (;; ++I) {
+      const int jmin = (I * SYMM_TRH) / SLAB;
+      const int cnt = NS - jmin;
+      if (rem < cnt) { J = jmin + rem; break; }
+      rem -= cnt;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = I * SYMM_TRH;
+  const int col0 = J * SLAB;
+  int jj[NU];
+  bool colok[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    jj[u] = col0 + wave * WCOLS + u * 64 * VN + lane * VN;      // each load instruction: 1 KB contiguous
+    colok[u] = jj[u] < N;
+  }
+  const T* Ab = A + (long)b * sA;
+  const T* Xb = X + (long)b * sX;
+  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
+  __syncthreads();
+
+  // rows of this tile that can hold an element on/above the diagonal: i <= last column of the slab
+  int i_end = row0 + SYMM_TRH;
+  const int col_last = col0 + SLAB - 1;
+  if (i_end > col_last + 1) i_end = col_last + 1;
+  if (i_end > N) i_end = N;
+  const bool crossing = (i_end - 1 >= col0);   // some row index reaches the first column: mask needed
+  VT acc_col[NU][P], xJ[NU][P];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+#pragma unroll
+      for (int v = 0; v < VN; ++v) acc_col[u][c][v] = T(0);
+      if (colok[u]) {
+        xJ[u][c] = *reinterpret_cast<const VT*>(Xb + (long)c * ldx + jj[u]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VN; ++v) xJ[u][c][v] = T(0);
+      }
+    }
+  if (crossing)
+    symm_tile_rows<T, P, true>(Ab, Xb, lda, ldx, N, row0, i_end, jj, colok, row0, acc_col, xJ, rowacc, lane);
+  else
+    symm_tile_rows<T, P, false>(Ab, Xb, lda, ldx, N, row0, i_end, jj, colok, row0, acc_col, xJ, rowacc, lane);
+  __syncthreads();
+  // flush: row partial slot J (rows of this tile), column partial slot I (columns of this slab)
+  T* rp = rowP + (((long)b * NS + J) * P) * (long)N;
+  const int nrows = (row0 + SYMM_TRH <= N ? SYMM_TRH : N - row0);
+  for (int idx = threadIdx.x; idx < nrows * P; idx += 256) {
+    const int c = idx / nrows, lr = idx - c * nrows;
+    rp[(long)c * N + row0 + lr] = rowacc[lr * P + c];
+  }
+  T* cp = colP + (((long)b * NT + I) * P) * (long)N;
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    if (colok[u]) {
+#pragma unroll
+      for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(cp + (long)c * N + jj[u]) = acc_col[u][c];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, const T* __restrict__ colP,
+                                                  T* __restrict__ Y, int N, int P, int NS, int NT, int slab,
+                                                  long ldy, long sY, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*P*N
+  if (idx >= total) return;
+  const long per_b = (long)P * N;
+  const long b = idx / per_b;
+  const long rem = idx - b * per_b;
+  const int c = (int)(rem / N);
+  const int n = (int)(rem - (long)c * N);
+  const int It = n / SYMM_TRH;                 // row tile of n
+  const int Jfirst = (It * SYMM_TRH) / slab;   // first column slab that owns a tile with row tile It
+  T s = T(0);
+  for (int J = Jfirst; J < NS; ++J) s += rowP[(((long)b * NS + J) * P + c) * (long)N + n];
+  const int Imax = ((n / slab) * slab + slab - 1) / SYMM_TRH;   // row tiles I with I*TRH <= last column of n's slab
+  for (int I = 0; I <= Imax && I < NT; ++I) s += colP[(((long)b * NT + I) * P + c) * (long)N + n];
+  Y[b * sY + (long)c * ldy + n] = s;
+}
+
+}  // namespace xk
+
+extern "C" {
+
+// workspace (elements): row partials (B, NS, P, N) + column partials (B, NT, P, N)
+long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
+  const int vn = 16 / elem_size;
+  const long slab = 256L * vn * xk::SYMM_NU;
+  const long NS = (N + slab - 1) / slab, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;
+  const long pc = P > 6 ? 6 : P;
+  return (long)B * (NS + NT) * pc * N;
+}
+
+#define XK_DEFINE_SYMM(SUF, T)                                                                              \
+  int xk_dense_symm_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P, long lda, \
+                          long sA, long ldx, long sX, long ldy, long sY, void* stream) {                    \
+    if (B < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                                         \
+    if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
+    constexpr int VN = xk::Vec16<T>::n;                                                                     \
+    constexpr int SLAB = 256 * VN * xk::SYMM_NU;                                                            \
+    if ((N % VN) || (lda % VN) || (sA % VN) || (ldx % VN) || (sX % VN) || ((uintptr_t)A & 15) ||             \
+        ((uintptr_t)X & 15) || ((uintptr_t)ws & 15))                                                        \
+      return XK_ERR_UNSUPPORTED;                                                                            \
+    hipStream_t st = (hipStream_t)stream;                                                                   \
+    const int NS = (N + SLAB - 1) / SLAB, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;                       \
+    int nt = 0;                                                                                             \
+    for (int I = 0; I < NT; ++I) nt += NS - (I * xk::SYMM_TRH) / SLAB;                                      \
+    int c0 = 0;                                                                                             \
+    while (c0 < P) {                                                                                        \
+      const int pc = (P - c0) >= 6 ? 6 : (P - c0);                                                          \
+      const long nrow = (long)B * NS * pc * N, ncol = (long)B * NT * pc * N;                                \
+      if (ws_elems < nrow + ncol) return XK_ERR_ARG;                                                        \
+      T* rowP = ws;                                                                                         \
+      T* colP = ws + nrow;                                                                                  \
+      const size_t lds = (size_t)xk::SYMM_TRH * pc * sizeof(T);                                             \
+      const dim3 grid((unsigned)((long)B * nt));                                                            \
+      const T* Xc = X + (long)c0 * ldx;                                                                     \
+      switch (pc) {                                                                                         \
+        XK_SYMM_CASE(1) XK_SYMM_CASE(2) XK_SYMM_CASE(3) XK_SYMM_CASE(4) XK_SYMM_CASE(5) XK_SYMM_CASE(6)     \
+      }                                                                                                     \
+      XK_LAUNCH_CHECK();                                                                                    \
+      const long total = (long)B * pc * N;                                                                  \
+      hipLaunchKernelGGL((xk::symm_fold<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rowP, \
+                         colP, Y + (long)c0 * ldy, N, pc, NS, NT, SLAB, ldy, sY, total);                    \
+      XK_LAUNCH_CHECK();                                                                                    \
+      c0 += pc;                                                                                             \
+    }                                                                                                       \
+    return XK_OK;                                                                                           \
+  }
+
+#define XK_SYMM_CASE(PP)                                                                                  \
+  case PP:                                                                                                \
+    hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP>), grid, dim3(256), lds, st, A, Xc, rowP, colP, nt,   \
+                       N, lda, sA, ldx, sX, NS, NT);                                                      \
+    break;
+
+#define TT double
+XK_DEFINE_SYMM(f64, double)
+#undef TT
+#define TT float
+XK_DEFINE_SYMM(f32, float)
+#undef TT
+
+}  // extern "C"

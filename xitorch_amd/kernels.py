@@ -179,3 +179,29 @@ def banded_mm(band, X, out=None, trans=False):
                                                 ldy, sY, 1 if trans else 0, stream_ptr())
     check(rc, "xk_banded_mm")
     return out
+
+
+# --------------------------------------------------------------------------- K1s symmetric storage
+def dense_symm(A, X, out=None):
+    """Y[b,c,:] = A_b X[b,c,:] for EXACTLY symmetric A (B or 1, N, N): only the upper triangle is read.
+    The caller guarantees A == A^T bit for bit.  X, Y panel-major (B, P, N)."""
+    require_device(A, "operator matrix")
+    require_device(X, "panel")
+    B, P, N = X.shape
+    if A.dim() == 2:
+        lda, sA = A.stride(0), 0
+    else:
+        lda, sA = A.stride(1), (A.stride(0) if A.shape[0] != 1 else 0)
+    if A.shape[-1] != N or A.shape[-2] != N or (N > 1 and A.stride(-1) != 1):
+        raise _capi.NativeLibraryError("symmetric operator must be (.., %d, %d) with unit stride" % (N, N))
+    ldx, sX = _panel_strides(X)
+    if out is None:
+        out = torch.empty((B, P, N), dtype=X.dtype, device=X.device)
+    ldy, sY = _panel_strides(out)
+    esize = 8 if X.dtype == torch.float64 else 4
+    nws = fn("xk_dense_symm_workspace_elems")(B, N, P, esize)
+    ws = _workspace(nws, X.dtype, X.device)
+    rc = fn("xk_dense_symm_" + suffix(X.dtype))(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA,
+                                                 ldx, sX, ldy, sY, stream_ptr())
+    check(rc, "xk_dense_symm")
+    return out

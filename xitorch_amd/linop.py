@@ -61,12 +61,16 @@ class LinearOperator(EditableModule):
     def m(cls, mat, is_hermitian=None):
         """Wrap a (batched) matrix; ``is_hermitian=None`` checks the symmetry, ``True`` asserts it
         (reference: linop.py:59-107)."""
+        exact = False
         if is_hermitian is None:
-            is_hermitian = mat.shape[-2] == mat.shape[-1] and _is_hermitian_matrix(mat)
+            is_hermitian, exact = _is_hermitian_matrix(mat)
         elif is_hermitian:
-            if not _is_hermitian_matrix(mat):
+            ok, exact = _is_hermitian_matrix(mat)
+            if not ok:
                 raise RuntimeError("The linear operator is indicated to be hermitian, but the matrix is not")
-        return MatrixLinearOperator(mat, is_hermitian)
+        # the symmetry scan above also tells whether the storage is EXACTLY symmetric; only then may the
+        # native apply read the upper triangle alone (K1s) without changing the reference's semantics
+        return MatrixLinearOperator(mat, is_hermitian, symmetric_storage=bool(is_hermitian and exact))
 
     def __init__(self, shape, is_hermitian=False, dtype=None, device=None, _suppress_hermit_warning=False):
         super(LinearOperator, self).__init__()
@@ -461,10 +465,13 @@ class MatrixLinearOperator(LinearOperator):
     """Dense operator.  HIP float32/float64 matrices are applied by the K1 kernel
     (replaces linop.py:676-708 of the reference)."""
 
-    def __init__(self, mat, is_hermitian):
+    def __init__(self, mat, is_hermitian, symmetric_storage=False):
         super().__init__(shape=mat.shape, is_hermitian=is_hermitian, dtype=mat.dtype, device=mat.device,
                          _suppress_hermit_warning=True)
         self.mat = mat
+        # True = the caller (or LinearOperator.m's scan) guarantees mat == mat^T bit for bit; the native
+        # eigensolver / Krylov loops then stream only the upper triangle (xk_dense_symm)
+        self.symmetric_storage = bool(symmetric_storage) and bool(is_hermitian) and not torch.is_complex(mat)
 
     def __repr__(self):
         return "MatrixLinearOperator with shape %s:\n   %s" % (_shape2str(self.shape), _indent(repr(self.mat), 3))
@@ -600,16 +607,22 @@ class BandedLinearOperator(LinearOperator):
 
 # ------------------------------------------------------------------------ helpers
 def _is_hermitian_matrix(mat):
+    """-> (hermitian within torch.allclose like the reference's check, exactly hermitian bit for bit)."""
     if mat.shape[-2] != mat.shape[-1]:
-        return False
+        return False, False
     if mat.numel() <= (1 << 24) or mat.dim() == 2:
-        return bool(torch.allclose(mat, mat.transpose(-2, -1).conj()))
+        mt = mat.transpose(-2, -1).conj()
+        close = bool(torch.allclose(mat, mt))
+        return close, close and bool(torch.equal(mat, mt))
     # large batched matrices: one member at a time, to bound the temporaries
     flat = mat.reshape(-1, *mat.shape[-2:])
+    exact = True
     for i in range(flat.shape[0]):
-        if not torch.allclose(flat[i], flat[i].transpose(-2, -1).conj()):
-            return False
-    return True
+        mt = flat[i].transpose(-2, -1).conj()
+        if not torch.allclose(flat[i], mt):
+            return False, False
+        exact = exact and bool(torch.equal(flat[i], mt))
+    return True, exact
 
 
 def checklinop(linop):
