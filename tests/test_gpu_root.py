@@ -82,3 +82,15 @@ def test_other_methods_and_errors(dev):
         return nr.broyden1(f, y0_, params, alpha=-1.0, f_tol=1e-9)
     rootfinder(fcn, yd, params=(Ad,), method=mymethod)
     assert called["ok"]
+
+
+def test_broyden_uv0_svd_and_rank_restart(dev):
+    # uv0="svd": rank-1 SVD of the Jacobian (native davidson on the autograd operator) seeds the model
+    fcn, y0, (A,) = cases.root_inputs(dict(kind="tanh", nbatch=2, n=10))
+    tr = {}
+    y = nr.broyden1(fcn, y0.to(dev), (A.to(dev),), alpha=-1.0, uv0="svd", f_tol=1e-9, trace=tr)
+    assert fcn(y, A.to(dev)).abs().max().item() < 1e-7 and tr["converged"]
+    # max_rank small: the history is dropped as a whole whenever it overflows (quirk Q3) and it still converges
+    tr2 = {}
+    y2 = nr.broyden1(fcn, y0.to(dev), (A.to(dev),), alpha=-1.0, max_rank=3, f_tol=1e-9, trace=tr2)
+    assert fcn(y2, A.to(dev)).abs().max().item() < 1e-7 and tr2["rank"] <= 4

@@ -130,3 +130,26 @@ def test_zero_rhs_shortcut(dev):
     A = xa.LinearOperator.m(torch.eye(8, dtype=torch.float64, device=dev) * 2, is_hermitian=True)
     X = nk.cg(A, torch.zeros(8, 2, dtype=torch.float64, device=dev))
     assert torch.all(X == 0)
+
+
+def test_preconditioned_cg_and_bicgstab(dev):
+    # precond / precond_l / precond_r are LinearOperators applied inside the native loops (solve.py:73,196-197)
+    g = torch.Generator().manual_seed(31)
+    n = 120
+    R = torch.rand(2, n, n, dtype=torch.float64, generator=g)
+    d = torch.linspace(1.0, 50.0, n, dtype=torch.float64)
+    Asym = ((R + R.transpose(-2, -1)) * 0.05 + torch.diag(d)).to(dev)
+    Agen = (0.1 * R + torch.diag(d)).to(dev)
+    Bm = torch.rand(2, n, 2, dtype=torch.float64, generator=g).to(dev)
+    Pinv = xa.LinearOperator.m(torch.diag(1.0 / d).to(dev), is_hermitian=True)       # Jacobi preconditioner
+    tr0, tr1 = {}, {}
+    x0 = nk.cg(xa.LinearOperator.m(Asym, True), Bm, rtol=1e-10, posdef=True, trace=tr0)
+    x1 = nk.cg(xa.LinearOperator.m(Asym, True), Bm, rtol=1e-10, posdef=True, precond=Pinv, trace=tr1)
+    ref = torch.linalg.solve(Asym, Bm)
+    assert torch.allclose(x0, ref, rtol=1e-7, atol=1e-9) and torch.allclose(x1, ref, rtol=1e-7, atol=1e-9)
+    assert tr1["niter"] < tr0["niter"]                    # the preconditioner must actually be used
+    for kw in (dict(precond_r=Pinv), dict(precond_l=Pinv), dict(precond_l=Pinv, precond_r=Pinv)):
+        x = nk.bicgstab(xa.LinearOperator.m(Agen, False), Bm, rtol=1e-10, posdef=True, **kw)
+        assert torch.allclose(x, torch.linalg.solve(Agen, Bm), rtol=1e-7, atol=1e-9), kw
+    with pytest.raises(TypeError):
+        nk.cg(xa.LinearOperator.m(Asym, True), Bm, precond=torch.eye(n))
