@@ -66,6 +66,20 @@ int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, l
 int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,
                       int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
 
+/* ---- K1w: wide panels on the matrix cores (MFMA) --------------------------------------------
+ * Y[b,c,n] = sum_i A[b,i,n] Xrm[b,i,c]  (= A^T X; = A X for a Hermitian operator), c < P <= 32, in ONE
+ * pass over A (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64, exact FMA chains).  Xrm is ROW-major
+ * (B, M, PP) with PP = xk_dense_wide_padded_width(P) zero-padded columns; Y panel-major (B, P, N).
+ * Requires N % 128 == 0 (fp32) / N % 32 == 0 (fp64).  Many-column torch.matmul(mat, x) of
+ * MatrixLinearOperator._mm/_rmm (xitorch/_core/linop.py:695-702), e.g. solve with ncols = 50
+ * (benchmarks/benchmarks_solve.py:11-15). */
+long xk_dense_wide_workspace_elems(int B, int M, int N, int P, int elem_size);
+int xk_dense_wide_padded_width(int P, int elem_size);
+int xk_dense_wide_f32(const float* A, const float* Xrm, float* Y, float* ws, long ws_elems, int B, int M,
+                      int N, int P, long lda, long sA, long ldxr, long sXr, long ldy, long sY, void* stream);
+int xk_dense_wide_f64(const double* A, const double* Xrm, double* Y, double* ws, long ws_elems, int B, int M,
+                      int N, int P, long lda, long sA, long ldxr, long sXr, long ldy, long sY, void* stream);
+
 /* ---- basis maintenance of the block eigensolver (K2/K4/K5/K6) ------------------------------
  * Panels must be PADDED: pitch a multiple of 16 B and >= N rounded up to 16 B, pads zero.
  *

@@ -15,7 +15,8 @@ CASES = [
     (2, 99, 131, 3, torch.float32, False), (2, 256, 384, 6, torch.float64, True),
     (3, 100, 131, 4, torch.float64, True), (2, 300, 200, 7, torch.float32, True),
     (1, 2048, 2048, 6, torch.float64, True), (4, 1, 64, 2, torch.float64, False),
-    (1, 64, 2, 3, torch.float64, True),
+    (1, 64, 2, 3, torch.float64, True), (2, 300, 256, 16, torch.float64, True), (1, 200, 130, 12, torch.float64, True),
+    (2, 128, 128, 29, torch.float64, True), (1, 256, 256, 50, torch.float32, True), (1, 96, 96, 50, torch.float64, False),
 ]
 
 
@@ -125,3 +126,24 @@ def test_dense_symm_vs_oracle(dev, B, N, P, dtype):
     Ap = torch.triu(A) + torch.tril(torch.full_like(A, float("nan")), -1)
     Y2 = K.dense_symm(Ap.to(dev), X.to(dev)).cpu().double()
     assert torch.equal(Y2, Y) or (Y2 - Y).abs().max().item() < tol * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,M,N,P,dtype", [(2, 512, 256, 32, torch.float32), (1, 300, 128, 17, torch.float32),
+                                           (2, 256, 384, 12, torch.float32), (2, 512, 64, 16, torch.float64),
+                                           (1, 130, 96, 32, torch.float64), (2, 77, 32, 25, torch.float64),
+                                           (1, 256, 256, 50, torch.float64), (1, 1024, 1024, 50, torch.float32)])
+def test_dense_wide_mfma_vs_oracle(dev, B, M, N, P, dtype):
+    # K1w: Y = A^T X for many panel columns on the matrix cores (asymmetric A catches transposed fragments)
+    g = torch.Generator().manual_seed(M + N + P)
+    A = torch.randn(B, M, N, dtype=dtype, generator=g)
+    X = torch.randn(B, P, M, dtype=dtype, generator=g)
+    ref = oops.DenseOp(A.double())._rmm(X.double().transpose(-2, -1)).transpose(-2, -1)
+    Y = K.dense_mm(A.to(dev), X.to(dev), trans=True).cpu().double()          # dispatches to K1w for P >= 12
+    Yv = K.dense_mm(A.to(dev), X.to(dev), trans=True, wide=False).cpu().double()
+    tol = 1e-13 if dtype == torch.float64 else 3e-6
+    scale = ref.abs().max().item()
+    assert (Y - ref).abs().max().item() / scale < tol * M ** 0.5
+    assert (Yv - ref).abs().max().item() / scale < tol * M ** 0.5
+    if P <= 32:
+        Yw = K.dense_wide(A.to(dev), X.to(dev)).cpu().double()
+        assert torch.equal(Yw, Y)

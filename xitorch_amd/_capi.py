@@ -62,6 +62,10 @@ def _declare(L):
     sigs["xk_small_eigh_workspace_elems"] = (Lg, [I, I, I])
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
+    sigs["xk_dense_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
+    sigs["xk_dense_wide_padded_width"] = (I, [I, I])
+    for sfx in ("f64", "f32"):
+        sigs["xk_dense_wide_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):
         sigs["xk_dense_symm_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):

@@ -405,6 +405,19 @@ static int rmm_cols(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, i
                     long lda, long sA, long ldx, long sX, long ldy, long sY, hipStream_t st) {
   int c0 = 0;
   while (c0 < P) {
+    // the column-oriented kernel keeps P*VN accumulators per lane and takes its panel values from scalar
+    // loads, so a 16-wide block still streams A at the HBM rate: wide panels (many right-hand sides) cost
+    // ceil(P/16) passes over the operator instead of ceil(P/8)
+    if (P - c0 >= 12) {
+      const int pw = (P - c0) >= 16 ? 16 : 12;
+      const T* Xw = X + (long)c0 * ldx;
+      T* Yw = Y + (long)c0 * ldy;
+      const int rcw = pw == 16 ? rmm_cols_p<T, 16>(A, Xw, Yw, ws, ws_elems, B, M, N, lda, sA, ldx, sX, ldy, sY, st)
+                               : rmm_cols_p<T, 12>(A, Xw, Yw, ws, ws_elems, B, M, N, lda, sA, ldx, sX, ldy, sY, st);
+      if (rcw != XK_OK) return rcw;
+      c0 += pw;
+      continue;
+    }
     const int pc = (P - c0) >= 8 ? 8 : (P - c0);
     const T* Xc = X + (long)c0 * ldx;
     T* Yc = Y + (long)c0 * ldy;
@@ -443,8 +456,8 @@ long xk_dense_mm_workspace_elems(int B, int M, int N, int P, int trans) {
     }
     return ns > 1 ? (long)ns * B * pc * M : 0;
   }
-  // trans=1 slab partials: at most ceil(2048/(B*ct)) slabs of (P<=8, N) per batch member
-  const int pc = P > 8 ? 8 : P;
+  // trans=1 slab partials: at most ceil(2048/(B*ct)) slabs of (P<=16, N) per batch member
+  const int pc = P > 16 ? 16 : P;
   const int ct = (N + 511) / 512;
   long nslab = (2048 + (long)B * ct - 1) / ((long)B * ct);
   long max_slab = (M + 63) / 64;

@@ -196,8 +196,12 @@ __global__ __launch_bounds__(256) void dense_symm_tiles(
         for (int v = 0; v < VN; ++v) xJ[u][c][v] = T(0);
       }
     }
-  if (crossing)
-    symm_tile_rows<T, P, true>(Ab, Xb, lda, ldx, N, row0, i_end, jj, colok, row0, acc_col, xJ, rowacc, lane);
+  if (crossing) {
+    // rows below this WAVE's last column hold only strictly-lower elements for it: stop there
+    int w_end = col0 + (wave + 1) * WCOLS;
+    w_end = w_end < i_end ? w_end : i_end;
+    symm_tile_rows<T, P, true>(Ab, Xb, lda, ldx, N, row0, w_end, jj, colok, row0, acc_col, xJ, rowacc, lane);
+  }
   else
     symm_tile_rows<T, P, false>(Ab, Xb, lda, ldx, N, row0, i_end, jj, colok, row0, acc_col, xJ, rowacc, lane);
   __syncthreads();

@@ -1,0 +1,216 @@
+// xitorch_amd :: K1w — WIDE operator-panel product on the matrix cores (MFMA).
+//
+//   Y[b, c, n] = sum_i A[b, i, n] * X[b, i, c]        c < P <= 32   (i.e. Y = A^T X; = A X for Hermitian A)
+//
+// The VALU kernels of xk_dense.hip keep P <= 8 (16) panel columns per pass; a solve with many
+// right-hand sides (benchmarks/benchmarks_solve.py: ncols = 50) or an eigensolve with a wide block then
+// re-streams the operator ceil(P/8) times.  Here one pass serves up to 32 columns.  At that width the
+// arithmetic intensity (2P/s flop per byte: 16 flop/B for fp32, P = 32) is beyond what fp32 VALU code
+// sustains while streaming (the guide measures ~52 TF for VALU vs 122-147 TF for MFMA f32), so the
+// contraction runs on v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64 — exact fp32/fp64 FMA chains, same
+// numerics as the VALU kernels — and stays HBM-bound (MFMA busy ~ 2/3 at P = 32).
+//
+// Operand mapping (column orientation, all global loads coalesced, no LDS):
+//   MFMA "M" = operator columns n, "K" = operator rows i (the contraction), "N" = panel columns c.
+//   A operand: lane l holds A[i0 + (l >> SH)][n0 + VN*(l & MSK) + q]: a 16 B vector load per lane gives
+//     VN consecutive columns = the A operands of VN MFMAs (q = 0..VN-1); one load instruction covers
+//     K rows x (VN*(MSK+1)) columns in contiguous 128/256 B runs.
+//   B operand: X is given ROW-major (B, M, PP) (PP = padded panel width), so lane l reads
+//     X[i0 + (l >> SH)][c0 + (l & MSK)]: contiguous 128 B runs.
+//   D: per wave VN tiles of (MSK+1) x (MSK+1) accumulators over the whole row slab; slab partials go to
+//     the same (B, nslab, P, N) workspace layout as dense_rmm_cols and are folded by fold_slabs.
+#include "xk_common.h"
+
+namespace xk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  static constexpr int TM = 32, TK = 2, SH = 5, MSK = 31, NACC = 16;
+  typedef f32x16 acc_t;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  // D element `r` of lane l: row m(r, l), column c = l & 31
+  static __device__ __forceinline__ int drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+template <> struct Mfma<double> {
+  static constexpr int TM = 16, TK = 4, SH = 4, MSK = 15, NACC = 4;
+  typedef f64x4 acc_t;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int drow(int r, int lane) { return (lane >> 4) + 4 * r; }
+};
+
+// NT = number of panel-column tiles of width TM handled per wave (P <= NT*TM)
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void dense_wide_cols(
+    const T* __restrict__ A, const T* __restrict__ Xrm, T* __restrict__ W, int M, int N, long lda, long sA,
+    long ldxr, long sXr, int P, int col_tiles, int nslab, int rows_per_slab) {
+  typedef typename Vec16<T>::type VT;
+  typedef Mfma<T> MM;
+  typedef typename MM::acc_t acc_t;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int WCOLS = VN * MM::TM;            // operator columns per wave (128 fp32 / 32 fp64)
+  int bid = blockIdx.x;
+  const int ct = bid % col_tiles; bid /= col_tiles;
+  const int slab = bid % nslab;
+  const int b = bid / nslab;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n0 = (ct * 4 + wave) * WCOLS;
+  if (n0 >= N) return;                           // whole wave out of range (N % WCOLS handled by the launcher)
+  const int kk = lane >> MM::SH;                 // which of the TK rows of a step this lane feeds
+  const int mm = lane & MM::MSK;
+  const T* Ab = A + (long)b * sA + n0 + VN * mm;
+  const T* Xb = Xrm + (long)b * sXr + mm;
+  const int i0 = slab * rows_per_slab;
+  int i1 = i0 + rows_per_slab; i1 = i1 < M ? i1 : M;
+  acc_t acc[NT][VN];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < VN; ++q)
+#pragma unroll
+      for (int r = 0; r < MM::NACC; ++r) acc[t][q][r] = T(0);
+  constexpr int U = 8;                           // steps in flight (8 KB of A per wave)
+  int i = i0;
+  for (; i + U * MM::TK <= i1; i += U * MM::TK) {
+    VT av[U];
+    T bv[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long row = i + u * MM::TK + kk;
+      av[u] = ld_stream(reinterpret_cast<const VT*>(Ab + row * lda));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[u][t] = Xb[row * ldxr + t * MM::TM];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < VN; ++q) acc[t][q] = MM::mma(av[u][q], bv[u][t], acc[t][q]);
+  }
+  for (; i < i1; i += MM::TK) {                  // tail steps: rows past the slab end contribute zeros
+    const long row = i + kk;
+    const bool ok = row < i1;
+    VT a1;
+    if (ok) a1 = ld_stream(reinterpret_cast<const VT*>(Ab + row * lda));
+    else {
+#pragma unroll
+      for (int q = 0; q < VN; ++q) a1[q] = T(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const T b1 = ok ? Xb[row * ldxr + t * MM::TM] : T(0);
+#pragma unroll
+      for (int q = 0; q < VN; ++q) acc[t][q] = MM::mma(a1[q], b1, acc[t][q]);
+    }
+  }
+  // slab partial: W[b][slab][c][n], c < P, n = n0 + VN*m + q
+  T* Wb = W + (((long)b * nslab + slab) * P) * (long)N;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = t * MM::TM + mm;
+    if (c < P) {
+#pragma unroll
+      for (int q = 0; q < VN; ++q)
+#pragma unroll
+        for (int r = 0; r < MM::NACC; ++r) {
+          const int n = n0 + VN * MM::drow(r, lane) + q;
+          Wb[(long)c * N + n] = acc[t][q][r];
+        }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wide_fold(const T* __restrict__ W, T* __restrict__ Y, int N, int P,
+                                                  int nslab, long ldy, long sY, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*P*N
+  if (idx >= total) return;
+  const long per_b = (long)P * N;
+  const long b = idx / per_b;
+  const long rem = idx - b * per_b;
+  const int c = (int)(rem / N);
+  const int n = (int)(rem - (long)c * N);
+  T s = T(0);
+  for (int k = 0; k < nslab; ++k) s += W[(((long)b * nslab + k) * P + c) * (long)N + n];
+  Y[b * sY + (long)c * ldy + n] = s;
+}
+
+template <typename T>
+static int wide_nslab(int B, int M, int N) {
+  constexpr int WC = Vec16<T>::n * Mfma<T>::TM * 4;   // columns per block
+  const int ct = (N + WC - 1) / WC;
+  int nslab = (2048 + B * ct - 1) / (B * ct);
+  const int max_slab = (M + 127) / 128;
+  if (nslab > max_slab) nslab = max_slab;
+  return nslab < 1 ? 1 : nslab;
+}
+
+template <typename T>
+static int wide_cols(const T* A, const T* Xrm, T* Y, T* ws, long ws_elems, int B, int M, int N, int P, long lda,
+                     long sA, long ldxr, long sXr, long ldy, long sY, hipStream_t st) {
+  typedef Mfma<T> MM;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int WCOLS = VN * MM::TM;
+  if (P > 32 || P < 1) return XK_ERR_ARG;
+  if ((N % WCOLS) || (lda % VN) || (sA % VN) || ((uintptr_t)A & 15)) return XK_ERR_UNSUPPORTED;
+  const int NT = (P + MM::TM - 1) / MM::TM;           // fp32: 1; fp64: 1 or 2
+  if (ldxr < (long)NT * MM::TM) return XK_ERR_ARG;    // X must be padded to whole tiles
+  const int ct = (N + 4 * WCOLS - 1) / (4 * WCOLS);
+  int nslab = wide_nslab<T>(B, M, N);
+  while ((long)B * nslab * P * (long)N > ws_elems && nslab > 1) --nslab;
+  if ((long)B * nslab * P * (long)N > ws_elems) return XK_ERR_ARG;
+  int rps = (M + nslab - 1) / nslab;
+  rps = (rps + MM::TK - 1) / MM::TK * MM::TK;         // whole MFMA K-steps per slab
+  nslab = (M + rps - 1) / rps;
+  const dim3 grid((unsigned)((long)B * nslab * ct));
+  if (NT == 1)
+    hipLaunchKernelGGL((dense_wide_cols<T, 1>), grid, dim3(256), 0, st, A, Xrm, ws, M, N, lda, sA, ldxr, sXr, P, ct,
+                       nslab, rps);
+  else
+    hipLaunchKernelGGL((dense_wide_cols<T, 2>), grid, dim3(256), 0, st, A, Xrm, ws, M, N, lda, sA, ldxr, sXr, P, ct,
+                       nslab, rps);
+  XK_LAUNCH_CHECK();
+  const long tot = (long)B * P * N;
+  hipLaunchKernelGGL((wide_fold<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, Y, N, P, nslab, ldy,
+                     sY, tot);
+  XK_LAUNCH_CHECK();
+  return XK_OK;
+}
+
+}  // namespace xk
+
+extern "C" {
+
+long xk_dense_wide_workspace_elems(int B, int M, int N, int P, int elem_size) {
+  const int ns = elem_size == 8 ? xk::wide_nslab<double>(B, M, N) : xk::wide_nslab<float>(B, M, N);
+  return (long)B * ns * P * (long)N;
+}
+
+// padded panel width the row-major X must have: whole MFMA tiles (32 for fp32; 16 or 32 for fp64)
+int xk_dense_wide_padded_width(int P, int elem_size) {
+  const int tm = elem_size == 8 ? 16 : 32;
+  return (P + tm - 1) / tm * tm;
+}
+
+int xk_dense_wide_f32(const float* A, const float* Xrm, float* Y, float* ws, long ws_elems, int B, int M, int N,
+                      int P, long lda, long sA, long ldxr, long sXr, long ldy, long sY, void* stream) {
+  if (B < 0 || M < 0 || N < 0) return XK_ERR_ARG;
+  if (B == 0 || M == 0 || N == 0) return XK_OK;
+  return xk::wide_cols<float>(A, Xrm, Y, ws, ws_elems, B, M, N, P, lda, sA, ldxr, sXr, ldy, sY, (hipStream_t)stream);
+}
+int xk_dense_wide_f64(const double* A, const double* Xrm, double* Y, double* ws, long ws_elems, int B, int M, int N,
+                      int P, long lda, long sA, long ldxr, long sXr, long ldy, long sY, void* stream) {
+  if (B < 0 || M < 0 || N < 0) return XK_ERR_ARG;
+  if (B == 0 || M == 0 || N == 0) return XK_OK;
+  return xk::wide_cols<double>(A, Xrm, Y, ws, ws_elems, B, M, N, P, lda, sA, ldxr, sXr, ldy, sY, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -31,7 +31,7 @@ def _workspace(nelem, dtype, device):
     return w
 
 
-def dense_mm(A, X, out=None, trans=False, rows_hint=0, stagger=1):
+def dense_mm(A, X, out=None, trans=False, rows_hint=0, stagger=1, wide=True):
     """Y[b,c,:] = A[b] @ X[b,c,:]  (trans=False)   or   A[b]^T @ X[b,c,:]  (trans=True).
 
     A: (B, M, N) or (M, N) (broadcast over the panel batch), unit stride along N.
@@ -61,6 +61,12 @@ def dense_mm(A, X, out=None, trans=False, rows_hint=0, stagger=1):
     if out is None:
         out = torch.empty((B, P, nout), dtype=X.dtype, device=X.device)
     ldy, sY = _panel_strides(out)
+    if trans and wide and P >= WIDE_MIN_P and _wide_ok(A, N, lda, sA):
+        # many columns: one MFMA pass per 32 columns instead of one VALU pass per 8/16
+        for c0 in range(0, P, 32):
+            pc = min(32, P - c0)
+            dense_wide(A, X[:, c0:c0 + pc], out=out[:, c0:c0 + pc])
+        return out
     ws, ws_n = None, 0
     ws_n = fn("xk_dense_mm_workspace_elems")(B, M, N, P, 1 if trans else 0)
     if ws_n > 0:
@@ -204,4 +210,43 @@ def dense_symm(A, X, out=None):
     rc = fn("xk_dense_symm_" + suffix(X.dtype))(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA,
                                                  ldx, sX, ldy, sY, stream_ptr())
     check(rc, "xk_dense_symm")
+    return out
+
+
+# --------------------------------------------------------------------------- K1w wide panels (MFMA)
+WIDE_MIN_P = 12
+
+
+def _wide_ok(A, N, lda, sA):
+    vn = 2 if A.dtype == torch.float64 else 4
+    wcols = 32 if A.dtype == torch.float64 else 128
+    return N % wcols == 0 and lda % vn == 0 and sA % vn == 0 and A.data_ptr() % 16 == 0
+
+
+def dense_wide(A, X, out=None):
+    """Y[b,c,:] = A_b^T X[b,c,:] for up to 32 panel columns in ONE pass over A (MFMA).
+    A (B or 1, M, N); X panel-major (B, P, M); returns panel-major (B, P, N)."""
+    require_device(A, "operator matrix")
+    require_device(X, "panel")
+    B, P, M = X.shape
+    if A.dim() == 2:
+        lda, sA = A.stride(0), 0
+        N = A.shape[1]
+    else:
+        lda, sA = A.stride(1), (A.stride(0) if A.shape[0] != 1 else 0)
+        N = A.shape[2]
+    if A.shape[-2] != M:
+        raise _capi.NativeLibraryError("panel length %d != operator rows %d" % (M, A.shape[-2]))
+    esize = 8 if X.dtype == torch.float64 else 4
+    PP = fn("xk_dense_wide_padded_width")(P, esize)
+    Xrm = torch.zeros((B, M, PP), dtype=X.dtype, device=X.device)      # row-major, zero-padded to whole tiles
+    Xrm[:, :, :P].copy_(X.transpose(1, 2))
+    if out is None:
+        out = torch.empty((B, P, N), dtype=X.dtype, device=X.device)
+    ldy, sY = _panel_strides(out)
+    nws = fn("xk_dense_wide_workspace_elems")(B, M, N, P, esize)
+    ws = _workspace(nws, X.dtype, X.device)
+    rc = fn("xk_dense_wide_" + suffix(X.dtype))(ptr(A), ptr(Xrm), ptr(out), ptr(ws), nws, B, M, N, P, lda, sA,
+                                                 Xrm.stride(1), Xrm.stride(0), ldy, sY, stream_ptr())
+    check(rc, "xk_dense_wide")
     return out

@@ -85,7 +85,7 @@ class PanelOperator:
 
     def _native(self, X, out, trans):
         N = self.N
-        if self.kind == "dense" and self.symm:
+        if self.kind == "dense" and self.symm and X.shape[1] < K.WIDE_MIN_P:
             K.dense_symm(self.mat, X[:, :, :N], out=out[:, :, :N])
         elif self.kind == "dense":
             t = (trans != self.flip)
