@@ -94,3 +94,27 @@ def test_broyden_uv0_svd_and_rank_restart(dev):
     tr2 = {}
     y2 = nr.broyden1(fcn, y0.to(dev), (A.to(dev),), alpha=-1.0, max_rank=3, f_tol=1e-9, trace=tr2)
     assert fcn(y2, A.to(dev)).abs().max().item() < 1e-7 and tr2["rank"] <= 4
+
+
+def test_equilibrium_and_minimize_native(dev):
+    from xitorch_amd.optimize import equilibrium, minimize
+    g = torch.Generator().manual_seed(41)
+    n = 24
+    A = (torch.rand(n, n, dtype=torch.float64, generator=g) * 0.1).to(dev).requires_grad_()
+    y0 = torch.zeros(n, 1, dtype=torch.float64, device=dev)
+
+    def fp(y, a):
+        return torch.tanh(a @ y + 0.1)
+    for method, kw in (("broyden1", dict(alpha=-1.0)), ("anderson_acc", dict())):
+        y = equilibrium(fp, y0, params=(A,), method=method, f_tol=1e-10, x_tol=1e-10, **kw)
+        assert (y - fp(y, A)).abs().max().item() < 1e-8, method
+    gA, = torch.autograd.grad(y.sum(), (A,))
+    assert torch.isfinite(gA).all() and gA.abs().max().item() > 0
+
+    target = torch.linspace(-1, 1, n, dtype=torch.float64, device=dev).unsqueeze(-1)
+
+    def energy(y, a):
+        return 0.5 * ((y - target) ** 2).sum() + 0.25 * (y ** 4).sum() + (a.sum() * 0.0)
+    ym = minimize(energy, y0, params=(A,), method="broyden1", alpha=-1.0, f_tol=1e-10, x_tol=1e-10)
+    grad = (ym - target) + ym ** 3
+    assert grad.abs().max().item() < 1e-8

@@ -331,3 +331,36 @@ def test_synthetic_operators_have_the_advertised_spectrum():
     assert torch.equal(off[0], synthetic.dense_symmetric(4, 64, "S1")[3])
     band = synthetic.banded(2, 50, hb=4)
     assert band.shape == (2, 9, 50) and band[0, 0, 0] == 0 and band[0, 8, 49] == 0
+
+
+# ----------------------------------------------------------------------------- equilibrium / minimize (next rows)
+def test_equilibrium_and_minimize_on_cpu_methods():
+    from xitorch_amd.optimize import equilibrium, minimize
+    A = torch.tensor([[0.3, 0.1], [0.05, 0.2]], dtype=f64).requires_grad_()
+    y0 = torch.zeros((2, 1), dtype=f64)
+
+    def fp(y, a):                      # contraction: y = tanh(a y + 0.1)
+        return torch.tanh(a @ y + 0.1)
+    y = equilibrium(fp, y0, params=(A,), method="anderson_acc", f_tol=1e-12, x_tol=1e-12)
+    assert torch.allclose(y, fp(y, A), atol=1e-10)
+    g, = torch.autograd.grad(y.sum(), (A,))
+    # implicit-function gradient by dense algebra
+    yd = y.detach()
+    J = torch.autograd.functional.jacobian(lambda yy: yy - fp(yy, A.detach()), yd).reshape(2, 2)
+    lam = torch.linalg.solve(J.T, -torch.ones(2, dtype=f64)).reshape(2, 1)
+    Ac = A.detach().clone().requires_grad_()
+    gref, = torch.autograd.grad(yd - fp(yd, Ac), (Ac,), grad_outputs=lam)
+    assert torch.allclose(g, gref, atol=1e-8)
+    y2 = equilibrium(fp, y0, params=(A,), method="linearmixing", alpha=-1.0, f_tol=1e-12, x_tol=1e-12)   # root-finder method
+    assert torch.allclose(y2, y, atol=1e-9)
+
+    def quad(y, a):
+        return ((y - 1.5) ** 2).sum() + 0.5 * (a * y).sum() ** 2 * 0.0 + (a.sum() * 0.0)
+    for method, kw in (("gd", dict(step=0.1, gamma=0.5, maxiter=400, x_rtol=1e-14, f_rtol=1e-16)),
+                       ("adam", dict(step=0.05, maxiter=3000, x_rtol=1e-12, f_rtol=1e-16))):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ym = minimize(quad, y0, params=(A,), method=method, **kw)
+        assert torch.allclose(ym, torch.full_like(ym, 1.5), atol=1e-4), method
+    with pytest.raises(RuntimeError, match="Unknown"):
+        minimize(quad, y0, params=(A,), method="nope")

@@ -1,3 +1,3 @@
-from xitorch_amd.optimize.rootfinder import rootfinder
+from xitorch_amd.optimize.rootfinder import rootfinder, equilibrium, minimize
 
-__all__ = ["rootfinder"]
+__all__ = ["rootfinder", "equilibrium", "minimize"]

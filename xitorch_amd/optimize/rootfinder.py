@@ -12,11 +12,23 @@ from xitorch_amd.linalg.solve import solve
 from xitorch_amd.grad.jachess import jac
 from xitorch_amd.debug import is_debug_enabled
 from xitorch_amd.editable import EditableModule
+from xitorch_amd.purefn import make_sibling
 from xitorch_amd.optimize.native_root import newton, broyden1, broyden2, linearmixing
+from xitorch_amd.optimize.extra import anderson_acc, gd, adam
 
-__all__ = ["rootfinder"]
+__all__ = ["rootfinder", "equilibrium", "minimize"]
 
 _RF_METHODS = {"newton": newton, "broyden1": broyden1, "broyden2": broyden2, "linearmixing": linearmixing}
+_EQUIL_METHODS = {"anderson_acc": anderson_acc}      # fixed-point-only methods (besides all root-finder ones)
+_OPT_METHODS = {"gd": gd, "adam": adam}
+_METHOD_TABLES = {"rootfinder": _RF_METHODS, "equilibrium": _EQUIL_METHODS, "minimizer": _OPT_METHODS}
+
+
+def _debug_check(fcn, args):
+    if is_debug_enabled():
+        import inspect
+        if inspect.ismethod(fcn) and isinstance(fcn.__self__, EditableModule):
+            fcn.__self__.assertparams(fcn, *args)
 
 
 def rootfinder(fcn, y0, params=[], bck_options={}, method=None, **fwd_options):
@@ -46,13 +58,67 @@ def rootfinder(fcn, y0, params=[], bck_options={}, method=None, **fwd_options):
     >>> A = torch.tensor([[1.1, 0.4], [0.3, 0.8]], device="cuda").requires_grad_()
     >>> yroot = rootfinder(func1, torch.zeros((2, 1), device="cuda"), params=(A,))
     """
-    if is_debug_enabled():
-        import inspect
-        if inspect.ismethod(fcn) and isinstance(fcn.__self__, EditableModule):
-            fcn.__self__.assertparams(fcn, y0, *params)
+    _debug_check(fcn, (y0, *params))
     pfunc = get_pure_function(fcn)
     fwd_options["method"] = "broyden1" if method is None else method
     return _RootFinder.apply(pfunc, y0, pfunc, "rootfinder", fwd_options, bck_options, len(params), *params,
+                             *pfunc.objparams())
+
+
+def equilibrium(fcn, y0, params=[], bck_options={}, method=None, **fwd_options):
+    r"""
+    Solve the equilibrium (fixed-point) equation :math:`\mathbf{y} = \mathbf{f}(\mathbf{y}, \theta)`, i.e. the
+    root of :math:`\mathbf{y} - \mathbf{f}(\mathbf{y}, \theta)` (reference: optimize/rootfinder.py:104-184).
+
+    ``method``: any root-finder method (default ``"broyden1"``) or ``"anderson_acc"``; arguments as for
+    :func:`rootfinder`.
+    """
+    _debug_check(fcn, (y0, *params))
+    pfunc = get_pure_function(fcn)
+
+    @make_sibling(pfunc)
+    def deviation(y, *p):
+        return y - pfunc(y, *p)
+
+    method = "broyden1" if method is None else method
+    fwd_options["method"] = method
+    fixed_point_method = isinstance(method, str) and method.lower() in _EQUIL_METHODS
+    fwd_fcn = pfunc if fixed_point_method else deviation
+    alg_type = "equilibrium" if fixed_point_method else "rootfinder"
+    return _RootFinder.apply(deviation, y0, fwd_fcn, alg_type, fwd_options, bck_options, len(params), *params,
+                             *pfunc.objparams())
+
+
+def minimize(fcn, y0, params=[], bck_options={}, method=None, **fwd_options):
+    r"""
+    Solve the unbounded minimisation :math:`\mathbf{y^*} = \arg\min_\mathbf{y} f(\mathbf{y}, \theta)` of a
+    scalar function (reference: optimize/rootfinder.py:186-288).  The solution is differentiable through the
+    stationarity condition :math:`\nabla_y f = 0`.
+
+    ``method``: ``"broyden1"`` (default) or any root-finder method applied to the gradient, or the
+    minimisers ``"gd"`` / ``"adam"``; arguments as for :func:`rootfinder`.
+    """
+    _debug_check(fcn, (y0, *params))
+    pfunc = get_pure_function(fcn)
+    method = "broyden1" if method is None else method
+    fwd_options["method"] = method
+    opt_method = not (isinstance(method, str) and method.lower() in _RF_METHODS)
+
+    @make_sibling(pfunc)
+    def value_and_grad(y, *p):
+        with torch.enable_grad():
+            y1 = y.clone().requires_grad_()
+            z = pfunc(y1, *p)
+        gy, = torch.autograd.grad(z, (y1,), retain_graph=True, create_graph=torch.is_grad_enabled())
+        return z, gy
+
+    @make_sibling(value_and_grad)
+    def grad_only(y, *p):
+        return value_and_grad(y, *p)[1]
+
+    fwd_fcn = value_and_grad if opt_method else grad_only
+    alg_type = "minimizer" if opt_method else "rootfinder"
+    return _RootFinder.apply(grad_only, y0, fwd_fcn, alg_type, fwd_options, bck_options, len(params), *params,
                              *pfunc.objparams())
 
 
@@ -64,7 +130,7 @@ class _RootFinder(torch.autograd.Function):
         params, objparams = allparams[:nparams], allparams[nparams:]
         with fwd_fcn.useobjparams(objparams):
             method = config.pop("method")
-            y = get_method(alg_type, _RF_METHODS, method)(fwd_fcn, y0, params, **config)
+            y = get_method(alg_type, _METHOD_TABLES[alg_type], method)(fwd_fcn, y0, params, **config)
         ctx.fcn = fcn
         ctx.nparams = nparams
         ctx.param_sep = ParamSplitter(allparams)
