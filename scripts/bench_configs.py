@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 
 
 def ev_ms(events):
-    return [a.elapsed_time(b) for (a, b, p) in events]
+    return [a.elapsed_time(b) for (a, b, p, nb) in events]
 
 
 def c3(B=256, N=65536, hb=63):
@@ -79,7 +79,7 @@ def c5(B=16, N=32768, p=6):
             evals, _ = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=2e-3, rng_device="device",
                               max_niter=60, trace=tr)
         torch.cuda.synchronize(); t = time.perf_counter() - t0
-    ms = [a.elapsed_time(b) for (a, b, pc) in ev if pc == p]
+    ms = [a.elapsed_time(b) for (a, b, pc, nb) in ev if pc == p]
     k1b = B * N * N * 4 + 2 * B * N * p * 4
     exact = syn.spectrum("S1", N, device=dev)[:p]
     return {"config": "c5 symeig fp32 per-GPU shard (16 x 32768^2)", "B": B, "N": N, "ms": t * 1e3, "niter": tr["niter"],

@@ -101,3 +101,26 @@ def test_native_requires_device():
     A = xa.LinearOperator.m(torch.eye(8, dtype=torch.float64), True)
     with pytest.raises(RuntimeError):
         davidson(A, 2, "lowest")
+
+
+@pytest.mark.parametrize("B,N", [(4, 512), (5, 384)])
+def test_two_group_pipeline_matches_single_group(dev, B, N):
+    # overlap=True: two batch groups on two HIP streams; must be the same computation as one group
+    from xitorch_amd import synthetic
+    mat = synthetic.dense_symmetric(B, N, "S1").to(dev)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    t1, t2 = {}, {}
+    e1, X1 = davidson(A, 4, "lowest", min_eps=1e-9, overlap=False, trace=t1)
+    e2, X2 = davidson(A, 4, "lowest", min_eps=1e-9, overlap=True, trace=t2)
+    torch.cuda.synchronize()
+    assert t2["groups"] == 2 and t1["groups"] == 1
+    assert t1["niter"] == t2["niter"] and t1["napply"] == t2["napply"]
+    # same iteration; bitwise equality is not expected (the contraction splits depend on the launch's batch size
+    # and K1s accumulates row sums with LDS float atomics), rounding-level agreement is
+    assert torch.allclose(e1, e2, rtol=0, atol=1e-12) and torch.allclose(X1.abs(), X2.abs(), rtol=0, atol=1e-9)
+    assert max(abs(a - b) for a, b in zip(t1["resid_history"], t2["resid_history"])) < 1e-9
+    # the general (non symmetric-storage) kernel path too
+    Ag = xa.MatrixLinearOperator(mat, True, symmetric_storage=False)
+    e3, _ = davidson(Ag, 4, "uppest", min_eps=1e-9, overlap=True)
+    e4, _ = davidson(Ag, 4, "uppest", min_eps=1e-9, overlap=False)
+    assert torch.allclose(e3, e4, rtol=0, atol=1e-11)

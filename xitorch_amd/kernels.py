@@ -23,7 +23,8 @@ _ws_cache = {}
 
 
 def _workspace(nelem, dtype, device):
-    key = (dtype, device)
+    # one scratch buffer per (dtype, device, stream): launches on different streams may run concurrently
+    key = (dtype, device, torch.cuda.current_stream().cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nelem:
         w = torch.empty(max(nelem, 1), dtype=dtype, device=device)

@@ -73,7 +73,7 @@ class PanelOperator:
             e0.record()
             self._native(X, out, trans)
             e1.record()
-            self.events.append((e0, e1, X.shape[1]))
+            self.events.append((e0, e1, X.shape[1], X.shape[0]))
             return out
         if self.kind != "generic":
             return self._native(X, out, trans)

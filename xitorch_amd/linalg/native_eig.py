@@ -79,9 +79,145 @@ def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device="c
     return V.to(device).transpose(-2, -1)
 
 
+class _Group:
+    """State of the Davidson iteration for one contiguous block of the batch, bound to one HIP stream."""
+
+    def __init__(self, opA, opM, B, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes):
+        self.opA, self.opM = opA, opM
+        self.B, self.N, self.Npad, self.p = B, N, Npad, p
+        self.dtype, self.device, self.mode = dtype, device, mode
+        self.small_eigh, self.orth_passes = small_eigh, orth_passes
+        self.cap = min(N, nguess + 8 * p) if N > nguess else nguess
+        z = lambda *shape: torch.zeros(shape, dtype=dtype, device=device)
+        self.Vs, self.AVs = z(B, self.cap, Npad), z(B, self.cap, Npad)
+        self.MVs = z(B, self.cap, Npad) if opM is not None else None
+        self.T = z(B, self.cap, self.cap)
+        self.Wflat = torch.empty((B * 32 * 32,), dtype=dtype, device=device)
+        self.info = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.status = torch.zeros((2,), dtype=torch.float64, device=device)
+        self.rmax = z(B)
+        self.Xbuf = [z(B, p, Npad), z(B, p, Npad)]
+        self.k = 0
+        self.best_slot, self.best_evals = -1, None
+        self.slot, self.lam, self.newpanel, self.nadd = 0, None, None, 0
+
+    def grow(self, need):
+        if need <= self.cap:
+            return
+        new = min(self.N, max(need, 2 * self.cap))
+
+        def bigger(old):
+            buf = torch.zeros((self.B, new, self.Npad), dtype=self.dtype, device=self.device)
+            buf[:, :old.shape[1]].copy_(old)
+            return buf
+        self.Vs, self.AVs = bigger(self.Vs), bigger(self.AVs)
+        if self.MVs is not None:
+            self.MVs = bigger(self.MVs)
+        Tn = torch.zeros((self.B, new, new), dtype=self.dtype, device=self.device)
+        Tn[:, :self.cap, :self.cap].copy_(self.T)
+        self.T, self.cap = Tn, new
+
+    def cholqr(self, k0, q):
+        """Orthonormalise basis rows k0..k0+q among themselves (M-inner product if M)."""
+        N = self.N
+        panel = self.Vs[:, k0:k0 + q]
+        if self.opM is None:
+            G = K.dense_mm(panel[:, :, :N], panel[:, :, :N])
+        else:
+            self.opM.apply(panel, self.MVs[:, k0:k0 + q])
+            G = K.dense_mm(panel[:, :, :N], self.MVs[:, k0:k0 + q, :N])
+        Wq = self.Wflat[:self.B * q * q].view(self.B, q, q)      # compact (B, q, q), as the C ABI expects
+        K.panel_chol(G, Wq, self.info, q)
+        K.panel_transform(panel, Wq, q)
+        if self.opM is not None:
+            K.panel_transform(self.MVs[:, k0:k0 + q], Wq, q)
+
+    def project_out(self, k0, q):
+        """panel <- panel - V (V^H M panel) for the basis rows [0, k0)."""
+        panel = self.Vs[:, k0:k0 + q]
+        basis_for_coef = self.Vs if self.opM is None else self.MVs
+        C = _gram(basis_for_coef, k0, panel, q, self.N)            # C[b,c,a] = <(M)V_a, t_c>
+        K.lincomb(self.Vs, C, panel, k0, q, coef_layout="ca", alpha=-1.0, beta=1.0)
+
+    def extend_T(self, k0, q):
+        """rows/cols k0..k0+q of T = V^T A V from the new A V panel only."""
+        N = self.N
+        Tn = K.dense_mm(self.Vs[:, :k0 + q, :N], self.AVs[:, k0:k0 + q, :N])     # (B, q, k0+q): <V_a, AV_c>
+        self.T[:, k0:k0 + q, :k0 + q] = Tn
+        self.T[:, :k0, k0:k0 + q] = Tn[:, :, :k0].transpose(-2, -1)
+
+    def start(self, V0p, wait_event=None):
+        k = V0p.shape[1]
+        self.grow(k + self.p)
+        self.Vs[:, :k, :self.N].copy_(V0p)
+        self.cholqr(0, k)
+        self.cholqr(0, k)          # CholeskyQR2: the second pass only removes rounding-level loss
+        if wait_event is not None:
+            torch.cuda.current_stream().wait_event(wait_event)
+        self.opA.apply(self.Vs[:, :k], self.AVs[:, :k])
+        done = torch.cuda.Event()
+        done.record()
+        self.extend_T(0, k)
+        self.k = k
+        return done
+
+    def small(self):
+        """Rayleigh-Ritz on the current basis: K3 + fused rotation/residual; leaves {max|resid|, flag} in
+        self.status (device) and the next panel in the basis.  No host sync."""
+        k, p, N = self.k, self.p, self.N
+        if self.small_eigh == "native" and k <= K.SMALL_EIGH_MAX_K and p <= K.SMALL_EIGH_MAX_P:
+            lam, Yt, _ = K.small_eigh(self.T, k, p, uppest=(self.mode != "lowest"))      # K3: LDS Jacobi kernel
+            Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
+        else:
+            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # large bases: library eigh
+            lam, Y = take_eigpairs(lam_all, Y_all, p, self.mode)
+            lam = lam.contiguous()
+        self.grow(min(N, k + p))
+        self.nadd = min(p, N - k)
+        self.slot = 1 - self.best_slot if self.best_slot >= 0 else 0
+        X = self.Xbuf[self.slot]
+        self.rmax.zero_()
+        if self.nadd == p:
+            self.newpanel = self.Vs[:, k:k + p]                 # the next panel is produced in place
+        else:
+            self.newpanel = torch.empty((self.B, p, self.Npad), dtype=self.dtype, device=self.device)
+        if self.opM is None:
+            K.ritz_residual(self.Vs, self.AVs, Y, lam, X, self.newpanel, self.rmax, k, p)
+        else:
+            # residual A X - lam (M X): rotate M V instead of V, then the eigenvectors separately
+            K.ritz_residual(self.MVs, self.AVs, Y, lam, X, self.newpanel, self.rmax, k, p)
+            K.lincomb(self.Vs, Y, X, k, p, coef_layout="ac", alpha=1.0, beta=0.0)
+        self.lam = lam
+        self.status[0] = self.rmax.max()
+        self.status[1] = self.info.max()
+
+    def expand(self, wait_event=None):
+        """Orthonormalise the residual panel against the basis, apply the operator to it, extend T."""
+        k, nadd = self.k, self.nadd
+        if nadd != self.p:
+            self.Vs[:, k:k + nadd].copy_(self.newpanel[:, :nadd])
+        for _ in range(max(1, self.orth_passes)):
+            self.project_out(k, nadd)
+        self.cholqr(k, nadd)
+        if wait_event is not None:
+            torch.cuda.current_stream().wait_event(wait_event)    # panel products of the groups run back to back
+        self.opA.apply(self.Vs[:, k:k + nadd], self.AVs[:, k:k + nadd])
+        done = torch.cuda.Event()
+        done.record()
+        self.extend_T(k, nadd)
+        self.k = k + nadd
+        return done
+
+
+def _sub_operator(A, B, N, b0, b1):
+    from xitorch_amd.linop import MatrixLinearOperator
+    mat = A.mat.reshape(B, N, N)[b0:b1]
+    return MatrixLinearOperator(mat, A.is_hermitian, symmetric_storage=getattr(A, "symmetric_storage", False))
+
+
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
-             rng_device="cpu", small_eigh="native", **unused):
+             rng_device="cpu", small_eigh="native", overlap="auto", **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -109,6 +245,12 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     small_eigh: str
         (extension) ``"native"`` (default): the Rayleigh–Ritz matrix is diagonalised by the LDS Jacobi
         kernel while the basis has <= 128 vectors; ``"library"``: always ``torch.linalg.eigh``
+    overlap: str or bool
+        (extension) ``True``: a batch of native dense operators is processed as two groups on two HIP
+        streams, so that the small Rayleigh–Ritz / orthogonalisation kernels of one group run underneath the
+        operator-panel product of the other (the panel products themselves stay back to back); iteration
+        counts and the stopping rule are unchanged.  ``"auto"`` (default) / ``False``: one group on the current
+        stream — at the benchmark size the two schedules measure the same
     V0: tensor or None
         (extension) start block ``(*batch, na, nguess)`` replacing the random draw
     orth_passes: int
@@ -132,144 +274,116 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         B *= d
     N, Npad = na, _pad(na, dtype)
     p = neig
-    opA = _PanelOperator(A, bdims, B, N)
-    if trace is not None and trace.get("k1_events") is not None:
-        opA.events = trace["k1_events"]         # bench.py: per-launch HIP events of the K1 kernel
-    opM = _PanelOperator(M, bdims, B, N) if M is not None else None
-
-    cap = min(N, nguess + 8 * p) if N > nguess else nguess
-    Vs = torch.zeros((B, cap, Npad), dtype=dtype, device=device)
-    AVs = torch.zeros((B, cap, Npad), dtype=dtype, device=device)
-    MVs = torch.zeros((B, cap, Npad), dtype=dtype, device=device) if M is not None else None
-    T = torch.zeros((B, cap, cap), dtype=dtype, device=device)
-
-    def grow(need):
-        nonlocal Vs, AVs, MVs, T, cap
-        if need <= cap:
-            return
-        new = min(N, max(need, 2 * cap))
-        def bigger(old):
-            buf = torch.zeros((B, new, Npad), dtype=dtype, device=device)
-            buf[:, :old.shape[1]].copy_(old)
-            return buf
-        Vs, AVs = bigger(Vs), bigger(AVs)
-        if MVs is not None:
-            MVs = bigger(MVs)
-        Tn = torch.zeros((B, new, new), dtype=dtype, device=device)
-        Tn[:, :cap, :cap].copy_(T)
-        T, cap = Tn, new
-
-    Wflat = torch.empty((B * 32 * 32,), dtype=dtype, device=device)
-    info = torch.zeros((B,), dtype=torch.int32, device=device)
-    status = torch.zeros((2,), dtype=torch.float64, device=device)
-    rmax = torch.zeros((B,), dtype=dtype, device=device)
-    Xbuf = [torch.zeros((B, p, Npad), dtype=dtype, device=device) for _ in range(2)]
-
-    def cholqr(k0, q):
-        """Orthonormalise basis rows k0..k0+q among themselves (M-inner product if M)."""
-        panel = Vs[:, k0:k0 + q]
-        if opM is None:
-            G = K.dense_mm(panel[:, :, :N], panel[:, :, :N])
-        else:
-            opM.apply(panel, MVs[:, k0:k0 + q])
-            G = K.dense_mm(panel[:, :, :N], MVs[:, k0:k0 + q, :N])
-        Wq = Wflat[:B * q * q].view(B, q, q)          # compact (B, q, q), as the C ABI expects
-        K.panel_chol(G, Wq, info, q)
-        K.panel_transform(panel, Wq, q)
-        if opM is not None:
-            K.panel_transform(MVs[:, k0:k0 + q], Wq, q)
-
-    def project_out(k0, q):
-        """panel <- panel - V (V^H M panel) for the basis rows [0, k0)."""
-        panel = Vs[:, k0:k0 + q]
-        basis_for_coef = Vs if opM is None else MVs
-        C = _gram(basis_for_coef, k0, panel, q, N)            # C[b,c,a] = <(M)V_a, t_c>
-        K.lincomb(Vs, C, panel, k0, q, coef_layout="ca", alpha=-1.0, beta=1.0)
-
-    def extend_T(k0, q):
-        """rows/cols k0..k0+q of T = V^T A V from the new A V panel only."""
-        Tn = K.dense_mm(Vs[:, :k0 + q, :N], AVs[:, k0:k0 + q, :N])     # (B, q, k0+q): <V_a, AV_c>
-        T[:, k0:k0 + q, :k0 + q] = Tn
-        T[:, :k0, k0:k0 + q] = Tn[:, :, :k0].transpose(-2, -1)
-
-    # ---- start block -----------------------------------------------------------------------
-    V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device)       # (B, nguess, N)
-    k = V0p.shape[1]
-    grow(k + p)
-    Vs[:, :k, :N].copy_(V0p)
-    if k > 32:
+    if nguess > 32:
         raise NativeLibraryError("nguess > 32 is not supported by the native panel Cholesky")
     if p > 32:
         raise NativeLibraryError("neig > 32 is not supported by the native davidson")
-    cholqr(0, k)
-    cholqr(0, k)          # CholeskyQR2: the second pass only removes rounding-level loss
-    opA.apply(Vs[:, :k], AVs[:, :k])
-    extend_T(0, k)
+    events = trace.get("k1_events") if trace is not None else None
+
+    # ---- batch groups: one, or two pipelined on two streams ---------------------------------
+    whole = _PanelOperator(A, bdims, B, N)
+    nA = 1
+    for d in A.shape[:-2]:
+        nA *= d
+    # "auto" currently means off: at config-2 size the half-batch panel products lose to block-count
+    # quantisation (8.5 instead of 17 full waves of tiles) what the overlap wins (measured 249.8 vs 249.6 ms)
+    two = overlap is True and M is None and whole.kind == "dense" \
+        and not whole.flip and nA == B and B >= 2
+    if two:
+        h = B // 2
+        spans = [(0, h), (h, B)]
+        ops = [_PanelOperator(_sub_operator(A, B, N, b0, b1), [b1 - b0], b1 - b0, N) for (b0, b1) in spans]
+        cur = torch.cuda.current_stream()
+        streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        for st in streams:
+            st.wait_stream(cur)
+    else:
+        spans, ops, streams = [(0, B)], [whole], [torch.cuda.current_stream()]
+    for op in ops:
+        op.events = events                       # bench.py: per-launch HIP events of the panel product
+    G = len(spans)
+
+    V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device)       # (B, nguess, N)
+    if two:
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+    groups = []
+    k1_done = [None] * G
+    for g, (b0, b1) in enumerate(spans):
+        with torch.cuda.stream(streams[g]):
+            opM = _PanelOperator(M, bdims, B, N) if M is not None else None
+            grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes)
+            k1_done[g] = grp.start(V0p[b0:b1], k1_done[g - 1] if g > 0 else None)
+            groups.append(grp)
 
     best_resid = float("inf")
-    best_evals = None
-    best_slot = -1
     history = []
     stop_reason = "max_niter"
     niter = 0
+    gstat = torch.zeros((2,), dtype=torch.float64, device=device) if process_group is not None else None
     for it in range(max_niter):
         niter = it + 1
-        if small_eigh == "native" and k <= K.SMALL_EIGH_MAX_K and p <= K.SMALL_EIGH_MAX_P:
-            lam, Yt, _ = K.small_eigh(T, k, p, uppest=(mode != "lowest"))      # K3: LDS Jacobi kernel
-            Y = Yt.transpose(1, 2)                                             # (B, k, p) view
-        else:
-            lam_all, Y_all = torch.linalg.eigh(T[:, :k, :k])                   # large bases: library eigh
-            lam, Y = take_eigpairs(lam_all, Y_all, p, mode)
-            lam = lam.contiguous()
-        grow(min(N, k + p))
-        nadd = min(p, N - k)
-        slot = 1 - best_slot if best_slot >= 0 else 0
-        X = Xbuf[slot]
-        rmax.zero_()
-        if nadd == p:
-            newpanel = Vs[:, k:k + p]                 # the next panel is produced in place
-        else:
-            newpanel = torch.empty((B, p, Npad), dtype=dtype, device=device)
-        if opM is None:
-            K.ritz_residual(Vs, AVs, Y, lam, X, newpanel, rmax, k, p)
-        else:
-            # residual A X - lam (M X): rotate M V instead of V, then the eigenvectors separately
-            K.ritz_residual(MVs, AVs, Y, lam, X, newpanel, rmax, k, p)
-            K.lincomb(Vs, Y, X, k, p, coef_layout="ac", alpha=1.0, beta=0.0)
-        status[0] = rmax.max()
-        status[1] = info.max()
-        allreduce_max_(status, process_group)
-        max_resid, bad = status.tolist()                                       # the one host sync
+        local_max, bad = 0.0, 0.0
+        deferred = []
+        for g in range(G):
+            with torch.cuda.stream(streams[g]):
+                groups[g].small()
+                st_g, bad_g = groups[g].status.tolist()               # host waits for THIS group's stream only
+            if st_g != st_g:
+                st_g = float("inf")
+            local_max, bad = max(local_max, st_g), max(bad, bad_g)
+            if g < G - 1:
+                # a local residual above the threshold already rules out global convergence: its expansion is
+                # certain, enqueue it now so its panel product runs under the next group's small kernels
+                if st_g >= min_eps and bad_g == 0 and groups[g].k < N:
+                    with torch.cuda.stream(streams[g]):
+                        k1_done[g] = groups[g].expand(k1_done[(g - 1) % G] if G > 1 else None)
+                else:
+                    deferred.append(g)
+        max_resid = local_max
+        if process_group is not None:
+            with torch.cuda.stream(streams[G - 1]):
+                gstat[0], gstat[1] = local_max, bad
+                allreduce_max_(gstat, process_group)
+                max_resid, bad = gstat.tolist()
         if bad != 0:
             raise RuntimeError("xitorch_amd davidson: the panel Gram matrix is not positive definite "
                                "(linearly dependent guess/residual vectors)")
         history.append(max_resid)
         if verbose:
-            print("Iter %3d (guess size: %d): resid: %.3e" % (it + 1, k, max_resid))
+            print("Iter %3d (guess size: %d): resid: %.3e" % (it + 1, groups[0].k, max_resid))
         if max_resid < best_resid:
-            best_resid, best_evals, best_slot = max_resid, lam, slot
+            best_resid = max_resid
+            for grp in groups:
+                grp.best_slot, grp.best_evals = grp.slot, grp.lam
         if max_resid < min_eps:
             stop_reason = "converged"
             break
-        if k == N:
+        if groups[0].k == N:
             stop_reason = "full_basis"
             break
-        if nadd != p:
-            Vs[:, k:k + nadd].copy_(newpanel[:, :nadd])
-        for _ in range(max(1, orth_passes)):
-            project_out(k, nadd)
-        cholqr(k, nadd)
-        opA.apply(Vs[:, k:k + nadd], AVs[:, k:k + nadd])
-        extend_T(k, nadd)
-        k += nadd
+        for g in deferred + [G - 1]:
+            with torch.cuda.stream(streams[g]):
+                k1_done[g] = groups[g].expand(k1_done[(g - 1) % G] if G > 1 else None)
 
-    if best_slot < 0:     # max_niter == 0 or NaN residuals throughout
+    if groups[0].best_slot < 0:     # max_niter == 0 or NaN residuals throughout
         raise RuntimeError("xitorch_amd davidson: no finite residual was produced")
+    if two:
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            cur.wait_stream(st)
+        evals = torch.cat([grp.best_evals for grp in groups], dim=0)
+        Xall = torch.cat([grp.Xbuf[grp.best_slot] for grp in groups], dim=0)
+        for grp in groups:                      # memory handed to the caller's stream
+            grp.best_evals.record_stream(cur)
+            grp.Xbuf[grp.best_slot].record_stream(cur)
+    else:
+        evals, Xall = groups[0].best_evals, groups[0].Xbuf[groups[0].best_slot]
     if trace is not None:
-        trace.update(niter=niter, napply=opA.napply, resid_history=history, basis_size=k,
-                     best_resid=best_resid, stop_reason=stop_reason)
-    evals = best_evals.reshape(*bdims, p)
-    evecs = Xbuf[best_slot][:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
+        trace.update(niter=niter, napply=sum(op.napply for op in ops) // G, resid_history=history,
+                     basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G)
+    evals = evals.reshape(*bdims, p)
+    evecs = Xall[:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
     return evals, evecs
 
 
