@@ -51,7 +51,6 @@ def c3(B=256, N=65536, hb=63):
 def c4(B=64, N=4096):
     A = syn.root_matrix(B, N, device=dev) * 2.0
     y0 = torch.zeros(B, N, dtype=torch.float64, device=dev)
-    dm = xa.linop.dense_apply
 
     def fcn(y, A_):
         return torch.tanh(xa.LinearOperator.m(A_, is_hermitian=False).mv(y) + 0.1) + y / 2.0

@@ -78,23 +78,12 @@ def _declare(L):
         sigs["xk_cg_update_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])
         sigs["xk_cg_p_" + sfx] = (I, [P] * 4 + [I, I, Lg, I, D, P])
         sigs["xk_kry_status_" + sfx] = (I, [P] * 4 + [I, I, P])
-    sigs.update(_EXTRA_SIGS)
     for name, (res, args) in sigs.items():
         if not hasattr(L, name):
             continue  # reported by the symbol test, and by check() at call time
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
-
-
-_EXTRA_SIGS = {}
-
-
-def register_signatures(sigs):
-    """Other modules of the package add their entry points here before first load."""
-    _EXTRA_SIGS.update(sigs)
-    if _lib is not None:
-        _declare(_lib)
 
 
 def check(rc, what):

@@ -26,8 +26,6 @@ from xitorch_amd import kernels as _k
 
 __all__ = ["LinearOperator", "MatrixLinearOperator", "BandedLinearOperator"]
 
-_OPTIONAL = ("_mm", "_rmv", "_rmm", "_fullmatrix", "_getparamnames")
-
 
 class LinearOperator(EditableModule):
     """Base class of operators of shape ``(*B, p, q)`` defined by their action.
