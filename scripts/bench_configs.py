@@ -48,7 +48,7 @@ def c3(B=256, N=65536, hb=63):
             "solves_per_s": B / t}
 
 
-def c4(B=64, N=4096):
+def c4(B=64, N=8192):
     A = syn.root_matrix(B, N, device=dev) * 2.0
     y0 = torch.zeros(B, N, dtype=torch.float64, device=dev)
 
@@ -62,7 +62,7 @@ def c4(B=64, N=4096):
     t0 = time.perf_counter()
     g, = torch.autograd.grad(y.sum(), (Ad,))
     torch.cuda.synchronize(); tb = time.perf_counter() - t0
-    return {"config": "c4 rootfinder broyden1 tanh(A y)", "B": B, "N": N, "fwd_ms": tf * 1e3, "bwd_ms": tb * 1e3,
+    return {"config": "c4 rootfinder broyden1 tanh(A y), per-GPU shard of configs[3] (64 x 8192^2)", "B": B, "N": N, "fwd_ms": tf * 1e3, "bwd_ms": tb * 1e3,
             "fnorm": fcn(y, Ad).norm().item(), "grad_finite": bool(torch.isfinite(g).all())}
 
 

@@ -117,3 +117,39 @@ def test_fullsize_config3_bicgstab_properties(dev):
     assert (x - xs).abs().max().item() < 1e-7
     # linearity of the operator at full size
     assert torch.allclose(A.mm(2.5 * xs), 2.5 * rhs, rtol=1e-12, atol=1e-12)
+
+
+def test_no_device_memory_growth(dev):
+    """Counterpart of the reference's test_memleak.py: repeated calls of the functionals must not accumulate
+    device memory (workspaces are cached per stream, everything else is released)."""
+    import gc
+    g = torch.Generator().manual_seed(51)
+    n = 96
+    R = torch.rand(2, n, n, dtype=f64, generator=g)
+    sym = ((R + R.transpose(-2, -1)) * 0.05 + torch.diag(torch.arange(n, dtype=f64))).to(dev)
+    Bm = torch.rand(2, n, 2, dtype=f64, generator=g).to(dev)
+    A = xa.LinearOperator.m(sym, True)
+
+    def fcn(y, a):
+        return torch.tanh(torch.einsum("bij,bj->bi", a, y) * 0.01 + 0.1) + y / 2.0
+
+    def one_round():
+        with torch.no_grad():
+            symeig(A, neig=3, method="davidson", min_eps=1e-8)
+            nk.cg(A, Bm, rtol=1e-9, posdef=True)
+            nk.bicgstab(A, Bm, rtol=1e-9, posdef=True)
+        m = sym.clone().requires_grad_()
+        from xitorch_amd.optimize import rootfinder
+        y = rootfinder(fcn, torch.zeros(2, n, dtype=f64, device=dev), params=(m,), alpha=-1.0, f_tol=1e-9)
+        y.sum().backward()
+    for _ in range(2):
+        one_round()            # warm the caches (workspaces, cuBLAS-like handles)
+    gc.collect()
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    for _ in range(5):
+        one_round()
+    gc.collect()
+    torch.cuda.synchronize()
+    after = torch.cuda.memory_allocated()
+    assert after - before <= 1 << 20, (before, after)

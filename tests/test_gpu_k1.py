@@ -147,3 +147,29 @@ def test_dense_wide_mfma_vs_oracle(dev, B, M, N, P, dtype):
     if P <= 32:
         Yw = K.dense_wide(A.to(dev), X.to(dev)).cpu().double()
         assert torch.equal(Yw, Y)
+
+
+def test_exact_symmetry_detection_large_batched(dev):
+    # LinearOperator.m on a big batched matrix takes the member-by-member scan; it must tell exact symmetry
+    # (-> upper-triangle kernel) from allclose-only symmetry (-> full-matrix kernel) and from non-symmetry
+    from xitorch_amd import synthetic
+    mat = synthetic.dense_symmetric(5, 2048, "S2", device=dev)              # 21M elements > 2^24
+    A = LinearOperator.m(mat)
+    assert A.is_hermitian and A.symmetric_storage
+    m2 = mat.clone()
+    m2[3, 5, 9] += 1e-13                                                     # allclose, not bit-exact
+    A2 = LinearOperator.m(m2, is_hermitian=True)
+    assert A2.is_hermitian and not A2.symmetric_storage
+    m3 = mat.clone()
+    m3[4, 7, 11] += 1.0
+    assert not LinearOperator.m(m3).is_hermitian
+    with pytest.raises(RuntimeError, match="indicated to be hermitian"):
+        LinearOperator.m(m3, is_hermitian=True)
+    # both kernels give the same product on the exactly symmetric operator
+    x = torch.randn(5, 2048, 3, dtype=torch.float64, device=dev)
+    from xitorch_amd.linalg._panel import PanelOperator, to_panel
+    Xp = to_panel(x, [5], 5, 2048)
+    y1 = PanelOperator(A, [5], 5, 2048).apply(Xp, torch.zeros_like(Xp))
+    y2 = PanelOperator(A2, [5], 5, 2048).apply(Xp, torch.zeros_like(Xp))
+    assert PanelOperator(A, [5], 5, 2048).symm and not PanelOperator(A2, [5], 5, 2048).symm
+    assert torch.allclose(y1, y2, rtol=1e-12, atol=1e-9)

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(
   T* S = reinterpret_cast<T*>(smem);                 // k2 x ld
   T* cs = S + (long)k2 * ld;                          // 2*m
   T* red = cs + 2 * m;                                // 16
-  int* sel = reinterpret_cast<int*>(red + 16);        // p selected indices (ascending eigenvalue)
+  T* rowabs = red + 16;                               // k2: sum_{l != j} |S_jl|
+  T* rowsq = rowabs + k2;                             // k2: sum_{l != j} S_jl^2
+  int* sel = reinterpret_cast<int*>(rowsq + k2);      // p selected indices (ascending eigenvalue)
+  int* flag = sel + 32;                               // k2 wanted flags + 1 decision slot
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int nt = blockDim.x;
@@ -86,6 +89,15 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(
   nrm = block_sum_1024(nrm, red);
   const T tol2 = (Eps<T>::v * k) * (Eps<T>::v * k) * nrm;
 
+  // the 2x2 blocks (I, J) a thread updates are the same in every step: decode them once
+  constexpr int MAXBLK = 4;                      // m*m <= 64*64 = 4096 blocks over 1024 threads
+  int blkI[MAXBLK], blkJ[MAXBLK];
+#pragma unroll
+  for (int u = 0; u < MAXBLK; ++u) {
+    const int idx = tid + u * nt;
+    if (idx < m * m) { blkI[u] = idx / m; blkJ[u] = idx - blkI[u] * m; }
+    else { blkI[u] = -1; blkJ[u] = 0; }
+  }
   int sweep = 0;
   for (; sweep < max_sweeps; ++sweep) {
     // convergence test on the off-diagonal mass
@@ -96,6 +108,48 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(
     }
     off = block_sum_1024(off, red);
     if (!(off > tol2)) break;
+    // ---- early exit: only the p wanted eigenpairs have to be resolved ------------------------------
+    // If the rows of the p extreme diagonal entries are decoupled from everything else (their
+    // off-diagonal mass is at round-off level) they ARE eigenpairs, whatever mixing is left inside the
+    // unwanted block — provided no eigenvalue of that block can still cross into the wanted range, which
+    // the Gershgorin row bounds of the unwanted rows certify.  Clustered bulks otherwise cost Jacobi many
+    // extra sweeps that the eigensolver never looks at.
+    if (sweep > 0) {
+      if (tid < k) {
+        const T di = S[tid * ld + tid];
+        int rank = 0;
+        T ra = T(0), rq = T(0);
+        for (int j = 0; j < k; ++j) {
+          const T v = S[tid * ld + j];
+          const T dj = S[j * ld + j];
+          rank += (dj < di || (dj == di && j < tid)) ? 1 : 0;
+          if (j != tid) { ra += fabs(v); rq += v * v; }
+        }
+        rowabs[tid] = ra;
+        rowsq[tid] = rq;
+        flag[tid] = uppest ? (rank >= k - p) : (rank < p);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        T offsel = T(0), edge_w = uppest ? T(INFINITY) : T(-INFINITY), edge_u = uppest ? T(-INFINITY) : T(INFINITY);
+        for (int j = 0; j < k; ++j) {
+          const T dj = S[j * ld + j];
+          if (flag[j]) {
+            offsel += rowsq[j];
+            edge_w = uppest ? (dj < edge_w ? dj : edge_w) : (dj > edge_w ? dj : edge_w);
+          } else {
+            const T g = uppest ? dj + rowabs[j] : dj - rowabs[j];      // Gershgorin bound of an unwanted row
+            edge_u = uppest ? (g > edge_u ? g : edge_u) : (g < edge_u ? g : edge_u);
+          }
+        }
+        const bool separated = (p == k) || (uppest ? (edge_u < edge_w) : (edge_u > edge_w));
+        flag[k2] = (!(offsel > tol2) && separated) ? 1 : 0;
+      }
+      __syncthreads();
+      const int done = flag[k2];
+      __syncthreads();
+      if (done) break;
+    }
     for (int r = 0; r < k2 - 1; ++r) {
       if (tid < m) {
         int pp, qq;
@@ -117,21 +171,24 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(
         lg[1] = s;
       }
       __syncthreads();
-      for (int idx = tid; idx < m * m; idx += nt) {
-        const int I = idx / m, J = idx - I * m;
-        int p1, q1, p2, q2;
-        rr_pair(I, r, k2, p1, q1);
-        rr_pair(J, r, k2, p2, q2);
-        const T c1 = cs[2 * I], s1 = cs[2 * I + 1], c2 = cs[2 * J], s2 = cs[2 * J + 1];
-        const T a = S[p1 * ld + p2], bb = S[p1 * ld + q2], cc = S[q1 * ld + p2], d = S[q1 * ld + q2];
-        // rows: G1^T * [[a,bb],[cc,d]]
-        const T r1a = c1 * a - s1 * cc, r1b = c1 * bb - s1 * d;
-        const T r2a = s1 * a + c1 * cc, r2b = s1 * bb + c1 * d;
-        // cols: * G2
-        T na = r1a * c2 - r1b * s2, nb = r1a * s2 + r1b * c2;
-        T nc = r2a * c2 - r2b * s2, nd = r2a * s2 + r2b * c2;
-        if (I == J && (c1 != T(1))) { nb = T(0); nc = T(0); }   // the annihilated pair, exactly
-        S[p1 * ld + p2] = na; S[p1 * ld + q2] = nb; S[q1 * ld + p2] = nc; S[q1 * ld + q2] = nd;
+#pragma unroll
+      for (int u = 0; u < MAXBLK; ++u) {
+        if (blkI[u] >= 0) {
+          const int I = blkI[u], J = blkJ[u];
+          int p1, q1, p2, q2;
+          rr_pair(I, r, k2, p1, q1);
+          rr_pair(J, r, k2, p2, q2);
+          const T c1 = cs[2 * I], s1 = cs[2 * I + 1], c2 = cs[2 * J], s2 = cs[2 * J + 1];
+          const T a = S[p1 * ld + p2], bb = S[p1 * ld + q2], cc = S[q1 * ld + p2], d = S[q1 * ld + q2];
+          // rows: G1^T * [[a,bb],[cc,d]]
+          const T r1a = c1 * a - s1 * cc, r1b = c1 * bb - s1 * d;
+          const T r2a = s1 * a + c1 * cc, r2b = s1 * bb + c1 * d;
+          // cols: * G2
+          T na = r1a * c2 - r1b * s2, nb = r1a * s2 + r1b * c2;
+          T nc = r2a * c2 - r2b * s2, nd = r2a * s2 + r2b * c2;
+          if (I == J && (c1 != T(1))) { nb = T(0); nc = T(0); }   // the annihilated pair, exactly
+          S[p1 * ld + p2] = na; S[p1 * ld + q2] = nb; S[q1 * ld + p2] = nc; S[q1 * ld + q2] = nd;
+        }
       }
       __syncthreads();
     }
@@ -220,7 +277,7 @@ long xk_small_eigh_workspace_elems(int B, int k, int max_sweeps) {
     const long k2 = (k + 1) & ~1;                                                                      \
     const long per = (long)max_sweeps * (k2 - 1) * (k2 / 2) * 2;                                       \
     if (ws_elems < per * B) return XK_ERR_ARG;                                                         \
-    const size_t lds = (size_t)(k2 * (k2 + 1) + k2 + 16) * sizeof(T) + 64 * sizeof(int);               \
+    const size_t lds = (size_t)(k2 * (k2 + 1) + 3 * k2 + 16) * sizeof(T) + (size_t)(k2 + 40) * sizeof(int);    \
     hipError_t e = hipFuncSetAttribute((const void*)xk::jacobi_eigh_kernel<T>,                         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
     if (e != hipSuccess) return (int)e;                                                                \

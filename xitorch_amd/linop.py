@@ -378,6 +378,20 @@ def _native_dtype(t):
     return t.is_cuda and t.dtype in (torch.float64, torch.float32)
 
 
+def _grad_wanted(t):
+    """Inside a custom backward: will the running autograd call actually consume a gradient for `t`?
+
+    `ctx.needs_input_grad` is fixed at forward time.  During the implicit backward solves the Jacobian operator
+    is applied many times with `autograd.grad(..., inputs=(y,))` only, and materialising the B*N^2 outer
+    product for the operator matrix on every one of those applies would dominate the solve.  The engine knows
+    which nodes it will execute; anything uncertain counts as wanted."""
+    try:
+        node = torch.autograd.graph.get_gradient_edge(t).node
+        return bool(torch._C._will_engine_execute_node(node))
+    except Exception:
+        return True
+
+
 def _sum_to_shape(t, shape):
     """Reduce a broadcast gradient back to ``shape``."""
     shape = tuple(shape)
@@ -440,10 +454,10 @@ class _DenseMM(torch.autograd.Function):
     def backward(ctx, gy):
         mat, x = ctx.saved_tensors
         gmat = gx = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _grad_wanted(x):
             gx = _sum_to_shape(_DenseMM.apply(mat, gy, not ctx.trans), x.shape)
-        if ctx.needs_input_grad[0]:
-            # the B*N^2 outer product is only materialised when the operator itself needs a gradient
+        if ctx.needs_input_grad[0] and _grad_wanted(mat):
+            # the B*N^2 outer product is only materialised when this backward call really asks for it
             outer = torch.matmul(x, gy.transpose(-2, -1)) if ctx.trans else torch.matmul(gy, x.transpose(-2, -1))
             gmat = _sum_to_shape(outer, mat.shape)
         return gmat, gx, None
@@ -523,9 +537,9 @@ class _BandedMM(torch.autograd.Function):
     def backward(ctx, gy):
         band, x = ctx.saved_tensors
         gband = gx = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _grad_wanted(x):
             gx = _sum_to_shape(_BandedMM.apply(band, gy, not ctx.trans), x.shape)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and _grad_wanted(band):
             # d/dband[d,i] = sum_c gy[i,c] x[i+off,c]  (trans: gy[i+off,c] x[i,c]) — one strided product per diagonal
             nd, n = band.shape[-2:]
             hb = nd // 2
