@@ -157,12 +157,18 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(
         const T apq = S[pp * ld + qq];
         const T app = S[pp * ld + pp], aqq = S[qq * ld + qq];
         T c = T(1), s = T(0);
-        const T thresh = Eps<T>::v * T(0.01) * sqrt(fabs(app * aqq)) ;
-        if (fabs(apq) > thresh && apq != T(0)) {
-          const T tau = (aqq - app) / (T(2) * apq);
-          const T t = (tau >= T(0) ? T(1) : T(-1)) / (fabs(tau) + sqrt(T(1) + tau * tau));
-          c = T(1) / sqrt(T(1) + t * t);
-          s = t * c;
+        // skip rotations that cannot change anything:  |apq| <= 0.01 eps sqrt(|app aqq|)   (compared squared)
+        const T thr2 = (Eps<T>::v * T(0.01)) * (Eps<T>::v * T(0.01)) * fabs(app * aqq);
+        if (apq * apq > thr2 && apq != T(0)) {
+          // the annihilating rotation without divisions: with d = aqq - app, e = 2 apq, h = hypot(d, e),
+          // w = |d| + h:  tan = sign(d) e / w,  cos = sqrt(w / 2h) = w r,  sin = sign(d) e r,  r = rsqrt(2 h w)
+          // (the dependent sqrt/div chain of the textbook formula is what a Jacobi step waits on)
+          const T d = aqq - app, e = T(2) * apq;
+          const T h = sqrt(d * d + e * e);
+          const T w = fabs(d) + h;
+          const T r = rsqrt(T(2) * h * w);
+          c = w * r;
+          s = (d >= T(0) ? e : -e) * r;
         }
         cs[2 * tid] = c;
         cs[2 * tid + 1] = s;
@@ -281,7 +287,11 @@ long xk_small_eigh_workspace_elems(int B, int k, int max_sweeps) {
     hipError_t e = hipFuncSetAttribute((const void*)xk::jacobi_eigh_kernel<T>,                         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
     if (e != hipSuccess) return (int)e;                                                                \
-    hipLaunchKernelGGL((xk::jacobi_eigh_kernel<T>), dim3(B), dim3(1024), lds, (hipStream_t)stream,     \
+    /* one thread per 2x2 block while that fits: fewer waves per barrier for small bases */            \
+    const long nblk = (k2 / 2) * (k2 / 2);                                                             \
+    int nthr = (int)((nblk + 255) / 256 * 256);                                                        \
+    nthr = nthr > 1024 ? 1024 : (nthr < 256 ? 256 : nthr);                                             \
+    hipLaunchKernelGGL((xk::jacobi_eigh_kernel<T>), dim3(B), dim3(nthr), lds, (hipStream_t)stream,     \
                        Tin, lam, Y, ws, sweeps, k, p, uppest, max_sweeps, ldt, sT, per);               \
     XK_LAUNCH_CHECK();                                                                                 \
     return XK_OK;                                                                                      \
