@@ -14,19 +14,26 @@
 // Mapping.  Tiles of TRH=1024 rows x 1024 columns (fp64; 2048 columns fp32).  One 256-thread block
 // per tile; the 4 waves own 4 x 256 columns (lane: two 16 B vectors, so each load instruction is a
 // contiguous 1 KB and the cross-lane reduction is amortised over twice the data), and walk down the
-// tile's rows in chunks of 4:
+// tile's rows in chunks of 8 (16 buffer loads = 16 KB in flight per wave; descriptor + one loop-invariant
+// lane offset + scalar row offset, no 64-bit vector address arithmetic):
 //   * column part: per-lane register accumulators acc_col[P][VN] over the whole tile (panel
 //     values x_I are wave-uniform scalar loads);
 //   * row part: per-lane products a[r]*x_J (x_J held in registers for the tile), folded across
-//     the 64 lanes by the transposing wave reduction, then added into an LDS accumulator
-//     rowacc[1024][P] (ds_add_f64; 48 KB for P=6);
+//     the 64 lanes by an eager transposing tree (half-exchange swaps first), then added into an LDS
+//     accumulator rowacc[1024][P] (ds_add_f64; 48 KB for P=6);
 //   * tile results go to partial buffers  rowP[J][c][i]  /  colP[I][c][j]  (one slot per column slab /
 //     row tile) and a fold kernel adds, for every output element, exactly the slots that exist:
 //        y[c][n] = sum_{J >= 2*(n>>10)} rowP[J][c][n] + sum_{I <= n>>10} colP[I][c][n].
-//   Tiles crossing the diagonal mask the strictly-lower elements (and count the diagonal once).
+//   Tiles crossing the diagonal mask the strictly-lower elements (and count the diagonal once); each of
+//   their waves stops at its own last column.  Lanes past the last column of a ragged matrix read through
+//   an out-of-range offset (hardware returns zeros).
 //
-// Traffic per launch: B*N^2*s/2 (+6 % for the crossing tiles) + 2 * B*(NS+NT)*P*N*s of partials
-// (7 %) — vs B*N^2*s for the general kernel.
+// Register budget (fp64, P=6): 203 VGPRs -> 2 waves per SIMD; the panel/accumulator registers (96) cannot be
+// shared between waves, so the third wave (<=168 VGPRs) is out of reach and the chunk depth is what keeps
+// enough bytes in flight.
+//
+// Traffic per launch: B*N^2*s/2 (+2 % for the crossing tiles) + 2 * B*(NS+NT)*P*N*s of partials
+// (2.5 %) — vs B*N^2*s for the general kernel.
 #include "xk_common.h"
 
 namespace xk {
@@ -34,110 +41,203 @@ namespace xk {
 constexpr int SYMM_TRH = 1024;   // rows per tile
 
 constexpr int SYMM_NU = 2;      // 16 B vectors per lane per row: a wave spans 2 x 64 x VN columns
-constexpr int SYMM_R = 4;       // rows per chunk (8 loads = 8 KB in flight per wave)
 
-// one chunk = SYMM_R rows x (SYMM_NU*64*VN) columns per wave
+// The operator tile is read through a buffer descriptor (base = first row of the tile, wave-uniform):
+// every load is  descriptor + per-lane column offset (one VGPR, loop-invariant) + scalar row offset,
+// so the streaming loop carries no 64-bit VGPR address arithmetic.  aux = 2: non-temporal.
+typedef __amdgpu_buffer_rsrc_t TileRsrc;
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+template <typename VT>
+__device__ __forceinline__ VT ld_tile(const TileRsrc rsrc, unsigned lane_off, unsigned row_off) {
+  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)row_off, 2);
+  return __builtin_bit_cast(VT, raw);
+}
+
+template <typename T>
+__device__ __forceinline__ TileRsrc make_tile_rsrc(const T* tile_base, long bytes) {
+  const uint64_t v = reinterpret_cast<uint64_t>(tile_base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  void* base = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xffffffffL ? 0xffffffffL : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)nrec, 0x00020000);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 8-row chunk (16 loads = 16 KB in flight per wave).  At 188+ VGPRs the kernel runs 2 waves per
+// SIMD whatever the chunk size, so the only way to keep more bytes in flight is a deeper chunk; the
+// row sums are folded EAGERLY so that the 48 partial sums never coexist:
+//   rows (2h, 2h+1)  -> half-exchange over lane bit 5      (6 values per row pair)
+//   row pairs        -> half-exchange over lane bit 4      (6 values per 4 rows)
+//   the two 4-groups -> select + xor-8 shuffle             (6 values per 8 rows)
+//   panel columns    -> (even P) select + xor-4 shuffle, then xor-2 / xor-1 butterflies
+// afterwards lane l holds, for row r = 4*bit3 + 2*bit4 + bit5 of the chunk, the complete sums of
+// columns c = 2w + bit2 (w < P/2); lanes with bits 1,0 clear add them into the LDS accumulator.
+// ---------------------------------------------------------------------------------------------
+constexpr int SYMM_R = 8;       // rows per chunk
+
 template <typename T, int P, bool CROSSING, bool TAIL>
-__device__ __forceinline__ void symm_chunk(
-    const T* __restrict__ Ab, const T* __restrict__ Xb, long lda, long ldx, int N, int i0, int i_end,
-    const int (&jj)[SYMM_NU], const bool (&colok)[SYMM_NU], int row_tile0,
+__device__ __forceinline__ void symm_chunk8(
+    typename Vec16<T>::type (&a)[SYMM_R][SYMM_NU], const TileRsrc Ab, const T* __restrict__ Xb, unsigned lda,
+    long ldx, int N, int i0, int i_end,
+    const int (&jj)[SYMM_NU], const unsigned (&joff)[SYMM_NU], int row_tile0,
     typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
     T* rowacc, int lane) {
   typedef typename Vec16<T>::type VT;
   constexpr int VN = Vec16<T>::n;
   constexpr int R = SYMM_R, NU = SYMM_NU;
-  VT a[R][NU];
+  const int i_last = i_end - 1;
+  T L2[2][P];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int row = i0 + r;
-    if (TAIL) row = row < N ? row : N - 1;          // clamped duplicate rows are masked below
+  for (int g = 0; g < 2; ++g) {
+    T L1[2][P];
+    // the panel values of a row group are fetched when the group starts (not all 8 rows up front: 96 SGPRs)
+    if (g > 0) asm volatile("" ::: "memory");
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (colok[u]) {
-        a[r][u] = ld_stream(reinterpret_cast<const VT*>(Ab + (long)row * lda + jj[u]));
-      } else {                                       // lanes past the last column still join the reduction
+    for (int h = 0; h < 2; ++h) {
+      T xi[P][2];
 #pragma unroll
-        for (int v = 0; v < VN; ++v) a[r][u][v] = T(0);
-      }
-    }
-  }
-  T prow[R * P];
+      for (int c = 0; c < P; ++c)
 #pragma unroll
-  for (int h = 0; h < R / 2; ++h) {
-    // panel values of 2 rows: wave-uniform scalar loads, a small batch at a time (SGPR budget)
-    T xi[P][2];
-#pragma unroll
-    for (int c = 0; c < P; ++c)
+        for (int q = 0; q < 2; ++q) {
+          int row = i0 + 4 * g + 2 * h + q;
+          if (TAIL) row = row < i_last ? row : i_last;
+          xi[c][q] = Xb[(long)c * ldx + row];
+        }
+      T s[2][P];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        int row = i0 + 2 * h + q;
-        if (TAIL) row = row < N ? row : N - 1;
-        xi[c][q] = Xb[(long)c * ldx + row];
+        const int r = 4 * g + 2 * h + q;
+        const int row = i0 + r;
+#pragma unroll
+        for (int c = 0; c < P; ++c) s[q][c] = T(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          VT ar = a[r][u], ac = a[r][u];
+          if (CROSSING) {
+#pragma unroll
+            for (int v = 0; v < VN; ++v) {
+              if (jj[u] + v < row) { ar[v] = T(0); ac[v] = T(0); }
+              if (jj[u] + v == row) ac[v] = T(0);
+            }
+          }
+          if (TAIL) {
+            if (row >= i_end) {
+#pragma unroll
+              for (int v = 0; v < VN; ++v) { ar[v] = T(0); ac[v] = T(0); }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < P; ++c)
+#pragma unroll
+            for (int v = 0; v < VN; ++v) {
+              acc_col[u][c][v] += ac[v] * xi[c][q];
+              s[q][c] += ar[v] * xJ[u][c][v];
+            }
+        }
       }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int r = 2 * h + q;
-      const int row = i0 + r;
-      T s[P];
+      for (int c = 0; c < P; ++c) L1[h][c] = swap_add32(s[0][c], s[1][c]);
+      // the column sums of this row pair must be complete here: without the pin the optimiser sinks all
+      // of them below the reduction, which keeps the whole 8-row chunk of matrix data live until then
 #pragma unroll
-      for (int c = 0; c < P; ++c) s[c] = T(0);
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        VT ar = a[r][u], ac = a[r][u];
-        if (CROSSING) {
+        for (int c = 0; c < P; ++c) asm volatile("" : "+v"(acc_col[u][c]));
+      // rolling prefetch: the two rows just consumed are refilled with the rows 8 further down, so the wave
+      // always has ~6 row pairs of loads in flight while it computes (rows past the end re-read the last one)
+      if (!TAIL) {
 #pragma unroll
-          for (int v = 0; v < VN; ++v) {
-            if (jj[u] + v < row) { ar[v] = T(0); ac[v] = T(0); }   // strictly lower: the mirror tile's job
-            if (jj[u] + v == row) ac[v] = T(0);                    // diagonal: counted once (row part)
-          }
+        for (int q = 0; q < 2; ++q) {
+          int row = i0 + R + 4 * g + 2 * h + q;
+          row = row < i_last ? row : i_last;
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
         }
-        if (TAIL) {
-          if (row >= i_end) {
-#pragma unroll
-            for (int v = 0; v < VN; ++v) { ar[v] = T(0); ac[v] = T(0); }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < P; ++c)
-#pragma unroll
-          for (int v = 0; v < VN; ++v) {
-            acc_col[u][c][v] += ac[v] * xi[c][q];
-            s[c] += ar[v] * xJ[u][c][v];
-          }
       }
+      __builtin_amdgcn_sched_barrier(0);      // keep the row pairs in program order (bounded live ranges)
+    }
 #pragma unroll
-      for (int c = 0; c < P; ++c) prow[r * P + c] = s[c];
+    for (int c = 0; c < P; ++c) L2[g][c] = swap_add16(L1[0][c], L1[1][c]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  T L3[P];
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const T keep = hi ? L2[1][c] : L2[0][c];
+      const T send = hi ? L2[0][c] : L2[1][c];
+      L3[c] = keep + shfl_xor_t(send, 8);
     }
   }
-  // fold the 64 lanes (half-exchange swaps), then the owning lanes add into the LDS row accumulator
-  wave_reduce_scatter<T, R * P>(prow, lane);
-  if (wave_rs_is_writer<R * P>(lane)) {
+  const int r = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+  const int lrow = i0 + r - row_tile0;
+  const bool rowok = !TAIL || (i0 + r < i_end);
+  if (P % 2 == 0) {
+    constexpr int PH = P / 2 > 0 ? P / 2 : 1;
+    T L4[PH];
+    const bool hi = (lane & 4) != 0;
 #pragma unroll
-    for (int w = 0; w < WaveRsCount<R * P>::value; ++w) {
-      const int idx = wave_rs_orig_index<R * P>(w, lane);      // = r*P + c
-      const int r = idx / P, c = idx - r * P;
-      const int lrow = i0 + r - row_tile0;
-      if (!TAIL || i0 + r < i_end)
-        __hip_atomic_fetch_add(&rowacc[lrow * P + c], prow[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int w = 0; w < P / 2; ++w) {
+      const T keep = hi ? L3[2 * w + 1] : L3[2 * w];
+      const T send = hi ? L3[2 * w] : L3[2 * w + 1];
+      L4[w] = keep + shfl_xor_t(send, 4);
+    }
+#pragma unroll
+    for (int w = 0; w < P / 2; ++w) {
+      L4[w] += shfl_xor_t(L4[w], 2);
+      L4[w] += shfl_xor_t(L4[w], 1);
+    }
+    if ((lane & 3) == 0 && rowok) {
+#pragma unroll
+      for (int w = 0; w < P / 2; ++w)
+        __hip_atomic_fetch_add(&rowacc[lrow * P + 2 * w + (hi ? 1 : 0)], L4[w], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      L3[c] += shfl_xor_t(L3[c], 4);
+      L3[c] += shfl_xor_t(L3[c], 2);
+      L3[c] += shfl_xor_t(L3[c], 1);
+    }
+    if ((lane & 7) == 0 && rowok) {
+#pragma unroll
+      for (int c = 0; c < P; ++c)
+        __hip_atomic_fetch_add(&rowacc[lrow * P + c], L3[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 }
 
 template <typename T, int P, bool CROSSING>
 __device__ __forceinline__ void symm_tile_rows(
-    const T* __restrict__ Ab, const T* __restrict__ Xb, long lda, long ldx, int N, int i_begin, int i_end,
-    const int (&jj)[SYMM_NU], const bool (&colok)[SYMM_NU], int row_tile0,
+    const TileRsrc Ab, const T* __restrict__ Xb, unsigned lda, long ldx, int N, int i_begin, int i_end,
+    const int (&jj)[SYMM_NU], const unsigned (&joff)[SYMM_NU], int row_tile0,
     typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
     T* rowacc, int lane) {
+  typedef typename Vec16<T>::type VT;
+  if (i_begin >= i_end) return;
   const int full_end = i_begin + ((i_end - i_begin) / SYMM_R) * SYMM_R;
+  const int i_last = i_end - 1;
+  VT a[SYMM_R][SYMM_NU];                     // ring of 8 rows, refilled pair by pair inside the chunks
+#pragma unroll
+  for (int r = 0; r < SYMM_R; ++r) {
+    int row = i_begin + r;
+    row = row < i_last ? row : i_last;
+#pragma unroll
+    for (int u = 0; u < SYMM_NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
+  }
   for (int i0 = i_begin; i0 < full_end; i0 += SYMM_R)
-    symm_chunk<T, P, CROSSING, false>(Ab, Xb, lda, ldx, N, i0, i_end, jj, colok, row_tile0, acc_col, xJ, rowacc, lane);
+    symm_chunk8<T, P, CROSSING, false>(a, Ab, Xb, lda, ldx, N, i0, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
   if (full_end < i_end)
-    symm_chunk<T, P, CROSSING, true>(Ab, Xb, lda, ldx, N, full_end, i_end, jj, colok, row_tile0, acc_col, xJ, rowacc, lane);
+    symm_chunk8<T, P, CROSSING, true>(a, Ab, Xb, lda, ldx, N, full_end, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
 }
 
 template <typename T, int P>
-__global__ __launch_bounds__(256) void dense_symm_tiles(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
     const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int ntiles,
     int N, long lda, long sA, long ldx, long sX, int NS, int NT) {
   typedef typename Vec16<T>::type VT;
@@ -147,12 +247,11 @@ __global__ __launch_bounds__(256) void dense_symm_tiles(
   constexpr int SLAB = 4 * WCOLS;              // columns per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
-  const int b = blockIdx.x / ntiles;
-  const int tix = blockIdx.x - b * ntiles;
   // tile list in row-tile-major order: row tile I owns the column slabs J >= (I*TRH)/SLAB
+  int b = blockIdx.x / ntiles;
   int I = 0, J = 0;
   {
-    int rem = tix;
+    int rem = blockIdx.x - b * ntiles;
     for (;; ++I) {
       const int jmin = (I * SYMM_TRH) / SLAB;
       const int cnt = NS - jmin;
@@ -160,16 +259,25 @@ __global__ __launch_bounds__(256) void dense_symm_tiles(
       rem -= cnt;
     }
   }
+  // the integer divisions above run on the vector ALU: pin their (wave-uniform) results in SGPRs so that
+  // everything derived from them (row pointers, loop bounds, panel addresses) is scalar arithmetic
+  b = __builtin_amdgcn_readfirstlane(b);
+  I = __builtin_amdgcn_readfirstlane(I);
+  J = __builtin_amdgcn_readfirstlane(J);
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar row pointers
   const int row0 = I * SYMM_TRH;
   const int col0 = J * SLAB;
   int jj[NU];
+  unsigned joff[NU];
   bool colok[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     jj[u] = col0 + wave * WCOLS + u * 64 * VN + lane * VN;      // each load instruction: 1 KB contiguous
     colok[u] = jj[u] < N;
+    // lanes past the last column get a byte offset beyond the descriptor's range: the hardware bounds
+    // check returns zeros for them (no branch, no select), so they add nothing to either sum
+    joff[u] = colok[u] ? (unsigned)jj[u] * (unsigned)sizeof(T) : 0x7ffffff0u;
   }
   const T* Ab = A + (long)b * sA;
   const T* Xb = X + (long)b * sX;
@@ -182,6 +290,9 @@ __global__ __launch_bounds__(256) void dense_symm_tiles(
   if (i_end > col_last + 1) i_end = col_last + 1;
   if (i_end > N) i_end = N;
   const bool crossing = (i_end - 1 >= col0);   // some row index reaches the first column: mask needed
+  const int tile_rows = (row0 + SYMM_TRH <= N ? SYMM_TRH : N - row0);
+  const unsigned ldab = (unsigned)(lda * (long)sizeof(T));
+  const TileRsrc tile = make_tile_rsrc(Ab + (long)row0 * lda, (long)tile_rows * lda * (long)sizeof(T));
   VT acc_col[NU][P], xJ[NU][P];
 #pragma unroll
   for (int u = 0; u < NU; ++u)
@@ -200,10 +311,10 @@ __global__ __launch_bounds__(256) void dense_symm_tiles(
     // rows below this WAVE's last column hold only strictly-lower elements for it: stop there
     int w_end = col0 + (wave + 1) * WCOLS;
     w_end = w_end < i_end ? w_end : i_end;
-    symm_tile_rows<T, P, true>(Ab, Xb, lda, ldx, N, row0, w_end, jj, colok, row0, acc_col, xJ, rowacc, lane);
+    symm_tile_rows<T, P, true>(tile, Xb, ldab, ldx, N, row0, w_end, jj, joff, row0, acc_col, xJ, rowacc, lane);
   }
   else
-    symm_tile_rows<T, P, false>(Ab, Xb, lda, ldx, N, row0, i_end, jj, colok, row0, acc_col, xJ, rowacc, lane);
+    symm_tile_rows<T, P, false>(tile, Xb, ldab, ldx, N, row0, i_end, jj, joff, row0, acc_col, xJ, rowacc, lane);
   __syncthreads();
   // flush: row partial slot J (rows of this tile), column partial slot I (columns of this slab)
   T* rp = rowP + (((long)b * NS + J) * P) * (long)N;
