@@ -112,6 +112,15 @@ int xk_panel_chol_f32(const float* G, float* W, int* info, int B, int P, long ld
 int xk_panel_transform_f64(double* Tp, const double* W, int B, int P, int N, long ldt, long sT, void* stream);
 int xk_panel_transform_f32(float* Tp, const float* W, int B, int P, int N, long ldt, long sT, void* stream);
 
+/* ---- Davidson diagonal preconditioner (extension; the reference's davidson has none, `t = -resid`,
+ * xitorch/_impls/linalg/symeig.py:206-207) ------------------------------------------------------
+ * t[b,c,n] /= (d[b,n] - lam[b,c]*m[b,n]) with |denominator| >= floor (sign kept); m == NULL: identity.
+ * t: (B,P,ld) panel, d/m: (B,N) with batch strides sD/sM (0 broadcasts), lam: (B,>=P) unit stride. */
+int xk_diag_precond_f64(double* t, const double* d, const double* m, const double* lam, int B, int N, int P,
+                        long ldt, long sT, long sD, long sM, long sLam, double floor_, void* stream);
+int xk_diag_precond_f32(float* t, const float* d, const float* m, const float* lam, int B, int N, int P,
+                        long ldt, long sT, long sD, long sM, long sLam, double floor_, void* stream);
+
 /* ---- K3: batched small symmetric eigensolver (LDS-resident parallel Jacobi) -----------------
  * Lowest (uppest=0) / uppermost (uppest=1) p eigenpairs of B symmetric k x k matrices (lower
  * triangle read, pitch ldt, batch pitch sT), eigenvalues ascending: lam (B,p), Y (B,p,k) with

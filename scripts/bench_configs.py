@@ -55,21 +55,24 @@ def c4(B=64, N=8192):
     def fcn(y, A_):
         return torch.tanh(xa.LinearOperator.m(A_, is_hermitian=False).mv(y) + 0.1) + y / 2.0
     Ad = A.clone().requires_grad_()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    y = rootfinder(fcn, y0, params=(Ad,), method="broyden1", alpha=-1.0, max_rank=32, f_tol=1e-8,
-                   bck_options=dict(method="bicgstab", posdef=True, rtol=1e-10))
-    torch.cuda.synchronize(); tf = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    g, = torch.autograd.grad(y.sum(), (Ad,))
-    torch.cuda.synchronize(); tb = time.perf_counter() - t0
+    for rep in range(2):                       # the second pass is the timed one (allocator / code caches warm)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y = rootfinder(fcn, y0, params=(Ad,), method="broyden1", alpha=-1.0, max_rank=32, f_tol=1e-8,
+                       bck_options=dict(method="bicgstab", posdef=True, rtol=1e-10))
+        torch.cuda.synchronize(); tf = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        g, = torch.autograd.grad(y.sum(), (Ad,))
+        torch.cuda.synchronize(); tb = time.perf_counter() - t0
+        print(json.dumps({"c4_rep": rep, "fwd_ms": tf * 1e3, "bwd_ms": tb * 1e3}), flush=True)
+        del g
     return {"config": "c4 rootfinder broyden1 tanh(A y), per-GPU shard of configs[3] (64 x 8192^2)", "B": B, "N": N, "fwd_ms": tf * 1e3, "bwd_ms": tb * 1e3,
-            "fnorm": fcn(y, Ad).norm().item(), "grad_finite": bool(torch.isfinite(g).all())}
+            "fnorm": fcn(y, Ad).norm().item()}
 
 
 def c5(B=16, N=32768, p=6):
     mat = torch.empty((B, N, N), dtype=torch.float32, device=dev)
     syn.dense_symmetric(B, N, "S1", dtype=torch.float32, device=dev, out=mat)
-    A = xa.MatrixLinearOperator(mat, True)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)        # the symmetry scan finds exactly symmetric storage -> K1s
     ev = []
     for i in range(2):
         tr = {"k1_events": ev if i == 1 else None}
@@ -82,6 +85,7 @@ def c5(B=16, N=32768, p=6):
     k1b = B * N * N * 4 + 2 * B * N * p * 4
     exact = syn.spectrum("S1", N, device=dev)[:p]
     return {"config": "c5 symeig fp32 per-GPU shard (16 x 32768^2)", "B": B, "N": N, "ms": t * 1e3, "niter": tr["niter"],
+            "panel_kernel": "K1s (upper triangle)" if getattr(A, "symmetric_storage", False) else "K1 general",
             "eigpairs_per_s": B * p / t, "k1_ms": sum(ms) / len(ms), "k1_GBps": k1b / (sum(ms) / len(ms)) / 1e6,
             "max_eval_err": (evals.double() - exact).abs().max().item()}
 

@@ -58,6 +58,7 @@ def _declare(L):
         sigs["xk_ritz_residual_" + sfx] = (I, [P, P, P, P, P, P, P, I, I, I, I] + [Lg] * 12 + [P])
         sigs["xk_panel_chol_" + sfx] = (I, [P, P, P, I, I, Lg, Lg, P])
         sigs["xk_panel_transform_" + sfx] = (I, [P, P, I, I, I, Lg, Lg, P])
+        sigs["xk_diag_precond_" + sfx] = (I, [P, P, P, P, I, I, I, Lg, Lg, Lg, Lg, Lg, D, P])
         sigs["xk_small_eigh_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, I, Lg, Lg, P])
     sigs["xk_small_eigh_workspace_elems"] = (Lg, [I, I, I])
     sigs["xk_kry_max_partials"] = (I, [])

@@ -293,6 +293,29 @@ static int ritz_residual(const T* V, const T* AV, const T* Y, const T* lam, T* X
   return XK_OK;
 }
 
+
+// Davidson's diagonal correction of the new search directions (the reference has none, symeig.py:206-207):
+//   t[b,c,n] <- t[b,c,n] / (d[b,n] - lam[b,c] * m[b,n]),   |denominator| kept >= floor (sign preserved)
+// d = diag(A), m = diag(M) (nullptr: identity).  One thread per element, coalesced along n.
+template <typename T>
+__global__ __launch_bounds__(256) void diag_precond_kernel(T* __restrict__ Tn, const T* __restrict__ d,
+                                                            const T* __restrict__ m, const T* __restrict__ lam,
+                                                            int N, int P, long ldt, long sT, long sD, long sM,
+                                                            long sLam, T floor_, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long per_b = (long)P * N;
+  const long b = idx / per_b;
+  const long rem = idx - b * per_b;
+  const int c = (int)(rem / N);
+  const int n = (int)(rem - (long)c * N);
+  const T mm = m ? m[b * sM + n] : T(1);
+  T den = d[b * sD + n] - lam[b * sLam + c] * mm;
+  if (fabs(den) < floor_) den = den < T(0) ? -floor_ : floor_;
+  T* t = Tn + b * sT + (long)c * ldt + n;
+  *t = *t / den;
+}
+
 }  // namespace xk
 
 extern "C" {
@@ -338,5 +361,19 @@ extern "C" {
 
 XK_DEFINE_BASIS(f64, double)
 XK_DEFINE_BASIS(f32, float)
+
+#define XK_DEFINE_PRECOND(SUF, T)                                                                          \
+  int xk_diag_precond_##SUF(T* Tn, const T* d, const T* m, const T* lam, int B, int N, int P, long ldt,    \
+                            long sT, long sD, long sM, long sLam, double floor_, void* stream) {           \
+    if (B < 0 || N < 0 || P < 0 || !(floor_ > 0)) return XK_ERR_ARG;                                       \
+    if (B == 0 || N == 0 || P == 0) return XK_OK;                                                          \
+    const long total = (long)B * P * N;                                                                    \
+    hipLaunchKernelGGL((xk::diag_precond_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,  \
+                       (hipStream_t)stream, Tn, d, m, lam, N, P, ldt, sT, sD, sM, sLam, (T)floor_, total); \
+    XK_LAUNCH_CHECK();                                                                                     \
+    return XK_OK;                                                                                          \
+  }
+XK_DEFINE_PRECOND(f64, double)
+XK_DEFINE_PRECOND(f32, float)
 
 }  // extern "C"

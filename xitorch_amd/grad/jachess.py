@@ -104,12 +104,7 @@ class _Jac(LinearOperator):
         else:
             _, _, v, dfdy = self._reevaluate(True)
         rows = gy.reshape(-1, self.nin)
-        outs = []
-        for i in range(rows.shape[0]):
-            o, = torch.autograd.grad(dfdy, (v,), grad_outputs=rows[i].reshape(self.inshape), retain_graph=True,
-                                     create_graph=torch.is_grad_enabled())
-            outs.append(o.unsqueeze(0))
-        res = torch.cat(outs, dim=0).reshape(*gy.shape[:-1], self.nout)
+        res = _batched_grad(dfdy, v, rows, self.inshape).reshape(*gy.shape[:-1], self.nout)
         return _connect(_connect(res, self.params_tensor), self.objparams)
 
     def _rmv(self, gout):
@@ -118,13 +113,29 @@ class _Jac(LinearOperator):
         else:
             yout, yparam, _, _ = self._reevaluate(False)
         rows = gout.reshape(-1, self.nout)
-        outs = []
-        for i in range(rows.shape[0]):
-            o, = torch.autograd.grad(yout, (yparam,), grad_outputs=rows[i].reshape(self.outshape),
-                                     retain_graph=True, create_graph=torch.is_grad_enabled())
-            outs.append(o.unsqueeze(0))
-        res = torch.cat(outs, dim=0).reshape(*gout.shape[:-1], self.nin)
+        res = _batched_grad(yout, yparam, rows, self.outshape).reshape(*gout.shape[:-1], self.nin)
         return _connect(_connect(res, self.params_tensor), self.objparams)
+
+
+def _batched_grad(out, inp, rows, shape):
+    """rows[i] -> d<out, rows[i]>/d inp for every row: ONE vmapped backward pass (``is_grads_batched``)
+    instead of the reference's Python loop over the vectors (jachess.py:163-170,189-196); graphs that
+    cannot be vmapped (or a single row) take the loop."""
+    n = rows.shape[0]
+    create = torch.is_grad_enabled()
+    if n > 1:
+        try:
+            o, = torch.autograd.grad(out, (inp,), grad_outputs=rows.reshape(n, *shape), retain_graph=True,
+                                     create_graph=create, is_grads_batched=True)
+            return o.reshape(n, -1)
+        except RuntimeError:
+            pass
+    outs = []
+    for i in range(n):
+        o, = torch.autograd.grad(out, (inp,), grad_outputs=rows[i].reshape(shape), retain_graph=True,
+                                 create_graph=create)
+        outs.append(o.reshape(1, -1))
+    return torch.cat(outs, dim=0)
 
 
 def _connect(out, params):

@@ -123,6 +123,26 @@ def ritz_residual(V, AV, Y, lam, X, Tn, rmax, k, P):
     check(rc, "xk_ritz_residual")
 
 
+def diag_precond(Tn, d, lam, P, m=None, floor=None):
+    """Davidson's diagonal correction in place: Tn[b,c,:] /= (d[b,:] - lam[b,c] * m[b,:]) with the magnitude of
+    the denominator kept above ``floor`` (extension: the reference's davidson takes t = -resid, symeig.py:206-207).
+    Tn: (B, >=P, ld) panel, d / m: (B or 1, N), lam: (B, >=P)."""
+    B, N = Tn.shape[0], d.shape[-1]
+    if floor is None:
+        floor = float(torch.finfo(Tn.dtype).eps) ** 0.5
+    d2 = d.reshape(-1, N)
+    m2 = m.reshape(-1, N) if m is not None else None
+    for t in (d2, m2):
+        if t is not None and (t.stride(-1) != 1 or t.dtype != Tn.dtype or t.shape[0] not in (1, B)):
+            raise _capi.NativeLibraryError("diag_precond: diagonals must be (B or 1, N), unit stride, dtype of the panel")
+    sD = d2.stride(0) if d2.shape[0] == B and B > 1 else (0 if d2.shape[0] == 1 else d2.stride(0))
+    sM = 0 if m2 is None or m2.shape[0] == 1 else m2.stride(0)
+    rc = fn("xk_diag_precond_" + suffix(Tn.dtype))(ptr(Tn), ptr(d2), ptr(m2) if m2 is not None else None,
+                                                   ptr(lam), B, N, P, Tn.stride(1), Tn.stride(0), sD, sM,
+                                                   lam.stride(0), float(floor), stream_ptr())
+    check(rc, "xk_diag_precond")
+
+
 def panel_chol(G, W, info, P):
     """W[b] = R^-1 with G[b] = R^T R (upper R); info[b] != 0 flags a non-positive pivot.
     G: (B, >=P, >=P) with unit stride along its last dim.  CholeskyQR step of tallqr (tensor.py:16-17)."""

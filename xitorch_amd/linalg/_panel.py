@@ -62,6 +62,17 @@ class PanelOperator:
             self.kind = "banded"
             self.band = A.band.reshape(nA, *A.band.shape[-2:])
 
+    def diagonal(self):
+        """diag(A) as a contiguous (nA, N) array (native operators only)."""
+        if self.kind == "dense":
+            mat = self.mat if self.mat.dim() == 3 else self.mat.unsqueeze(0)
+            return mat.diagonal(dim1=-2, dim2=-1).contiguous()
+        if self.kind == "banded":
+            hb = (self.band.shape[-2] - 1) // 2
+            return self.band[:, hb, :].contiguous()
+        raise K._capi.NativeLibraryError("the diagonal of a generic LinearOperator is not available: pass it "
+                                         "explicitly (precond=<tensor (*batch, N)>) or use a LinearOperator")
+
     def apply(self, X, out, trans=False):
         """out[:, :, :N] = A X  (trans: A^H X).  X, out: (Bt, p, ld)."""
         self.napply += 1

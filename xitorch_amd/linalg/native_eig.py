@@ -82,8 +82,10 @@ def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device="c
 class _Group:
     """State of the Davidson iteration for one contiguous block of the batch, bound to one HIP stream."""
 
-    def __init__(self, opA, opM, B, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes):
+    def __init__(self, opA, opM, B, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
+                 precond=None):
         self.opA, self.opM = opA, opM
+        self.precond = precond                    # None | ("diag", dA, dM) | ("op", PanelOperator)
         self.B, self.N, self.Npad, self.p = B, N, Npad, p
         self.dtype, self.device, self.mode = dtype, device, mode
         self.small_eigh, self.orth_passes = small_eigh, orth_passes
@@ -187,6 +189,14 @@ class _Group:
             # residual A X - lam (M X): rotate M V instead of V, then the eigenvectors separately
             K.ritz_residual(self.MVs, self.AVs, Y, lam, X, self.newpanel, self.rmax, k, p)
             K.lincomb(self.Vs, Y, X, k, p, coef_layout="ac", alpha=1.0, beta=0.0)
+        if self.precond is not None:
+            # (extension) preconditioned correction t = K^-1 (-resid); the residual test above is unaffected
+            if self.precond[0] == "diag":
+                K.diag_precond(self.newpanel, self.precond[1], lam, p, m=self.precond[2])
+            else:
+                tmp = torch.zeros_like(self.newpanel)
+                self.precond[1].apply(self.newpanel, tmp)
+                self.newpanel.copy_(tmp)
         self.lam = lam
         self.status[0] = self.rmax.max()
         self.status[1] = self.info.max()
@@ -217,7 +227,7 @@ def _sub_operator(A, B, N, b0, b1):
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
-             rng_device="cpu", small_eigh="native", overlap="auto", **unused):
+             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -251,6 +261,11 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         operator-panel product of the other (the panel products themselves stay back to back); iteration
         counts and the stopping rule are unchanged.  ``"auto"`` (default) / ``False``: one group on the current
         stream — at the benchmark size the two schedules measure the same
+    precond: None, str, tensor or LinearOperator
+        (extension; the reference has no preconditioner, symeig.py:206-207) ``None`` (default): new directions
+        are the negated residuals, exactly like the reference.  ``"diag"``: Davidson's diagonal correction
+        ``t = -r / (diag(A) - lam diag(M))`` with the operator's own diagonal (native dense / banded
+        operators); a tensor ``(*batch, na)``: the same with that diagonal; a ``LinearOperator``: ``t = K (-r)``
     V0: tensor or None
         (extension) start block ``(*batch, na, nguess)`` replacing the random draw
     orth_passes: int
@@ -303,6 +318,35 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         op.events = events                       # bench.py: per-launch HIP events of the panel product
     G = len(spans)
 
+    # ---- optional preconditioner of the new directions -----------------------------------------
+    pc_full = None
+    if precond is not None:
+        from xitorch_amd.linop import LinearOperator as _LinOp
+        if isinstance(precond, str):
+            if precond.lower() not in ("diag", "jacobi", "davidson"):
+                raise RuntimeError("Unknown davidson preconditioner: %s" % precond)
+            dA = whole.diagonal()
+            dM = _PanelOperator(M, bdims, B, N).diagonal() if M is not None else None
+            pc_full = ("diag", dA, dM)
+        elif isinstance(precond, torch.Tensor):
+            if precond.shape[-1] != N:
+                raise RuntimeError("precond diagonal must have shape (*batch, %d), got %s" % (N, tuple(precond.shape)))
+            dA = precond.to(device=device, dtype=dtype).expand(*bdims, N).reshape(B, N).contiguous()
+            dM = _PanelOperator(M, bdims, B, N).diagonal() if M is not None else None
+            pc_full = ("diag", dA, dM)
+        elif isinstance(precond, _LinOp):
+            if two:
+                raise RuntimeError("a LinearOperator preconditioner cannot be combined with overlap=True")
+            pc_full = ("op", _PanelOperator(precond, bdims, B, N))
+        else:
+            raise TypeError("precond must be None, 'diag', a tensor or a LinearOperator, got %s" % type(precond))
+
+    def _pc_slice(b0, b1):
+        if pc_full is None or pc_full[0] == "op":
+            return pc_full
+        cut = lambda t: None if t is None else (t if t.shape[0] == 1 else t[b0:b1])
+        return ("diag", cut(pc_full[1]), cut(pc_full[2]))
+
     V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device)       # (B, nguess, N)
     if two:
         for st in streams:
@@ -312,7 +356,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     for g, (b0, b1) in enumerate(spans):
         with torch.cuda.stream(streams[g]):
             opM = _PanelOperator(M, bdims, B, N) if M is not None else None
-            grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes)
+            grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
+                         precond=_pc_slice(b0, b1))
             k1_done[g] = grp.start(V0p[b0:b1], k1_done[g - 1] if g > 0 else None)
             groups.append(grp)
 
