@@ -148,8 +148,10 @@ def main():
         step(False)
     fence()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         evals, evecs = step(True)
+        step_marks.append(time.perf_counter())      # host clock only (davidson returns after its last status read)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -234,6 +236,8 @@ def main():
             "roofline_general_k1": roofline_general,
             "matvec_fraction_of_step": sum(durs) / elapsed if elapsed > 0 else None,
             "check": {"ok": bool(ok), "max_eval_err_vs_exact": eval_err, "max_resid": resid},
+            "step_ms": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)],
+            "k1_ms_first_last": [round(durs[0] * 1e3, 3), round(durs[-1] * 1e3, 3)] if durs else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
