@@ -6,17 +6,9 @@ odd shapes (lower triangle poisoned with NaN), then timed at bench size.
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from xitorch_amd import _capi
 from xitorch_amd.kernels import dense_mm, dense_symm
 
 dev = torch.device("cuda:0")
-VARIANTS = [(8, 0)]
-
-
-def tune(r, order):
-    pass        # the (rows-per-chunk, tile-order) experiment is over: 8-row chunks, row-tile-major order
-
-
 def timeit(f, reps=5):
     f(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -46,15 +38,12 @@ for (B, N, P, dtype) in [(2, 2048, 6, torch.float64), (3, 1536, 4, torch.float64
     ref = dense_mm(A, X, trans=True)
     Ap = torch.triu(A) + torch.tril(torch.full_like(A, float("nan")), -1)     # the lower triangle must not be read
     tol = (1e-13 if dtype == torch.float64 else 3e-6) * N ** 0.5
-    for (r, o) in VARIANTS:
-        tune(r, o)
-        Y = dense_symm(Ap, X)
-        err = ((Y - ref).abs().max() / ref.abs().max()).item()
-        ok = err < tol
-        bad += (not ok)
-        if not ok or (r, o) == (8, 0):
-            print(json.dumps({"check": [B, N, P, str(dtype)], "rows": r, "order": o, "relerr": err, "ok": ok}), flush=True)
-print(json.dumps({"variants_failed": bad}), flush=True)
+    Y = dense_symm(Ap, X)
+    err = ((Y - ref).abs().max() / ref.abs().max()).item()
+    ok = err < tol
+    bad += (not ok)
+    print(json.dumps({"check": [B, N, P, str(dtype)], "relerr": err, "ok": ok}), flush=True)
+print(json.dumps({"checks_failed": bad}), flush=True)
 
 # ---- timing at bench size -------------------------------------------------------------------------
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -66,12 +55,10 @@ for P in (6, 4, 1):
     Y1 = dense_mm(A, X, trans=True)
     t1 = timeit(lambda: dense_mm(A, X, out=Y1, trans=True))
     row = {"B": B, "P": P, "general_ms": round(t1, 3), "general_GBps": round(full / t1, 1)}
-    for (r, o) in VARIANTS:
-        tune(r, o)
-        Y2 = dense_symm(A, X)
-        err = ((Y1 - Y2).abs().max() / Y1.abs().max()).item()
-        t2 = timeit(lambda: dense_symm(A, X, out=Y2))
-        row["r%d_o%d" % (r, o)] = {"ms": round(t2, 3), "triangle_GBps": round(full / 2 / t2, 1), "relerr": err}
+    Y2 = dense_symm(A, X)
+    err = ((Y1 - Y2).abs().max() / Y1.abs().max()).item()
+    t2 = timeit(lambda: dense_symm(A, X, out=Y2))
+    row["symm"] = {"ms": round(t2, 3), "triangle_GBps": round(full / 2 / t2, 1), "relerr": err}
     print(json.dumps(row), flush=True)
 del A
 if B >= 16:
@@ -81,11 +68,8 @@ if B >= 16:
     Y1 = dense_mm(A, X, trans=True)
     t1 = timeit(lambda: dense_mm(A, X, out=Y1, trans=True))
     row = {"fp32_B": 8, "N": 32768, "P": 6, "general_ms": round(t1, 3), "general_GBps": round(full / t1, 1)}
-    for (r, o) in VARIANTS:
-        tune(r, o)
-        Y2 = dense_symm(A, X)
-        err = ((Y1 - Y2).abs().max() / Y1.abs().max()).item()
-        t2 = timeit(lambda: dense_symm(A, X, out=Y2))
-        row["r%d_o%d" % (r, o)] = {"ms": round(t2, 3), "triangle_GBps": round(full / 2 / t2, 1), "relerr": err}
+    Y2 = dense_symm(A, X)
+    err = ((Y1 - Y2).abs().max() / Y1.abs().max()).item()
+    t2 = timeit(lambda: dense_symm(A, X, out=Y2))
+    row["symm"] = {"ms": round(t2, 3), "triangle_GBps": round(full / 2 / t2, 1), "relerr": err}
     print(json.dumps(row), flush=True)
-tune(4, 0)

@@ -36,17 +36,6 @@ __device__ __forceinline__ V ld_stream(const V* p) {
   return __builtin_nontemporal_load(p);
 }
 
-// Pin a wave-uniform pointer into an SGPR pair, so that `uniform_ptr(p) + lane_offset32` selects the
-// scalar-base + 32-bit-VGPR-offset form of global_load (no per-load 64-bit VGPR address pair and no
-// loop-strength-reduced VGPR pointer per row).
-template <typename P>
-__device__ __forceinline__ const P* uniform_ptr(const P* p) {
-  const uint64_t v = reinterpret_cast<uint64_t>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<const P*>(((uint64_t)hi << 32) | lo);
-}
-
 __device__ __forceinline__ double shfl_xor_t(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_xor_t(float v, int mask) { return __shfl_xor(v, mask, 64); }
 
