@@ -166,3 +166,45 @@ def test_davidson_diagonal_preconditioner(dev):
     # through the front-end
     evf, _ = xa.linalg.symeig(Aop, neig=neig, method="davidson", precond="diag", **kw)
     assert (evf.cpu() - lam_ref).abs().max().item() < 1e-10 * 600
+
+
+@pytest.mark.parametrize("B,N,neig,mode", [(3, 333, 3, "lowest"), (2, 130, 5, "uppest"), (1, 77, 1, "lowest")])
+def test_davidson_ragged_sizes_vs_oracle(dev, B, N, neig, mode):
+    # N not a multiple of the vector width / pad unit: padded pitch, general panel kernel; same iterates as the oracle
+    g = torch.Generator().manual_seed(N)
+    R = torch.randn(B, N, N, dtype=torch.float64, generator=g)
+    mat = (R + R.transpose(-2, -1)) * 0.05 + torch.diag(torch.linspace(0.0, 30.0, N, dtype=torch.float64))
+    tr, tr_o = {}, {}
+    ev, X = davidson(xa.LinearOperator.m(mat.to(dev), True), neig, mode, min_eps=1e-8, trace=tr)
+    ev_o, X_o = osym.davidson(oops.DenseOp(mat, True), neig, mode, None, min_eps=1e-8, trace=tr_o)
+    assert (ev.cpu() - ev_o).abs().max().item() < 1e-10 * 30
+    assert abs(tr["niter"] - tr_o["niter"]) <= 2
+    Xc = X.cpu()
+    assert (torch.matmul(mat, Xc) - Xc * ev.cpu().unsqueeze(-2)).abs().max().item() < 1e-7
+    exact = torch.linalg.eigvalsh(mat)
+    exact = exact[:, :neig] if mode == "lowest" else exact[:, -neig:]
+    assert (ev.cpu() - exact).abs().max().item() < 1e-10 * 30
+
+
+def test_davidson_full_basis_stop_and_float32(dev):
+    # (1) an unreachable tolerance: the basis grows until it is square, then the exact pairs are returned
+    #     (stop rule `k == N`, symeig.py:196-203)
+    g = torch.Generator().manual_seed(4)
+    N = 20
+    R = torch.randn(2, N, N, dtype=torch.float64, generator=g)
+    mat = (R + R.transpose(-2, -1)) * 0.5
+    tr = {}
+    ev, X = davidson(xa.LinearOperator.m(mat.to(dev), True), 3, "lowest", min_eps=1e-300, trace=tr)
+    assert tr["stop_reason"] == "full_basis" and tr["basis_size"] == N
+    assert (ev.cpu() - torch.linalg.eigvalsh(mat)[:, :3]).abs().max().item() < 1e-10
+    # (2) float32 operator: fp32 kernels end to end, eigenvalues to fp32 accuracy
+    mat32 = (mat * 0.1 + torch.diag(torch.arange(N, dtype=torch.float64))).float()
+    mat32 = (mat32 + mat32.transpose(-2, -1)) * 0.5
+    ev32, X32 = davidson(xa.LinearOperator.m(mat32.to(dev), True), 2, "uppest", min_eps=1e-4)
+    assert ev32.dtype == torch.float32
+    assert (ev32.cpu().double() - torch.linalg.eigvalsh(mat32.double())[:, -2:]).abs().max().item() < 2e-4
+    # (3) batch dims of rank 2 and neig == nguess == 1
+    mat4 = mat.reshape(2, 1, N, N).expand(2, 2, N, N).contiguous()
+    ev4, X4 = davidson(xa.LinearOperator.m(mat4.to(dev), True), 1, "lowest", min_eps=1e-9)
+    assert list(ev4.shape) == [2, 2, 1] and list(X4.shape) == [2, 2, N, 1]
+    assert (ev4.cpu()[:, 0, 0] - torch.linalg.eigvalsh(mat)[:, 0]).abs().max().item() < 1e-10
