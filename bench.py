@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--max-niter", type=int, default=200, help="guard only; ~19 iterations are needed")
-    ap.add_argument("--overlap", action="store_true", help="two batch groups pipelined on two HIP streams")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one batch group on one stream (default: two groups, panel products on a CU-masked stream)")
+    ap.add_argument("--reserve-cus", type=int, default=32,
+                    help="compute units the panel-product stream leaves to the small kernels of the other batch half")
     ap.add_argument("--k1", default="auto", choices=["auto", "general"],
                     help="auto: upper-triangle kernel when the storage is exactly symmetric; general: full matrix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,7 +136,7 @@ def main():
         with torch.no_grad():
             evals, evecs = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=args.min_eps,
                                   v_init="randn", rng_device="device", max_niter=args.max_niter,
-                                  overlap=bool(args.overlap),
+                                  overlap=(False if args.no_overlap else "auto"), reserve_cus=args.reserve_cus,
                                   process_group=group, trace=tr)
         if timed:
             traces.append(tr)

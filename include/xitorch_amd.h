@@ -35,6 +35,14 @@ extern "C" {
 /* library/ABI version (bumped when a signature changes) */
 int xk_abi_version(void);
 
+/* ---- CU-masked stream (no reference counterpart: the reference runs everything on one stream) ----
+ * Creates a HIP stream whose kernels may use all but `reserve_cus` compute units of `device`
+ * (hipExtStreamCreateWithCUMask).  The eigensolver launches the HBM-bound panel product on it so that the
+ * latency-bound small kernels of the other half of the batch find free CUs (linalg.symeig davidson,
+ * option overlap).  The caller owns the stream (xk_stream_destroy). */
+int xk_stream_create_cu_masked(int device, int reserve_cus, void** stream_out);
+int xk_stream_destroy(void* stream);
+
 /* ---- K1: batched dense operator-panel product --------------------------------
  * trans=0:  Y[b,c,i] = sum_j A[b,i,j] X[b,c,j]     i<M, j<N
  * trans=1:  Y[b,c,j] = sum_i A[b,i,j] X[b,c,i]

@@ -49,6 +49,8 @@ def _declare(L):
     P, I, Lg, D = c_void_p, c_int, c_long, c_double
     sigs = {
         "xk_abi_version": (I, []),
+        "xk_stream_create_cu_masked": (I, [I, I, P]),
+        "xk_stream_destroy": (I, [P]),
         "xk_dense_mm_workspace_elems": (Lg, [I, I, I, I, I]),
         "xk_dense_mm_f64": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),
         "xk_dense_mm_f32": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),

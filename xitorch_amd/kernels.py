@@ -208,6 +208,29 @@ def banded_mm(band, X, out=None, trans=False):
     return out
 
 
+# --------------------------------------------------------------------------- CU-masked stream
+_MASKED_STREAMS = {}
+
+
+def masked_stream(device, reserve_cus=32, slot=0):
+    """A process-lifetime HIP stream on `device` that leaves `reserve_cus` compute units unused
+    (hipExtStreamCreateWithCUMask), wrapped as a torch stream.  The HBM-bound panel product runs at full
+    speed on 192-224 CUs; the CUs it leaves free serve the latency-bound kernels of the other batch half.
+    A stream with a CU mask owns its hardware queue, so `reserve_cus=0` streams (distinct `slot`s) are also how
+    the two batch groups get queues that never share a barrier packet — torch's pooled streams are multiplexed
+    onto a few hardware queues, and a group whose stream lands behind the other group's "wait for the panel
+    product" barrier is serialised with it."""
+    import ctypes
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(reserve_cus), int(slot))
+    if key not in _MASKED_STREAMS:
+        out = ctypes.c_void_p()
+        rc = fn("xk_stream_create_cu_masked")(key[0], key[1], ctypes.byref(out))
+        check(rc, "xk_stream_create_cu_masked")
+        _MASKED_STREAMS[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key[0]))
+    return _MASKED_STREAMS[key]
+
+
 # --------------------------------------------------------------------------- K1s symmetric storage
 def dense_symm(A, X, out=None):
     """Y[b,c,:] = A_b X[b,c,:] for EXACTLY symmetric A (B or 1, N, N): only the upper triangle is read.

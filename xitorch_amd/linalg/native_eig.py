@@ -86,6 +86,8 @@ class _Group:
                  precond=None):
         self.opA, self.opM = opA, opM
         self.precond = precond                    # None | ("diag", dA, dM) | ("op", PanelOperator)
+        self.k1_stream = None                     # two-group pipeline: the (CU-masked) stream of the panel products
+        self.timeline, self.tag = None, 0         # debugging: (tag, label, start event, end event) per phase
         self.B, self.N, self.Npad, self.p = B, N, Npad, p
         self.dtype, self.device, self.mode = dtype, device, mode
         self.small_eigh, self.orth_passes = small_eigh, orth_passes
@@ -148,32 +150,63 @@ class _Group:
         self.T[:, k0:k0 + q, :k0 + q] = Tn
         self.T[:, :k0, k0:k0 + q] = Tn[:, :, :k0].transpose(-2, -1)
 
-    def start(self, V0p, wait_event=None):
+    def _mark(self, label, stream=None):
+        """timeline instrumentation: returns a closer that records the end event"""
+        if self.timeline is None:
+            return lambda: None
+        st = stream if stream is not None else torch.cuda.current_stream()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+
+        def close():
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(st)
+            self.timeline.append((self.tag, label, e0, e1))
+        return close
+
+    def apply_A(self, X, out):
+        """out = A X.  In the two-group pipeline the panel products of both groups are funnelled through one
+        stream (so they run back to back) whose CU mask leaves compute units free for the other group's small
+        kernels; the group's own stream waits for the result."""
+        if self.k1_stream is None:
+            self.opA.apply(X, out)
+            return
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.k1_stream):
+            self.k1_stream.wait_event(ready)
+            end = self._mark("k1", self.k1_stream)
+            self.opA.apply(X, out)
+            end()
+            done = torch.cuda.Event()
+            done.record(self.k1_stream)
+        cur.wait_event(done)
+
+    def start(self, V0p):
         k = V0p.shape[1]
         self.grow(k + self.p)
         self.Vs[:, :k, :self.N].copy_(V0p)
         self.cholqr(0, k)
         self.cholqr(0, k)          # CholeskyQR2: the second pass only removes rounding-level loss
-        if wait_event is not None:
-            torch.cuda.current_stream().wait_event(wait_event)
-        self.opA.apply(self.Vs[:, :k], self.AVs[:, :k])
-        done = torch.cuda.Event()
-        done.record()
+        self.apply_A(self.Vs[:, :k], self.AVs[:, :k])
         self.extend_T(0, k)
         self.k = k
-        return done
 
     def small(self):
         """Rayleigh-Ritz on the current basis: K3 + fused rotation/residual; leaves {max|resid|, flag} in
         self.status (device) and the next panel in the basis.  No host sync."""
         k, p, N = self.k, self.p, self.N
         if self.small_eigh == "native" and k <= K.SMALL_EIGH_MAX_K and p <= K.SMALL_EIGH_MAX_P:
+            end = self._mark("k3")
             lam, Yt, _ = K.small_eigh(self.T, k, p, uppest=(self.mode != "lowest"))      # K3: LDS Jacobi kernel
+            end()
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
         else:
             lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # large bases: library eigh
             lam, Y = take_eigpairs(lam_all, Y_all, p, self.mode)
             lam = lam.contiguous()
+        end_ritz = self._mark("ritz")
         self.grow(min(N, k + p))
         self.nadd = min(p, N - k)
         self.slot = 1 - self.best_slot if self.best_slot >= 0 else 0
@@ -200,23 +233,23 @@ class _Group:
         self.lam = lam
         self.status[0] = self.rmax.max()
         self.status[1] = self.info.max()
+        end_ritz()
 
-    def expand(self, wait_event=None):
+    def expand(self):
         """Orthonormalise the residual panel against the basis, apply the operator to it, extend T."""
         k, nadd = self.k, self.nadd
         if nadd != self.p:
             self.Vs[:, k:k + nadd].copy_(self.newpanel[:, :nadd])
+        end = self._mark("orth")
         for _ in range(max(1, self.orth_passes)):
             self.project_out(k, nadd)
         self.cholqr(k, nadd)
-        if wait_event is not None:
-            torch.cuda.current_stream().wait_event(wait_event)    # panel products of the groups run back to back
-        self.opA.apply(self.Vs[:, k:k + nadd], self.AVs[:, k:k + nadd])
-        done = torch.cuda.Event()
-        done.record()
+        end()
+        self.apply_A(self.Vs[:, k:k + nadd], self.AVs[:, k:k + nadd])
+        end = self._mark("extT")
         self.extend_T(k, nadd)
+        end()
         self.k = k + nadd
-        return done
 
 
 def _sub_operator(A, B, N, b0, b1):
@@ -227,7 +260,7 @@ def _sub_operator(A, B, N, b0, b1):
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
-             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, **unused):
+             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=32, **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -256,11 +289,14 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         (extension) ``"native"`` (default): the Rayleigh–Ritz matrix is diagonalised by the LDS Jacobi
         kernel while the basis has <= 128 vectors; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
-        (extension) ``True``: a batch of native dense operators is processed as two groups on two HIP
-        streams, so that the small Rayleigh–Ritz / orthogonalisation kernels of one group run underneath the
-        operator-panel product of the other (the panel products themselves stay back to back); iteration
-        counts and the stopping rule are unchanged.  ``"auto"`` (default) / ``False``: one group on the current
-        stream — at the benchmark size the two schedules measure the same
+        (extension) a batch of native dense operators can be processed as two groups: the operator-panel
+        products of both groups run back to back on one stream whose CU mask leaves ``reserve_cus`` compute
+        units free, and the small Rayleigh–Ritz / orthogonalisation kernels of one group run on those CUs (own
+        hardware queue) underneath the panel product of the other.  Iteration counts and the stopping rule are
+        unchanged.  ``"auto"`` (default): on from 8 GiB of operator storage; ``True`` / ``False`` force it
+    reserve_cus: int
+        (extension) compute units the panel-product stream leaves to the small kernels (default 32 of 256; the
+        HBM-bound panel product is as fast on 192-224 CUs as on all of them)
     precond: None, str, tensor or LinearOperator
         (extension; the reference has no preconditioner, symeig.py:206-207) ``None`` (default): new directions
         are the negated residuals, exactly like the reference.  ``"diag"``: Davidson's diagonal correction
@@ -300,20 +336,23 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     nA = 1
     for d in A.shape[:-2]:
         nA *= d
-    # "auto" currently means off: at config-2 size the half-batch panel products lose to block-count
-    # quantisation (8.5 instead of 17 full waves of tiles) what the overlap wins (measured 249.8 vs 249.6 ms)
-    two = overlap is True and M is None and whole.kind == "dense" \
-        and not whole.flip and nA == B and B >= 2
+    # Two groups pay off when a half-batch panel product is long enough (>= ~1 ms) to hide the other half's
+    # small-kernel chain: "auto" switches them on from 8 GiB of operator storage (config 2: 137 GB).
+    can_two = M is None and whole.kind == "dense" and not whole.flip and nA == B and B >= 2 \
+        and not (precond is not None and not isinstance(precond, (str, torch.Tensor)))
+    big = B * N * N * (8 if dtype == torch.float64 else 4) >= 2 ** 33
+    two = can_two and (overlap is True or (overlap == "auto" and big))
     if two:
         h = B // 2
         spans = [(0, h), (h, B)]
         ops = [_PanelOperator(_sub_operator(A, B, N, b0, b1), [b1 - b0], b1 - b0, N) for (b0, b1) in spans]
         cur = torch.cuda.current_stream()
-        streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
-        for st in streams:
+        streams = [K.masked_stream(device, 0, slot=1), K.masked_stream(device, 0, slot=2)]   # own hardware queues
+        k1_stream = K.masked_stream(device, reserve_cus)
+        for st in streams + [k1_stream]:
             st.wait_stream(cur)
     else:
-        spans, ops, streams = [(0, B)], [whole], [torch.cuda.current_stream()]
+        spans, ops, streams, k1_stream = [(0, B)], [whole], [torch.cuda.current_stream()], None
     for op in ops:
         op.events = events                       # bench.py: per-launch HIP events of the panel product
     G = len(spans)
@@ -335,8 +374,6 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
             dM = _PanelOperator(M, bdims, B, N).diagonal() if M is not None else None
             pc_full = ("diag", dA, dM)
         elif isinstance(precond, _LinOp):
-            if two:
-                raise RuntimeError("a LinearOperator preconditioner cannot be combined with overlap=True")
             pc_full = ("op", _PanelOperator(precond, bdims, B, N))
         else:
             raise TypeError("precond must be None, 'diag', a tensor or a LinearOperator, got %s" % type(precond))
@@ -352,13 +389,15 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())
     groups = []
-    k1_done = [None] * G
     for g, (b0, b1) in enumerate(spans):
         with torch.cuda.stream(streams[g]):
             opM = _PanelOperator(M, bdims, B, N) if M is not None else None
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
                          precond=_pc_slice(b0, b1))
-            k1_done[g] = grp.start(V0p[b0:b1], k1_done[g - 1] if g > 0 else None)
+            grp.k1_stream = k1_stream
+            if trace is not None and "timeline" in trace:
+                grp.timeline, grp.tag = trace["timeline"], g
+            grp.start(V0p[b0:b1])
             groups.append(grp)
 
     best_resid = float("inf")
@@ -382,7 +421,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                 # certain, enqueue it now so its panel product runs under the next group's small kernels
                 if st_g >= min_eps and bad_g == 0 and groups[g].k < N:
                     with torch.cuda.stream(streams[g]):
-                        k1_done[g] = groups[g].expand(k1_done[(g - 1) % G] if G > 1 else None)
+                        groups[g].expand()
                 else:
                     deferred.append(g)
         max_resid = local_max
@@ -409,13 +448,13 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
             break
         for g in deferred + [G - 1]:
             with torch.cuda.stream(streams[g]):
-                k1_done[g] = groups[g].expand(k1_done[(g - 1) % G] if G > 1 else None)
+                groups[g].expand()
 
     if groups[0].best_slot < 0:     # max_niter == 0 or NaN residuals throughout
         raise RuntimeError("xitorch_amd davidson: no finite residual was produced")
     if two:
         cur = torch.cuda.current_stream()
-        for st in streams:
+        for st in streams + [k1_stream]:
             cur.wait_stream(st)
         evals = torch.cat([grp.best_evals for grp in groups], dim=0)
         Xall = torch.cat([grp.Xbuf[grp.best_slot] for grp in groups], dim=0)
