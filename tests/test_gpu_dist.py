@@ -1,0 +1,74 @@
+"""-m gpu: the sharded eigensolver with a REAL process group — two processes on the one GPU of the test box
+(gloo backend: RCCL refuses two ranks on one device; the code path in davidson is the same all-reduce MAX).
+Each rank owns half of the batch; the iteration count, eigenvalues and residuals must equal the unsharded run,
+with and without the two-group pipeline."""
+import os
+import socket
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import xitorch_amd as xa
+        from xitorch_amd import dist as xd, synthetic
+        from xitorch_amd.linalg.native_eig import davidson
+        dev = torch.device("cuda:0")
+        B, N, neig = 6, 768, 4
+        mat = synthetic.dense_symmetric(B, N, "S1", device=dev)
+        # make the members converge at different speeds: the slowest one (on rank 1) decides for everybody
+        mat = mat * torch.linspace(1.0, 1.6, B, dtype=torch.float64, device=dev).reshape(B, 1, 1)
+        lo, hi = xd.shard_range(B, world, rank)
+        V0 = torch.randn(B, N, neig, dtype=torch.float64, generator=torch.Generator().manual_seed(7)).to(dev)
+        out = {}
+        for overlap in (False, True):
+            tr_f, tr_s = {}, {}
+            ev_f, _ = davidson(xa.LinearOperator.m(mat, True), neig, "lowest", min_eps=1e-8, trace=tr_f, overlap=False,
+                               V0=V0)
+            ev_s, X_s = davidson(xa.LinearOperator.m(mat[lo:hi].contiguous(), True), neig, "lowest", min_eps=1e-8,
+                                 trace=tr_s, overlap=overlap, process_group=dist.group.WORLD, V0=V0[lo:hi])
+            R = torch.matmul(mat[lo:hi], X_s) - X_s * ev_s.unsqueeze(-2)
+            out[overlap] = dict(niter=(tr_s["niter"], tr_f["niter"]), groups=tr_s["groups"],
+                                err=(ev_s - ev_f[lo:hi]).abs().max().item(), resid=R.abs().max().item(),
+                                hist=max(abs(a - b) for a, b in zip(tr_s["resid_history"], tr_f["resid_history"])))
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_davidson_two_ranks_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    results = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for rank in range(world):
+        for overlap in (False, True):
+            r = results[rank][overlap]
+            assert r["niter"][0] == r["niter"][1], r            # lock step with the global stopping rule
+            assert r["groups"] == (2 if overlap else 1)
+            assert r["err"] < 1e-10 * 160 and r["resid"] < 1e-7, r
+            assert r["hist"] < 1e-6, r                           # the all-reduced residual IS the global one

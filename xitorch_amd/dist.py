@@ -32,15 +32,19 @@ def shard_range(total, world_size, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def _trivial(group):
+    return group is None or torch.distributed.get_world_size(group) == 1
+
+
 def allreduce_max_(t, group=None):
-    """In-place MAX over the group (no-op when group is None)."""
-    if group is not None:
+    """In-place MAX over the group (no-op when group is None or has a single rank)."""
+    if not _trivial(group):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
     return t
 
 
 def allreduce_sum_(t, group=None):
-    """In-place SUM over the group (no-op when group is None)."""
-    if group is not None:
+    """In-place SUM over the group (no-op when group is None or has a single rank)."""
+    if not _trivial(group):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
     return t

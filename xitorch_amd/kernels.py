@@ -212,7 +212,7 @@ def banded_mm(band, X, out=None, trans=False):
 _MASKED_STREAMS = {}
 
 
-def masked_stream(device, reserve_cus=32, slot=0):
+def masked_stream(device, reserve_cus=64, slot=0):
     """A process-lifetime HIP stream on `device` that leaves `reserve_cus` compute units unused
     (hipExtStreamCreateWithCUMask), wrapped as a torch stream.  The HBM-bound panel product runs at full
     speed on 192-224 CUs; the CUs it leaves free serve the latency-bound kernels of the other batch half.

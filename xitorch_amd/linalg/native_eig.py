@@ -260,7 +260,7 @@ def _sub_operator(A, B, N, b0, b1):
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
-             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=32, **unused):
+             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -295,8 +295,9 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         hardware queue) underneath the panel product of the other.  Iteration counts and the stopping rule are
         unchanged.  ``"auto"`` (default): on from 8 GiB of operator storage; ``True`` / ``False`` force it
     reserve_cus: int
-        (extension) compute units the panel-product stream leaves to the small kernels (default 32 of 256; the
-        HBM-bound panel product is as fast on 192-224 CUs as on all of them)
+        (extension) compute units the panel-product stream leaves to the small kernels (default 64 of 256: the
+        HBM-bound panel product is as fast on 192 CUs as on all of them; whole 32-CU mask words measured best:
+        224.2 ms per config-2 call with 64, 227.5 with 32, 233 with 48 or 8, 241 with 96)
     precond: None, str, tensor or LinearOperator
         (extension; the reference has no preconditioner, symeig.py:206-207) ``None`` (default): new directions
         are the negated residuals, exactly like the reference.  ``"diag"``: Davidson's diagonal correction
@@ -347,7 +348,10 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         spans = [(0, h), (h, B)]
         ops = [_PanelOperator(_sub_operator(A, B, N, b0, b1), [b1 - b0], b1 - b0, N) for (b0, b1) in spans]
         cur = torch.cuda.current_stream()
-        streams = [K.masked_stream(device, 0, slot=1), K.masked_stream(device, 0, slot=2)]   # own hardware queues
+        # each group gets a stream with its own hardware queue (see kernels.masked_stream).  The caller's
+        # stream is not used for a group: it usually is the legacy null stream, which synchronises implicitly
+        # with every blocking stream and serialises the pipeline (measured: 280 instead of 224 ms)
+        streams = [K.masked_stream(device, 0, slot=1), K.masked_stream(device, 0, slot=2)]
         k1_stream = K.masked_stream(device, reserve_cus)
         for st in streams + [k1_stream]:
             st.wait_stream(cur)
@@ -404,7 +408,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     history = []
     stop_reason = "max_niter"
     niter = 0
-    gstat = torch.zeros((2,), dtype=torch.float64, device=device) if process_group is not None else None
+    distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
+    gstat = torch.zeros((2,), dtype=torch.float64, device=device) if distributed else None
     for it in range(max_niter):
         niter = it + 1
         local_max, bad = 0.0, 0.0
@@ -425,11 +430,15 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                 else:
                     deferred.append(g)
         max_resid = local_max
-        if process_group is not None:
+        if distributed:
             with torch.cuda.stream(streams[G - 1]):
-                gstat[0], gstat[1] = local_max, bad
+                # every group's {max|resid|, flag} is complete (the host has read them): fold them on the
+                # device, one all-reduce (MAX) over the ranks, one read
+                torch.amax(torch.stack([grp.status for grp in groups]), dim=0, out=gstat)
                 allreduce_max_(gstat, process_group)
                 max_resid, bad = gstat.tolist()
+            if max_resid != max_resid:
+                max_resid = float("inf")
         if bad != 0:
             raise RuntimeError("xitorch_amd davidson: the panel Gram matrix is not positive definite "
                                "(linearly dependent guess/residual vectors)")
