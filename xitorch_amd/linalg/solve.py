@@ -7,7 +7,7 @@ Same signature, defaults, argument checks and adjoint backward as the reference
 """
 import warnings
 import torch
-from xitorch_amd.linop import LinearOperator, MatrixLinearOperator
+from xitorch_amd.linop import MatrixLinearOperator
 from xitorch_amd.debug import is_debug_enabled
 from xitorch_amd._util import assert_runtime, merge_options, null_context, get_method
 

@@ -7,7 +7,7 @@ HIP eigensolver (xitorch_amd/linalg/native_eig.py) and the backward solve goes t
 """
 import warnings
 import torch
-from xitorch_amd.linop import LinearOperator, MatrixLinearOperator
+from xitorch_amd.linop import LinearOperator  # noqa: F401  (re-exported for type references in user code)
 from xitorch_amd.linalg.solve import solve
 from xitorch_amd.linalg.native_eig import davidson, exacteig
 from xitorch_amd.debug import is_debug_enabled
