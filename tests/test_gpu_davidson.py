@@ -208,3 +208,22 @@ def test_davidson_full_basis_stop_and_float32(dev):
     ev4, X4 = davidson(xa.LinearOperator.m(mat4.to(dev), True), 1, "lowest", min_eps=1e-9)
     assert list(ev4.shape) == [2, 2, 1] and list(X4.shape) == [2, 2, N, 1]
     assert (ev4.cpu()[:, 0, 0] - torch.linalg.eigvalsh(mat)[:, 0]).abs().max().item() < 1e-10
+
+
+def test_two_group_pipeline_with_preconditioner_and_odd_batch(dev):
+    # the diagonal of the operator is sliced per group; an odd batch splits 2 + 3
+    B, N, neig = 5, 400, 3
+    g = torch.Generator().manual_seed(9)
+    R = torch.randn(B, N, N, dtype=torch.float64, generator=g) * 0.02
+    A = (R + R.transpose(-2, -1)) * 0.5 + torch.diag(torch.linspace(1.0, 400.0, N, dtype=torch.float64))
+    Aop = xa.LinearOperator.m(A.to(dev), is_hermitian=True)
+    t1, t2 = {}, {}
+    kw = dict(min_eps=1e-9, v_init="eye", precond="diag")
+    ev1, X1 = davidson(Aop, neig, "lowest", overlap=False, trace=t1, **kw)
+    ev2, X2 = davidson(Aop, neig, "lowest", overlap=True, trace=t2, **kw)
+    assert t1["groups"] == 1 and t2["groups"] == 2 and t1["niter"] == t2["niter"]
+    assert torch.allclose(ev1, ev2, rtol=0, atol=1e-11 * 400)
+    ref = torch.linalg.eigvalsh(A)[:, :neig]
+    assert (ev2.cpu() - ref).abs().max().item() < 1e-10 * 400
+    Xc = X2.cpu()
+    assert (torch.matmul(A, Xc) - Xc * ev2.cpu().unsqueeze(-2)).abs().max().item() < 1e-7
