@@ -14,8 +14,8 @@
 // Mapping.  Tiles of TRH=1024 rows x 1024 columns (fp64; 2048 columns fp32).  One 256-thread block
 // per tile; the 4 waves own 4 x 256 columns (lane: two 16 B vectors, so each load instruction is a
 // contiguous 1 KB and the cross-lane reduction is amortised over twice the data), and walk down the
-// tile's rows in chunks of 8 (16 buffer loads = 16 KB in flight per wave, issued together at the top of the
-// chunk; descriptor + one loop-invariant lane offset + scalar row offset, no 64-bit vector address arithmetic):
+// tile's rows in chunks of 8 (16 buffer loads = 16 KB in flight per wave; descriptor + one loop-invariant
+// lane offset + scalar row offset, no 64-bit vector address arithmetic):
 //   * column part: per-lane register accumulators acc_col[P][VN] over the whole tile (panel
 //     values x_I are wave-uniform scalar loads);
 //   * row part: per-lane products a[r]*x_J (x_J held in registers for the tile), folded across
@@ -30,12 +30,18 @@
 //
 // Register budget (fp64, P=6): 203 VGPRs -> 2 waves per SIMD; the panel/accumulator registers (96) cannot be
 // shared between waves, so the third wave (<=168 VGPRs) is out of reach and the chunk depth is what keeps
-// enough bytes in flight.  A rolling prefetch ring (rows refilled pair by pair while the chunk is being
-// reduced) was built and measured: no gain over issuing the chunk's loads up front, so it is not used.
-// The first version of this kernel (4-row chunks, per-lane 64-bit addresses, 188 VGPRs) is 1-4 % faster when it
-// has the GPU to itself, but 7 % slower (6.78 vs 6.32 ms per half-batch launch) in the eigensolver's pipeline,
-// where it shares HBM and CUs with the other batch group's small kernels — the deeper chunk is what keeps its
-// request stream up under contention.
+// enough bytes in flight.
+//
+// What was measured (fp64, P = 6, N = 16384, half batch of 32 per launch):
+//   alone on the GPU — this kernel 5.60-5.76 ms; the same with the chunk's 16 loads issued up front instead of
+//     the rolling ring 5.58-5.74; the first version (4-row chunks, per-lane 64-bit addresses, generic
+//     reduction, 188 VGPRs) 5.53-5.70;
+//   inside the eigensolver's two-group pipeline, i.e. sharing HBM and CUs with the other group's small kernels
+//     — ring 6.03-6.12 ms (222-225 ms per symeig call), loads-up-front 6.32-6.41 (232-235), first version
+//     6.78 (248.5).  The ring keeps 12-16 KB per wave in flight at all times and is what holds the request
+//     stream up under contention, so it is the shipped form although it wins nothing in isolation.
+//   tile orders other than row-tile-major (XCD-contiguous runs, batch-fastest, short-tiles-first, slab-major,
+//     member pairs interleaved): 0-7 % slower; balancing the diagonal tiles across waves: 1 % slower.
 //
 // Traffic per launch: B*N^2*s/2 (+2 % for the crossing tiles) + 2 * B*(NS+NT)*P*N*s of partials
 // (2.5 %) — vs B*N^2*s for the general kernel.
@@ -84,7 +90,8 @@ constexpr int SYMM_R = 8;       // rows per chunk
 
 template <typename T, int P, bool CROSSING, bool TAIL>
 __device__ __forceinline__ void symm_chunk8(
-    const TileRsrc Ab, const T* __restrict__ Xb, unsigned lda, long ldx, int N, int i0, int i_end,
+    typename Vec16<T>::type (&a)[SYMM_R][SYMM_NU], const TileRsrc Ab, const T* __restrict__ Xb, unsigned lda,
+    long ldx, int N, int i0, int i_end,
     const int (&jj)[SYMM_NU], const unsigned (&joff)[SYMM_NU], int row_tile0,
     typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
     T* rowacc, int lane) {
@@ -92,14 +99,6 @@ __device__ __forceinline__ void symm_chunk8(
   constexpr int VN = Vec16<T>::n;
   constexpr int R = SYMM_R, NU = SYMM_NU;
   const int i_last = i_end - 1;
-  VT a[R][NU];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int row = i0 + r;
-    if (TAIL) row = row < i_last ? row : i_last;       // rows past the end re-read the last one (masked below)
-#pragma unroll
-    for (int u = 0; u < NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
-  }
   T L2[2][P];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -157,6 +156,18 @@ __device__ __forceinline__ void symm_chunk8(
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int c = 0; c < P; ++c) asm volatile("" : "+v"(acc_col[u][c]));
+      // rolling prefetch: the two rows just consumed are refilled with the rows 8 further down, so the wave
+      // always has ~6 row pairs of loads in flight while it computes (rows past the end re-read the last one)
+      if (!TAIL) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          int row = i0 + R + 4 * g + 2 * h + q;
+          row = row < i_last ? row : i_last;
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);      // keep the row pairs in program order (bounded live ranges)
     }
 #pragma unroll
@@ -218,12 +229,22 @@ __device__ __forceinline__ void symm_tile_rows(
     const int (&jj)[SYMM_NU], const unsigned (&joff)[SYMM_NU], int row_tile0,
     typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
     T* rowacc, int lane) {
+  typedef typename Vec16<T>::type VT;
   if (i_begin >= i_end) return;
   const int full_end = i_begin + ((i_end - i_begin) / SYMM_R) * SYMM_R;
+  const int i_last = i_end - 1;
+  VT a[SYMM_R][SYMM_NU];                     // ring of 8 rows, refilled pair by pair inside the chunks
+#pragma unroll
+  for (int r = 0; r < SYMM_R; ++r) {
+    int row = i_begin + r;
+    row = row < i_last ? row : i_last;
+#pragma unroll
+    for (int u = 0; u < SYMM_NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
+  }
   for (int i0 = i_begin; i0 < full_end; i0 += SYMM_R)
-    symm_chunk8<T, P, CROSSING, false>(Ab, Xb, lda, ldx, N, i0, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
+    symm_chunk8<T, P, CROSSING, false>(a, Ab, Xb, lda, ldx, N, i0, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
   if (full_end < i_end)
-    symm_chunk8<T, P, CROSSING, true>(Ab, Xb, lda, ldx, N, full_end, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
+    symm_chunk8<T, P, CROSSING, true>(a, Ab, Xb, lda, ldx, N, full_end, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
 }
 
 template <typename T, int P>
