@@ -25,11 +25,11 @@ extern "C" int xk_stream_create_cu_masked(int device, int reserve_cus, void** st
   for (int w = 0; w < nwords; ++w) mask[w] = 0;
   for (int cu = 0; cu < ncu - reserve_cus; ++cu) mask[cu >> 5] |= (1u << (cu & 31));
   int prev = 0;
-  hipGetDevice(&prev);
-  if (prev != device) hipSetDevice(device);
+  if (hipGetDevice(&prev) != hipSuccess) prev = device;
+  if (prev != device && hipSetDevice(device) != hipSuccess) return XK_ERR_ARG;
   hipStream_t st = nullptr;
   e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask);
-  if (prev != device) hipSetDevice(prev);
+  if (prev != device) (void)hipSetDevice(prev);
   if (e != hipSuccess) return (int)e;
   *stream_out = (void*)st;
   return XK_OK;
