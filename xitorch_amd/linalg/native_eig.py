@@ -344,6 +344,14 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     big = B * N * N * (8 if dtype == torch.float64 else 4) >= 2 ** 33
     two = can_two and (overlap is True or (overlap == "auto" and big))
     if two:
+        try:
+            grp_streams = [K.masked_stream(device, 0, slot=1), K.masked_stream(device, 0, slot=2)]
+            k1_stream = K.masked_stream(device, reserve_cus)
+        except NativeLibraryError as err:            # no CU-mask support: same kernels, one group, one stream
+            import warnings
+            warnings.warn("xitorch_amd davidson: CU-masked streams unavailable (%s); running one batch group" % err)
+            two = False
+    if two:
         h = B // 2
         spans = [(0, h), (h, B)]
         ops = [_PanelOperator(_sub_operator(A, B, N, b0, b1), [b1 - b0], b1 - b0, N) for (b0, b1) in spans]
@@ -351,8 +359,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         # each group gets a stream with its own hardware queue (see kernels.masked_stream).  The caller's
         # stream is not used for a group: it usually is the legacy null stream, which synchronises implicitly
         # with every blocking stream and serialises the pipeline (measured: 280 instead of 224 ms)
-        streams = [K.masked_stream(device, 0, slot=1), K.masked_stream(device, 0, slot=2)]
-        k1_stream = K.masked_stream(device, reserve_cus)
+        streams = grp_streams
         for st in streams + [k1_stream]:
             st.wait_stream(cur)
     else:
