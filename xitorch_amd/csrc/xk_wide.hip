@@ -8,7 +8,9 @@
 // arithmetic intensity (2P/s flop per byte: 16 flop/B for fp32, P = 32) is beyond what fp32 VALU code
 // sustains while streaming (the guide measures ~52 TF for VALU vs 122-147 TF for MFMA f32), so the
 // contraction runs on v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64 — exact fp32/fp64 FMA chains, same
-// numerics as the VALU kernels — and stays HBM-bound (MFMA busy ~ 2/3 at P = 32).
+// numerics as the VALU kernels.  Measured at P = 32: fp32 5.6-5.8 TB/s one-pass-equivalent = 93 TFLOP/s with the
+// matrix cores 85 % busy at the ~1.5 GHz the chip clocks to under fp32 MFMA load (compute/power-bound; rocBLAS
+// 1.08x faster); fp64 5.2-5.6 TB/s with 69 % MFMA busy (balanced); P = 16 fp64 6.3-6.6 TB/s (HBM-bound).
 //
 // Operand mapping (column orientation, all global loads coalesced, no LDS):
 //   MFMA "M" = operator columns n, "K" = operator rows i (the contraction), "N" = panel columns c.
@@ -45,6 +47,36 @@ template <> struct Mfma<double> {
   static __device__ __forceinline__ int drow(int r, int lane) { return (lane >> 4) + 4 * r; }
 };
 
+// Streaming loads go through buffer descriptors (wave-uniform base of the slab, per-lane offset computed once,
+// scalar row-step offset): left to flat addressing the compiler rebuilt a 64-bit address with five integer
+// multiplies per load and — to save registers — waited for every load before issuing the next (one 1 KB
+// request in flight per wave).  aux = 2: non-temporal (the operator), aux = 0 for the L2-resident panel.
+typedef __amdgpu_buffer_rsrc_t WRsrc;
+typedef unsigned int wu4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wu2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__device__ __forceinline__ WRsrc wide_rsrc(const T* base, long bytes) {
+  const uint64_t v = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  void* b = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xffffffffL ? 0xffffffffL : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(b, (short)0, (int)nrec, 0x00020000);
+}
+__device__ __forceinline__ f4 wide_ld_a(float, const WRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2));
+}
+__device__ __forceinline__ d2 wide_ld_a(double, const WRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2));
+}
+__device__ __forceinline__ float wide_ld_x(float, const WRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ double wide_ld_x(double, const WRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+
 // NT = number of panel-column tiles of width TM handled per wave (P <= NT*TM)
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void dense_wide_cols(
@@ -57,18 +89,27 @@ __global__ __launch_bounds__(256) void dense_wide_cols(
   constexpr int WCOLS = VN * MM::TM;            // operator columns per wave (128 fp32 / 32 fp64)
   int bid = blockIdx.x;
   const int ct = bid % col_tiles; bid /= col_tiles;
-  const int slab = bid % nslab;
-  const int b = bid / nslab;
+  const int slab = __builtin_amdgcn_readfirstlane(bid % nslab);
+  const int b = __builtin_amdgcn_readfirstlane(bid / nslab);
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int n0 = (ct * 4 + wave) * WCOLS;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = __builtin_amdgcn_readfirstlane((ct * 4 + wave) * WCOLS);
   if (n0 >= N) return;                           // whole wave out of range (N % WCOLS handled by the launcher)
   const int kk = lane >> MM::SH;                 // which of the TK rows of a step this lane feeds
   const int mm = lane & MM::MSK;
-  const T* Ab = A + (long)b * sA + n0 + VN * mm;
-  const T* Xb = Xrm + (long)b * sXr + mm;
   const int i0 = slab * rows_per_slab;
   int i1 = i0 + rows_per_slab; i1 = i1 < M ? i1 : M;
+  const int nrows = i1 - i0;
+  if (nrows <= 0) return;
+  // descriptors: the slab's rows of this wave's column window / of the row-major panel
+  const unsigned ldab = (unsigned)(lda * (long)sizeof(T)), ldxb = (unsigned)(ldxr * (long)sizeof(T));
+  const WRsrc ra = wide_rsrc(A + (long)b * sA + (long)i0 * lda + n0,
+                             ((long)(nrows - 1) * lda + (N - n0)) * (long)sizeof(T));
+  const WRsrc rx = wide_rsrc(Xrm + (long)b * sXr + (long)i0 * ldxr, (long)nrows * ldxr * (long)sizeof(T));
+  const unsigned aoff = (unsigned)kk * ldab + (unsigned)(VN * mm) * (unsigned)sizeof(T);
+  unsigned xoff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) xoff[t] = (unsigned)kk * ldxb + (unsigned)(mm + t * MM::TM) * (unsigned)sizeof(T);
   acc_t acc[NT][VN];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -76,37 +117,48 @@ __global__ __launch_bounds__(256) void dense_wide_cols(
     for (int q = 0; q < VN; ++q)
 #pragma unroll
       for (int r = 0; r < MM::NACC; ++r) acc[t][q][r] = T(0);
-  constexpr int U = 8;                           // steps in flight (8 KB of A per wave)
-  int i = i0;
-  for (; i + U * MM::TK <= i1; i += U * MM::TK) {
+  constexpr int U = 8;                           // ring of K-steps in flight (8 KB of A per wave)
+  constexpr int BLK = U * MM::TK;                // rows per ring revolution
+  const int nfull = (nrows / BLK) * BLK;
+  if (nfull > 0) {
     VT av[U];
     T bv[U][NT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long row = i + u * MM::TK + kk;
-      av[u] = ld_stream(reinterpret_cast<const VT*>(Ab + row * lda));
+      const unsigned r0 = (unsigned)(u * MM::TK);
+      av[u] = wide_ld_a(T(0), ra, aoff, r0 * ldab);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[u][t] = Xb[row * ldxr + t * MM::TM];
+      for (int t = 0; t < NT; ++t) bv[u][t] = wide_ld_x(T(0), rx, xoff[t], r0 * ldxb);
     }
+    const int last = nfull - BLK;                // first row of the last full block (ring refills clamp to it)
+    for (int i = 0; i < nfull; i += BLK) {
+      int nxt = i + BLK;
+      nxt = nxt < last ? nxt : last;
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q = 0; q < VN; ++q) acc[t][q] = MM::mma(av[u][q], bv[u][t], acc[t][q]);
+          for (int q = 0; q < VN; ++q) acc[t][q] = MM::mma(av[u][q], bv[u][t], acc[t][q]);
+        // refill the step just consumed with the same step of the next block
+        const unsigned r0 = (unsigned)(nxt + u * MM::TK);
+        av[u] = wide_ld_a(T(0), ra, aoff, r0 * ldab);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[u][t] = wide_ld_x(T(0), rx, xoff[t], r0 * ldxb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
-  for (; i < i1; i += MM::TK) {                  // tail steps: rows past the slab end contribute zeros
-    const long row = i + kk;
-    const bool ok = row < i1;
-    VT a1;
-    if (ok) a1 = ld_stream(reinterpret_cast<const VT*>(Ab + row * lda));
-    else {
-#pragma unroll
-      for (int q = 0; q < VN; ++q) a1[q] = T(0);
-    }
+  for (int i = nfull; i < nrows; i += MM::TK) {  // tail steps: rows past the slab end contribute zeros
+    const bool ok = i + kk < nrows;
+    // a lane whose row lies past the end reads the panel through an out-of-range offset (the hardware returns 0)
+    // and the operator from the slab's last row (valid memory): its products vanish
+    const unsigned av_off = ok ? aoff + (unsigned)i * ldab
+                               : (unsigned)(nrows - 1) * ldab + (unsigned)(VN * mm) * (unsigned)sizeof(T);
+    const VT a1 = wide_ld_a(T(0), ra, av_off, 0u);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const T b1 = ok ? Xb[row * ldxr + t * MM::TM] : T(0);
+      const T b1 = wide_ld_x(T(0), rx, ok ? xoff[t] + (unsigned)i * ldxb : 0x7ffffff0u, 0u);
 #pragma unroll
       for (int q = 0; q < VN; ++q) acc[t][q] = MM::mma(a1[q], b1, acc[t][q]);
     }
