@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void dense_rmm_cols(
     for (int v = 0; v < VN; ++v) acc[c][v] = T(0);
   int i = i0;
   // 4 rows per step and no scheduling fence: this kernel runs 8 waves per SIMD, and an 8-row step with the
-  // loads fenced together measured 4-9 % SLOWER (6.2 vs 6.8 TB/s at P = 6) — unlike dense_mm_rows above
+  // loads fenced together measured 4-9 % SLOWER (6.2 vs 6.8 TB/s at P = 6) — unlike dense_mm_rows above.  The
+  // K1s recipe (buffer descriptor + ring of 8 rows refilled after use) is equal alone (6.73 vs 6.79 TB/s) and
+  // 3 % slower inside the eigensolver's pipeline (410 vs 397 ms per call), and spills SGPRs at P = 8.
   for (; i + 4 <= i1; i += 4) {
     V a0 = ld_stream(reinterpret_cast<const V*>(Ab + (long)(i + 0) * lda + j));
     V a1 = ld_stream(reinterpret_cast<const V*>(Ab + (long)(i + 1) * lda + j));
