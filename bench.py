@@ -189,6 +189,10 @@ def main():
                 traffic = rec.get("hbm_bytes_per_launch") * nb_launch / rec["B"]
         except Exception:
             traffic = None
+    if symm and nb_launch < b_local:
+        # two-group pipeline: the events bracket the tile kernel on the panel-product stream; its 0.11 ms fold runs
+        # on the group's own stream
+        kernel_name = "K1s xk::dense_symm_tiles (upper-triangle panel product, half-batch launch; symm_fold runs beside it)"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "kernel": kernel_name, "launches_timed": len(durs),
                 "avg_launch_ms": k1_avg * 1e3, "algorithmic_bytes_per_launch": k1_bytes,

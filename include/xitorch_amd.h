@@ -73,6 +73,18 @@ int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, l
                       int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
 int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,
                       int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+/* The two halves of the call above as separate launches (P <= 6): the tile kernel leaves per-slab / per-row-tile
+ * partial sums in `ws`, the fold adds them into Y.  The eigensolver's two-group pipeline runs the tile kernels of
+ * both groups back to back on one (CU-masked) stream and each fold on its group's own stream, off that
+ * critical path; `ws` must stay untouched between the two calls. */
+int xk_dense_symm_tiles_f64(const double* A, const double* X, double* ws, long ws_elems, int B, int N, int P,
+                            long lda, long sA, long ldx, long sX, void* stream);
+int xk_dense_symm_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
+                            long lda, long sA, long ldx, long sX, void* stream);
+int xk_dense_symm_fold_f64(double* Y, const double* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
+                           void* stream);
+int xk_dense_symm_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
+                           void* stream);
 
 /* ---- K1w: wide panels on the matrix cores (MFMA) --------------------------------------------
  * Y[b,c,n] = sum_i A[b,i,n] Xrm[b,i,c]  (= A^T X; = A X for a Hermitian operator), c < P <= 32, in ONE

@@ -71,6 +71,8 @@ def _declare(L):
         sigs["xk_dense_wide_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):
         sigs["xk_dense_symm_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
+        sigs["xk_dense_symm_tiles_" + sfx] = (I, [P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, P])
+        sigs["xk_dense_symm_fold_" + sfx] = (I, [P, P, Lg, I, I, I, Lg, Lg, P])
     for sfx in ("f64", "f32"):
         sigs["xk_banded_mm_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
         sigs["xk_kry_dots_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, P])

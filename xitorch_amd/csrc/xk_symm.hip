@@ -377,10 +377,12 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
 }
 
 #define XK_DEFINE_SYMM(SUF, T)                                                                              \
-  int xk_dense_symm_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P, long lda, \
-                          long sA, long ldx, long sX, long ldy, long sY, void* stream) {                    \
+  static int symm_launch_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P,     \
+                               long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream,       \
+                               int phase) {                                                                 \
     if (B < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                                         \
     if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
+    if (phase != 0 && P > 6) return XK_ERR_UNSUPPORTED;   /* split phases: one column chunk only */         \
     constexpr int VN = xk::Vec16<T>::n;                                                                     \
     constexpr int SLAB = 256 * VN * xk::SYMM_NU;                                                            \
     if ((N % VN) || (lda % VN) || (sA % VN) || (ldx % VN) || (sX % VN) || ((uintptr_t)A & 15) ||             \
@@ -400,17 +402,35 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
       const size_t lds = (size_t)xk::SYMM_TRH * pc * sizeof(T);                                             \
       const dim3 grid((unsigned)((long)B * nt));                                                            \
       const T* Xc = X + (long)c0 * ldx;                                                                     \
-      switch (pc) {                                                                                         \
-        XK_SYMM_CASE(1) XK_SYMM_CASE(2) XK_SYMM_CASE(3) XK_SYMM_CASE(4) XK_SYMM_CASE(5) XK_SYMM_CASE(6)     \
+      if (phase != 2) {                                                                                     \
+        switch (pc) {                                                                                       \
+          XK_SYMM_CASE(1) XK_SYMM_CASE(2) XK_SYMM_CASE(3) XK_SYMM_CASE(4) XK_SYMM_CASE(5) XK_SYMM_CASE(6)   \
+        }                                                                                                   \
+        XK_LAUNCH_CHECK();                                                                                  \
       }                                                                                                     \
-      XK_LAUNCH_CHECK();                                                                                    \
-      const long total = (long)B * pc * N;                                                                  \
-      hipLaunchKernelGGL((xk::symm_fold<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rowP, \
-                         colP, Y + (long)c0 * ldy, N, pc, NS, NT, SLAB, ldy, sY, total);                    \
-      XK_LAUNCH_CHECK();                                                                                    \
+      if (phase != 1) {                                                                                     \
+        const long total = (long)B * pc * N;                                                                \
+        hipLaunchKernelGGL((xk::symm_fold<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,     \
+                           rowP, colP, Y + (long)c0 * ldy, N, pc, NS, NT, SLAB, ldy, sY, total);            \
+        XK_LAUNCH_CHECK();                                                                                  \
+      }                                                                                                     \
       c0 += pc;                                                                                             \
     }                                                                                                       \
     return XK_OK;                                                                                           \
+  }                                                                                                         \
+  int xk_dense_symm_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P, long lda, \
+                          long sA, long ldx, long sX, long ldy, long sY, void* stream) {                    \
+    return symm_launch_##SUF(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, stream, 0);         \
+  }                                                                                                         \
+  int xk_dense_symm_tiles_##SUF(const T* A, const T* X, T* ws, long ws_elems, int B, int N, int P,          \
+                                long lda, long sA, long ldx, long sX, void* stream) {                       \
+    return symm_launch_##SUF(A, X, (T*)nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, stream, 1);  \
+  }                                                                                                         \
+  int xk_dense_symm_fold_##SUF(T* Y, const T* ws, long ws_elems, int B, int N, int P, long ldy, long sY,    \
+                               void* stream) {                                                              \
+    /* the fold never touches A or X: alignment-checked placeholders */                                     \
+    return symm_launch_##SUF((const T*)ws, (const T*)ws, Y, (T*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, \
+                             stream, 2);                                                                    \
   }
 
 #define XK_SYMM_CASE(PP)                                                                                  \

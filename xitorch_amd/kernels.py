@@ -257,6 +257,42 @@ def dense_symm(A, X, out=None):
     return out
 
 
+def dense_symm_split(A, X, out, tiles_stream):
+    """K1s with its two launches on two streams (P <= 6): the tile kernel on `tiles_stream` (after everything
+    queued so far on the current stream), the fold back on the current stream once the tiles are done.  The
+    partial-sum workspace belongs to the current stream, so callers on different streams never share one.
+    Returns (start, end) timing events of the tile kernel when `timed`."""
+    require_device(A, "operator matrix")
+    require_device(X, "panel")
+    B, P, N = X.shape
+    if P > 6:
+        raise _capi.NativeLibraryError("dense_symm_split serves panels of at most 6 columns")
+    if A.dim() == 2:
+        lda, sA = A.stride(0), 0
+    else:
+        lda, sA = A.stride(1), (A.stride(0) if A.shape[0] != 1 else 0)
+    ldx, sX = _panel_strides(X)
+    ldy, sY = _panel_strides(out)
+    esize = 8 if X.dtype == torch.float64 else 4
+    nws = fn("xk_dense_symm_workspace_elems")(B, N, P, esize)
+    cur = torch.cuda.current_stream()
+    ws = _workspace(nws, X.dtype, X.device)                 # keyed by the CURRENT (group) stream
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    sfx = suffix(X.dtype)
+    with torch.cuda.stream(tiles_stream):
+        tiles_stream.wait_event(ready)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(tiles_stream)
+        rc = fn("xk_dense_symm_tiles_" + sfx)(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, stream_ptr())
+        check(rc, "xk_dense_symm_tiles")
+        e1.record(tiles_stream)
+    cur.wait_event(e1)
+    rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, stream_ptr())
+    check(rc, "xk_dense_symm_fold")
+    return e0, e1
+
+
 # --------------------------------------------------------------------------- K1w wide panels (MFMA)
 WIDE_MIN_P = 12
 

@@ -94,6 +94,28 @@ class PanelOperator:
         out[:, :, :N].copy_(y.expand(*self.bdims, N, p).reshape(self.Bt, N, p).transpose(-2, -1))
         return out
 
+    def apply_on(self, X, out, k1_stream):
+        """out = A X with the panel product running on `k1_stream` (the two-group pipeline's CU-masked stream)
+        and the result ordered into the current stream.  For the symmetric-storage kernel only the tile kernel
+        goes to `k1_stream`; its small fold runs on the current stream, off the panel-product critical path."""
+        N = self.N
+        if self.kind == "dense" and self.symm and X.shape[1] <= 6 and not self.flip:
+            self.napply += 1
+            e0, e1 = K.dense_symm_split(self.mat, X[:, :, :N], out[:, :, :N], k1_stream)
+            if self.events is not None:
+                self.events.append((e0, e1, X.shape[1], X.shape[0]))
+            return out
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(k1_stream):
+            k1_stream.wait_event(ready)
+            self.apply(X, out)
+            done = torch.cuda.Event()
+            done.record(k1_stream)
+        cur.wait_event(done)
+        return out
+
     def _native(self, X, out, trans):
         N = self.N
         if self.kind == "dense" and self.symm and X.shape[1] < K.WIDE_MIN_P:

@@ -171,17 +171,11 @@ class _Group:
         if self.k1_stream is None:
             self.opA.apply(X, out)
             return
-        cur = torch.cuda.current_stream()
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        with torch.cuda.stream(self.k1_stream):
-            self.k1_stream.wait_event(ready)
-            end = self._mark("k1", self.k1_stream)
-            self.opA.apply(X, out)
-            end()
-            done = torch.cuda.Event()
-            done.record(self.k1_stream)
-        cur.wait_event(done)
+        n0 = len(self.opA.events) if (self.timeline is not None and self.opA.events is not None) else None
+        self.opA.apply_on(X, out, self.k1_stream)
+        if n0 is not None and len(self.opA.events) > n0:            # timeline: the launch's own events
+            e0, e1 = self.opA.events[-1][:2]
+            self.timeline.append((self.tag, "k1", e0, e1))
 
     def start(self, V0p):
         k = V0p.shape[1]
