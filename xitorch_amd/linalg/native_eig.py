@@ -16,7 +16,10 @@ product K1 is the only O(N^2) work and everything else is an O(k N) stream:
   * the full CholeskyQR of [V, t] (tallqr, _utils/tensor.py:8-19) becomes block Gram–Schmidt of
     the new panel against the (already orthonormal) basis + CholeskyQR of the panel alone — in
     exact arithmetic the same Q, since chol([[I, C],[C^T, G]]) = [[I, C],[0, chol(G - C^T C)]];
-  * one host sync per iteration (the reference has three: symeig.py:196,200,202).
+  * one host sync per iteration and batch group (the reference has three: symeig.py:196,200,202);
+  * large batches of native dense operators run as two groups: the panel products of both groups back to back on
+    one CU-masked stream, each group's small kernels on its own hardware queue underneath the other group's
+    panel product (option `overlap`).
 
 All numerics run in libxitorch_amd.so (xk_dense_mm, xk_lincomb, xk_ritz_residual,
 xk_panel_chol, xk_panel_transform); the only library call is the small k x k `eigh` of T.
