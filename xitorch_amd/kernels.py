@@ -261,7 +261,7 @@ def dense_symm_split(A, X, out, tiles_stream):
     """K1s with its two launches on two streams (P <= 6): the tile kernel on `tiles_stream` (after everything
     queued so far on the current stream), the fold back on the current stream once the tiles are done.  The
     partial-sum workspace belongs to the current stream, so callers on different streams never share one.
-    Returns (start, end) timing events of the tile kernel when `timed`."""
+    Returns the (start, end) timing events recorded around the tile kernel."""
     require_device(A, "operator matrix")
     require_device(X, "panel")
     B, P, N = X.shape
