@@ -28,6 +28,9 @@ def test_library_exports_every_declared_symbol():
     assert _capi.fn("xk_abi_version")() >= 1
     assert _capi.fn("xk_kry_max_partials")() == 64
     assert _capi.fn("xk_dense_mm_workspace_elems")(4, 16, 16, 2, 0) == 0
+    # every declared entry point has a ctypes signature (argument conversion is never left to defaults)
+    untyped = [s for s in syms if getattr(L, s).argtypes is None]
+    assert not untyped, untyped
 
 
 def test_native_paths_refuse_cpu_tensors():
