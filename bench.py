@@ -94,6 +94,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    if args.gpus != world:
+        # one process per GPU: N > 1 means `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch it with torch.distributed.run "
+                         "(one rank per GPU)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
