@@ -29,6 +29,11 @@ DAVIDSON_CASES = [
     dict(name="s1_1024_b1_lowest6", kind="S1", n=1024, batch=(1,), neig=6, mode="lowest", min_eps=1e-8),
     # config 1 of BASELINE.json: benchmarks_solve.py shape family, N=512, lowest 6
     dict(name="c1_rand512_lowest6", kind="randsym", n=512, batch=(), neig=6, mode="lowest", min_eps=1e-8),
+    # generalised problem A x = lam M x (M-orthonormal basis, symeig.py:183-185,216-218).  (v_init="eye" is not
+    # pinned: on these operators the reference's own CholeskyQR of the basis fails — its residual blocks become
+    # linearly dependent — so there is no reference output to compare with.)
+    dict(name="genM_120_b2_lowest3", kind="gen", n=120, batch=(2,), neig=3, mode="lowest", min_eps=1e-8, M=True),
+    dict(name="genM_90_b2_uppest2", kind="gen", n=90, batch=(2,), neig=2, mode="uppest", min_eps=1e-8, M=True),
 ]
 
 
@@ -59,7 +64,21 @@ def davidson_matrix(case):
         return syn.dense_symmetric(batch[0], n, kind)
     if kind == "randsym":
         return random_symmetric(n, -1.0, 1.0, 123)
+    if kind == "gen":
+        g = torch.Generator().manual_seed(3 + n)
+        R = torch.rand((*batch, n, n), dtype=f64, generator=g)
+        return (R + R.transpose(-2, -1)) * 0.5 + torch.diag(torch.arange(n, dtype=f64) * 0.5)
     raise ValueError(kind)
+
+
+def davidson_M(case):
+    """SPD overlap matrix of the generalised cases (None otherwise)."""
+    if not case.get("M"):
+        return None
+    n, batch = case["n"], tuple(case["batch"])
+    g = torch.Generator().manual_seed(77 + n)
+    R2 = torch.rand((*batch, n, n), dtype=f64, generator=g)
+    return 0.02 * (R2 + R2.transpose(-2, -1)) + torch.eye(n, dtype=f64)
 
 
 # ------------------------------------------------------------------ linear-solver cases
@@ -78,6 +97,14 @@ SOLVE_CASES = [
          kwargs=dict(rtol=1e-8, posdef=True)),
     dict(name="bicgstab_nonsym_AE", method="bicgstab", op="dense", hermitian=False, n=80, batch=(2,), ncols=3,
          E=True, kwargs=dict(rtol=1e-8, posdef=True)),
+    # preconditioned loops (solve.py:73,121-122,136,170 and :196-197,247-249,277,283): Jacobi preconditioner of a
+    # matrix with a spread diagonal
+    dict(name="cg_sym120_jacobi", method="cg", op="dense", hermitian=True, n=120, batch=(2,), ncols=2, spread=True,
+         precond=("precond",), kwargs=dict(rtol=1e-10, posdef=True)),
+    dict(name="bicgstab_nonsym120_jacobi_r", method="bicgstab", op="dense", hermitian=False, n=120, batch=(2,),
+         ncols=2, spread=True, precond=("precond_r",), kwargs=dict(rtol=1e-10, posdef=True)),
+    dict(name="bicgstab_nonsym120_jacobi_l", method="bicgstab", op="dense", hermitian=False, n=120, batch=(2,),
+         ncols=2, spread=True, precond=("precond_l",), kwargs=dict(rtol=1e-10, posdef=True)),
 ]
 
 
@@ -90,7 +117,8 @@ def solve_inputs(case):
         B = syn.banded_apply_reference(A, xs)
     else:
         R = torch.rand((*batch, n, n), dtype=f64, generator=g)
-        A = 0.1 * R + torch.eye(n, dtype=f64)
+        A = 0.1 * R + (torch.diag(torch.linspace(1.0, 50.0, n, dtype=f64)) if case.get("spread")
+                       else torch.eye(n, dtype=f64))
         if case["hermitian"]:
             A = (A + A.transpose(-2, -1)) * 0.5
         B = torch.rand((*batch, n, nc), dtype=f64, generator=g)
@@ -101,6 +129,15 @@ def solve_inputs(case):
         R2 = torch.rand((*batch, n, n), dtype=f64, generator=g)
         M = 0.05 * (R2 + R2.transpose(-2, -1)) * 0.5 + torch.eye(n, dtype=f64)
     return A, B, E, M
+
+
+def solve_precond(case, A):
+    """kwarg name -> dense matrix diag(A)^-1 for the cases that run with a (Jacobi) preconditioner."""
+    names = case.get("precond", ())
+    if not names:
+        return {}
+    P = torch.diag_embed(1.0 / A.diagonal(dim1=-2, dim2=-1))
+    return {k: P for k in names}
 
 
 # ------------------------------------------------------------------ root-finder cases

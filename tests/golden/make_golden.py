@@ -84,19 +84,23 @@ def gen_davidson():
     for case in cases.DAVIDSON_CASES:
         name = case["name"]
         mat = cases.davidson_matrix(case)
+        Mmat = cases.davidson_M(case)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             rop = CountingRefOp(xitorch.LinearOperator.m(mat, is_hermitian=True))
-        kw = dict(max_niter=case.get("max_niter", 1000), min_eps=case["min_eps"], v_init="randn")
-        ev_r, X_r = ref_symeig.davidson(rop, case["neig"], case["mode"], None, **kw)
+            rM = xitorch.LinearOperator.m(Mmat, is_hermitian=True) if Mmat is not None else None
+        kw = dict(max_niter=case.get("max_niter", 1000), min_eps=case["min_eps"], v_init=case.get("v_init", "randn"))
+        ev_r, X_r = ref_symeig.davidson(rop, case["neig"], case["mode"], rM, **kw)
         tr = {}
         oop = oops.DenseOp(mat, is_hermitian=True)
-        ev_o, X_o = osym.davidson(oop, case["neig"], case["mode"], None, trace=tr, **kw)
+        oM = oops.DenseOp(Mmat, is_hermitian=True) if Mmat is not None else None
+        ev_o, X_o = osym.davidson(oop, case["neig"], case["mode"], oM, trace=tr, **kw)
         exact(ev_r, ev_o, name + " evals")
         exact(X_r, X_o, name + " evecs")
         assert tr["napply"] == rop.n, (tr["napply"], rop.n)
-        ev_x, _ = ref_symeig.exacteig(xitorch.LinearOperator.m(mat, is_hermitian=True), case["neig"], case["mode"], None)
-        resid = (torch.matmul(mat, X_r) - X_r * ev_r.unsqueeze(-2)).abs().max()
+        ev_x, _ = ref_symeig.exacteig(xitorch.LinearOperator.m(mat, is_hermitian=True), case["neig"], case["mode"], rM)
+        MX = torch.matmul(Mmat, X_r) if Mmat is not None else X_r
+        resid = (torch.matmul(mat, X_r) - MX * ev_r.unsqueeze(-2)).abs().max()
         # store evecs only through a sign-free, small summary: |X|^T at a few probe rows
         probe = cases.probe_rows(mat.shape[-1])
         save("davidson_" + name, evals=ev_r, evals_exact=ev_x, napply=rop.n, niter=tr["niter"],
@@ -121,13 +125,16 @@ def gen_solve():
             rM = xitorch.LinearOperator.m(M, is_hermitian=True) if M is not None else None
             oM = oops.DenseOp(M, is_hermitian=True) if M is not None else None
         kw = dict(case["kwargs"])
+        pre = cases.solve_precond(case, A) if case["op"] != "banded" else {}
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
+            kw_r = dict(kw, **{k: xitorch.LinearOperator.m(P, is_hermitian=True) for k, P in pre.items()})
+            kw_o = dict(kw, **{k: oops.DenseOp(P, is_hermitian=True) for k, P in pre.items()})
             fr = getattr(ref_solve, case["method"])
             fo = getattr(osolve, case["method"])
-            X_r = fr(rA, B, E, rM, **kw)
+            X_r = fr(rA, B, E, rM, **kw_r)
             tr = {}
-            X_o = fo(oA, B, E, oM, trace=tr, **kw)
+            X_o = fo(oA, B, E, oM, trace=tr, **kw_o)
         exact(X_r, X_o, name)
         assert oA.n_apply == rA.n, (name, oA.n_apply, rA.n)
         X_x = osolve.exactsolve(oA, B, E, oM) if case["method"] != "gmres" or E is None else X_r

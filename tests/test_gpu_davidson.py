@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _check_pairs(mat, evals, evecs, ref_evals, min_eps, exact_evals=None):
+def _check_pairs(mat, evals, evecs, ref_evals, min_eps, exact_evals=None, Mmat=None):
     # eigenvalues: 1e-10 (north_star tolerance), ascending order identical
     scale = max(1.0, float(np.abs(ref_evals).max()))
     assert np.all(np.diff(evals, axis=-1) >= -1e-12), "eigenvalues must be ascending"
@@ -22,10 +22,11 @@ def _check_pairs(mat, evals, evecs, ref_evals, min_eps, exact_evals=None):
         assert np.abs(evals - exact_evals).max() <= 1e-10 * scale
     # residual identity A X = X E (reference test style, test_linop_fcns.py:174-176)
     X = torch.from_numpy(evecs)
-    R = torch.matmul(mat, X) - X * torch.from_numpy(evals).unsqueeze(-2)
+    MX = torch.matmul(Mmat, X) if Mmat is not None else X
+    R = torch.matmul(mat, X) - MX * torch.from_numpy(evals).unsqueeze(-2)
     assert R.abs().max().item() <= 10 * min_eps
-    # orthonormality
-    G = torch.matmul(X.transpose(-2, -1), X)
+    # (M-)orthonormality
+    G = torch.matmul(X.transpose(-2, -1), MX)
     assert (G - torch.eye(G.shape[-1], dtype=G.dtype)).abs().max().item() < 1e-9
 
 
@@ -33,12 +34,14 @@ def _check_pairs(mat, evals, evecs, ref_evals, min_eps, exact_evals=None):
 def test_davidson_vs_golden_and_oracle(dev, case):
     gold = np.load(os.path.join(GOLD, "davidson_%s.npz" % case["name"]))
     mat = cases.davidson_matrix(case)
+    Mmat = cases.davidson_M(case)
     A = xa.LinearOperator.m(mat.to(dev), is_hermitian=True)
+    Mop = xa.LinearOperator.m(Mmat.to(dev), is_hermitian=True) if Mmat is not None else None
     tr = {}
-    evals, evecs = davidson(A, case["neig"], case["mode"], None, min_eps=case["min_eps"], v_init="randn", trace=tr)
+    evals, evecs = davidson(A, case["neig"], case["mode"], Mop, min_eps=case["min_eps"], v_init="randn", trace=tr)
     evals, evecs = evals.cpu().numpy(), evecs.cpu().numpy()
     assert evals.shape == gold["evals"].shape
-    _check_pairs(mat, evals, evecs, gold["evals"], case["min_eps"], gold["evals_exact"])
+    _check_pairs(mat, evals, evecs, gold["evals"], case["min_eps"], gold["evals_exact"], Mmat)
     # same iteration path as the reference: same start block, same algorithm -> same count (+-2 for
     # rounding-level differences in the stopping test)
     assert abs(tr["niter"] - int(gold["niter"])) <= 2, (tr["niter"], int(gold["niter"]))
@@ -49,7 +52,8 @@ def test_davidson_vs_golden_and_oracle(dev, case):
         assert np.abs(np.abs(evecs[..., probe, :]) - gold["absX_probe"]).max() < 1e-6
     # the live oracle on the same inputs agrees with the fixture (oracle is the checker)
     tr_o = {}
-    ev_o, _ = osym.davidson(oops.DenseOp(mat, True), case["neig"], case["mode"], None, min_eps=case["min_eps"], trace=tr_o)
+    oM = oops.DenseOp(Mmat, True) if Mmat is not None else None
+    ev_o, _ = osym.davidson(oops.DenseOp(mat, True), case["neig"], case["mode"], oM, min_eps=case["min_eps"], trace=tr_o)
     assert np.abs(ev_o.numpy() - gold["evals"]).max() <= 1e-12 * max(1.0, np.abs(gold["evals"]).max())
 
 

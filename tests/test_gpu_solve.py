@@ -45,10 +45,12 @@ def test_krylov_vs_golden_and_oracle(dev, case):
     A, B, E, M = cases.solve_inputs(case)
     Aop, Mop, oA = _operators(case, A, M, dev)
     fcn = getattr(nk, case["method"])
+    pre = {k: xa.LinearOperator.m(P.to(dev), is_hermitian=True) for k, P in cases.solve_precond(case, A).items()} \
+        if case["op"] != "banded" else {}
     tr = {}
     with warnings.catch_warnings():
         warnings.simplefilter("error")                   # a ConvergenceWarning would be a failure here
-        X = fcn(Aop, B.to(dev), E.to(dev) if E is not None else None, Mop, trace=tr, **case["kwargs"])
+        X = fcn(Aop, B.to(dev), E.to(dev) if E is not None else None, Mop, trace=tr, **case["kwargs"], **pre)
     X = X.cpu()
     assert list(X.shape) == list(gold["X"].shape)
     # (1) the residual identity the reference tests assert (test_linop_fcns.py:467-468, 674-676)

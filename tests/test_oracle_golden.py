@@ -20,13 +20,16 @@ FAST_DAVIDSON = [c for c in cases.DAVIDSON_CASES if c["n"] <= 600 or c["kind"] !
 def test_oracle_davidson(case):
     gold = np.load(os.path.join(GOLD, "davidson_%s.npz" % case["name"]))
     mat = cases.davidson_matrix(case)
+    Mmat = cases.davidson_M(case)
+    oM = oops.DenseOp(Mmat, True) if Mmat is not None else None
     tr = {}
-    ev, X = osym.davidson(oops.DenseOp(mat, True), case["neig"], case["mode"], min_eps=case["min_eps"], trace=tr)
+    ev, X = osym.davidson(oops.DenseOp(mat, True), case["neig"], case["mode"], oM, min_eps=case["min_eps"], trace=tr)
     scale = max(1.0, np.abs(gold["evals"]).max())
     assert np.abs(ev.numpy() - gold["evals"]).max() <= 1e-11 * scale
     assert np.abs(ev.numpy() - gold["evals_exact"]).max() <= 1e-10 * scale
     assert abs(tr["niter"] - int(gold["niter"])) <= 1       # bit-equal on the generating machine
-    assert (torch.matmul(mat, X) - X * ev.unsqueeze(-2)).abs().max().item() <= 10 * case["min_eps"]
+    MX = torch.matmul(Mmat, X) if Mmat is not None else X
+    assert (torch.matmul(mat, X) - MX * ev.unsqueeze(-2)).abs().max().item() <= 10 * case["min_eps"]
 
 
 @pytest.mark.parametrize("case", cases.SOLVE_CASES, ids=[c["name"] for c in cases.SOLVE_CASES])
@@ -36,10 +39,11 @@ def test_oracle_solve(case):
     oA = oops.DenseOp(oops.BandedOp(A).fullmatrix(), False) if case["op"] == "banded" else \
         oops.DenseOp(A, case["hermitian"])
     oM = oops.DenseOp(M, True) if M is not None else None
+    pre = {k: oops.DenseOp(P, True) for k, P in cases.solve_precond(case, A).items()} if case["op"] != "banded" else {}
     tr = {}
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        X = getattr(osolve, case["method"])(oA, B, E, oM, trace=tr, **case["kwargs"])
+        X = getattr(osolve, case["method"])(oA, B, E, oM, trace=tr, **case["kwargs"], **pre)
     assert np.abs(X.numpy() - gold["X"]).max() <= 1e-9 * max(1.0, np.abs(gold["X"]).max())
     assert abs(tr["niter"] - int(gold["niter"])) <= 1
 
