@@ -204,6 +204,46 @@ def nonlin_solve(fcn, x0, params, jacobian, maxiter=None, f_tol=None, f_rtol=Non
     return x.reshape(xshape)
 
 
+class BroydenSecond(BroydenFirst):
+    """reference: BroydenSecond, _jacobian.py:120-137 ("bad" Broyden: v = dy, d = dy / |dy|^2)."""
+
+    def update(self, x, y):
+        dy = y - self.y_prev
+        dx = x - self.x_prev
+        dynorm = dy.norm()
+        self.Gm.reduce(self.max_rank)
+        c = dx - self.Gm.mv(dy)
+        d = dy / (dynorm * dynorm)
+        self.Gm.append(c, d)
+        self.y_prev, self.x_prev = y, x
+
+
+class LinearMixing:
+    """reference: LinearMixing, _jacobian.py:139-154: the inverse Jacobian is the constant -alpha*I."""
+
+    def __init__(self, alpha=None):
+        self.alpha = -1.0 if alpha is None else alpha
+
+    def setup(self, x0, y0, func):
+        pass
+
+    def solve(self, v, tol=0):
+        return -v * self.alpha
+
+    def update(self, x, y):
+        pass
+
+
 def broyden1(fcn, x0, params=(), alpha=None, uv0=None, max_rank=None, **kwargs):
     """reference: broyden1, rootsolver.py:176-206."""
     return nonlin_solve(fcn, x0, params, BroydenFirst(alpha=alpha, uv0=uv0, max_rank=max_rank), **kwargs)
+
+
+def broyden2(fcn, x0, params=(), alpha=None, uv0=None, max_rank=None, **kwargs):
+    """reference: broyden2, rootsolver.py:209-238."""
+    return nonlin_solve(fcn, x0, params, BroydenSecond(alpha=alpha, uv0=uv0, max_rank=max_rank), **kwargs)
+
+
+def linearmixing(fcn, x0, params=(), alpha=None, **kwargs):
+    """reference: linearmixing, rootsolver.py:241-256."""
+    return nonlin_solve(fcn, x0, params, LinearMixing(alpha=alpha), **kwargs)

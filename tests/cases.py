@@ -155,6 +155,11 @@ ROOT_CASES = [
     dict(name="readme2", kind="readme", grad=True, kwargs=dict()),
     dict(name="tanh_b4_n64", kind="tanh", nbatch=4, n=64, kwargs=dict(alpha=-1.0, max_rank=None, f_tol=1e-8)),
     dict(name="tanh_b3_n96_rank8", kind="tanh", nbatch=3, n=96, kwargs=dict(alpha=-1.0, max_rank=8, f_tol=1e-8)),
+    # the other quasi-Newton models of the reference (rootsolver.py:209-256, _jacobian.py:120-154)
+    dict(name="tanh_b3_n64_broyden2", kind="tanh", nbatch=3, n=64, method="broyden2",
+         kwargs=dict(alpha=-1.0, max_rank=None, f_tol=1e-8)),
+    dict(name="tanh_b2_n48_linearmixing", kind="tanh", nbatch=2, n=48, method="linearmixing",
+         kwargs=dict(alpha=-1.0, f_tol=1e-8, maxiter=400)),
 ]
 
 

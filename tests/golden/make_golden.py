@@ -154,9 +154,10 @@ def gen_root():
             def cfcn(y, *p):
                 nfev_r[0] += 1
                 return fcn(y, *p)
-            y_r = ref_root.broyden1(cfcn, y0, params, **kw)
+            meth = case.get("method", "broyden1")
+            y_r = getattr(ref_root, meth)(cfcn, y0, params, **kw)
             tr = {}
-            y_o = oroot.broyden1(fcn, y0, params, trace=tr, **kw)
+            y_o = getattr(oroot, meth)(fcn, y0, params, trace=tr, **kw)
         exact(y_r, y_o, name)
         assert tr["nfev"] == nfev_r[0], (name, tr["nfev"], nfev_r[0])
         out = dict(y=y_r, nfev=nfev_r[0], niter=tr["niter"], fnorm=fcn(y_r, *params).norm())

@@ -18,7 +18,8 @@ def test_broyden1_vs_golden_and_oracle(dev, case):
     gold = np.load(os.path.join(GOLD, "root_%s.npz" % case["name"]))
     fcn, y0, params = cases.root_inputs(case)
     tr = {}
-    y = nr.broyden1(fcn, y0.to(dev), tuple(p.to(dev) for p in params), trace=tr, **case["kwargs"])
+    meth = case.get("method", "broyden1")
+    y = getattr(nr, meth)(fcn, y0.to(dev), tuple(p.to(dev) for p in params), trace=tr, **case["kwargs"])
     yg = torch.from_numpy(gold["y"])
     assert list(y.shape) == list(yg.shape)
     # same iterate as the reference (it returns the iterate BEFORE the converged one, quirk Q1)
@@ -26,7 +27,7 @@ def test_broyden1_vs_golden_and_oracle(dev, case):
     assert tr["nfev"] == int(gold["nfev"]) and tr["niter"] == int(gold["niter"])
     assert abs(fcn(y.cpu(), *params).norm().item() - float(gold["fnorm"])) <= 1e-9
     # live oracle agrees too
-    yo = oroot.broyden1(fcn, y0, params, **case["kwargs"])
+    yo = getattr(oroot, meth)(fcn, y0, params, **case["kwargs"])
     assert (y.cpu() - yo).abs().max().item() <= 1e-8
 
 

@@ -53,7 +53,7 @@ def test_oracle_root(case):
     gold = np.load(os.path.join(GOLD, "root_%s.npz" % case["name"]))
     fcn, y0, params = cases.root_inputs(case)
     tr = {}
-    y = oroot.broyden1(fcn, y0, params, trace=tr, **case["kwargs"])
+    y = getattr(oroot, case.get("method", "broyden1"))(fcn, y0, params, trace=tr, **case["kwargs"])
     assert np.abs(y.numpy() - gold["y"]).max() <= 1e-10
     assert tr["nfev"] == int(gold["nfev"])
 
