@@ -7,6 +7,7 @@ view, xitorch/_utils/tensor.py:21-32, seen as its transpose).
 import torch
 from xitorch_amd import _capi
 from xitorch_amd._capi import ptr, stream_ptr, check, suffix, fn, require_device
+from ctypes import c_void_p as c_void_p_
 
 __all__ = ["dense_mm"]
 
@@ -227,8 +228,23 @@ def masked_stream(device, reserve_cus=64, slot=0):
         out = ctypes.c_void_p()
         rc = fn("xk_stream_create_cu_masked")(key[0], key[1], ctypes.byref(out))
         check(rc, "xk_stream_create_cu_masked")
+        if not _MASKED_STREAMS:
+            import atexit
+            atexit.register(_destroy_masked_streams)
         _MASKED_STREAMS[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key[0]))
     return _MASKED_STREAMS[key]
+
+
+def _destroy_masked_streams():
+    """The streams live as long as the process; hand them back before the HIP runtime (and any profiler layered
+    on it) tears down — rocprofv3 otherwise crashes at exit on streams it still tracks."""
+    for key, st in list(_MASKED_STREAMS.items()):
+        try:
+            st.synchronize()
+            fn("xk_stream_destroy")(c_void_p_(st.cuda_stream))
+        except Exception:
+            pass
+    _MASKED_STREAMS.clear()
 
 
 # --------------------------------------------------------------------------- K1s symmetric storage
