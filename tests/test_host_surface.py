@@ -2,6 +2,7 @@
 table, the backward formulas (exact methods on CPU tensors, gradcheck) and the closed-form inputs.
 Modelled on the reference's xitorch/_tests/test_linop.py, test_linop_fcns.py, test_optimize.py."""
 import ctypes
+import os
 import warnings
 import pytest
 import torch
@@ -367,3 +368,38 @@ def test_equilibrium_and_minimize_on_cpu_methods():
         assert torch.allclose(ym, torch.full_like(ym, 1.5), atol=1e-4), method
     with pytest.raises(RuntimeError, match="Unknown"):
         minimize(quad, y0, params=(A,), method="nope")
+
+
+def test_header_is_plain_c_and_usable_from_c(tmp_path):
+    # the boundary is a C ABI: the header must compile as C99 and a C program must be able to bind the library
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = _capi.HEADER_PATH
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "bind.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <dlfcn.h>
+#include "xitorch_amd.h"
+typedef int (*abi_fn)(void);
+typedef long (*ws_fn)(int, int, int, int);
+int main(int argc, char** argv) {
+  void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+  if (!h) { fprintf(stderr, "%s\n", dlerror()); return 2; }
+  abi_fn abi = (abi_fn)dlsym(h, "xk_abi_version");
+  ws_fn ws = (ws_fn)dlsym(h, "xk_dense_symm_workspace_elems");
+  if (!abi || !ws) return 3;
+  /* prototypes from the header and the exported symbols agree in arity/types at least for these two */
+  printf("%d %ld\n", abi(), ws(2, 2048, 6, 8));
+  (void)argc;
+  return 0;
+}
+''')
+    exe = tmp_path / "bind"
+    subprocess.check_call([gcc, "-std=gnu99", "-I", os.path.dirname(hdr), str(src), "-o", str(exe), "-ldl"])
+    out = subprocess.check_output([str(exe), _capi.LIB_PATH]).decode().split()
+    assert int(out[0]) >= 1
+    assert int(out[1]) == 2 * (2 + 2) * 6 * 2048          # (NS + NT) slots of P x N per batch member
