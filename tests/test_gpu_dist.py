@@ -1,4 +1,4 @@
-"""-m gpu: the sharded eigensolver with a REAL process group — two processes on the one GPU of the test box
+"""-m gpu: the sharded solvers with a REAL process group — two processes on the one GPU of the test box
 (gloo backend: RCCL refuses two ranks on one device; the code path in davidson is the same all-reduce MAX).
 Each rank owns half of the batch; the iteration count, eigenvalues and residuals must equal the unsharded run,
 with and without the two-group pipeline."""
@@ -46,6 +46,37 @@ def _worker(rank, world, port, results):
             out[overlap] = dict(niter=(tr_s["niter"], tr_f["niter"]), groups=tr_s["groups"],
                                 err=(ev_s - ev_f[lo:hi]).abs().max().item(), resid=R.abs().max().item(),
                                 hist=max(abs(a - b) for a, b in zip(tr_s["resid_history"], tr_f["resid_history"])))
+        # ---- sharded Krylov solves and the sharded Broyden driver (same process group) ----------------
+        from xitorch_amd.linalg import native_krylov as nk
+        from xitorch_amd.optimize import native_root as nr
+        from tests import cases
+        g = torch.Generator().manual_seed(21)
+        nb, n = 4, 256
+        R = torch.rand(nb, n, n, dtype=torch.float64, generator=g)
+        Amat = (0.1 * R + torch.diag(torch.linspace(1.0, 4.0, n, dtype=torch.float64))).to(dev)
+        Amat = Amat * torch.linspace(1.0, 3.0, nb, dtype=torch.float64, device=dev).reshape(nb, 1, 1)
+        Bm = torch.rand(nb, n, 2, dtype=torch.float64, generator=g).to(dev)
+        l2, h2 = xd.shard_range(nb, world, rank)
+        kry = {}
+        for meth in ("bicgstab", "cg", "gmres"):
+            herm = meth == "cg"
+            Am = (Amat + Amat.transpose(-2, -1)) * 0.5 if herm else Amat
+            kw = dict(rtol=1e-10, atol=1e-12, posdef=True)
+            if meth == "gmres":
+                kw["max_niter"] = 80
+            tf, ts = {}, {}
+            Xf = getattr(nk, meth)(xa.LinearOperator.m(Am, herm), Bm, trace=tf, **kw)
+            Xs = getattr(nk, meth)(xa.LinearOperator.m(Am[l2:h2].contiguous(), herm), Bm[l2:h2].contiguous(), trace=ts,
+                                   process_group=dist.group.WORLD, **kw)
+            kry[meth] = dict(niter=(ts["niter"], tf["niter"]), err=(Xs - Xf[l2:h2]).abs().max().item())
+        out["krylov"] = kry
+        fcn, y0, (Ar,) = cases.root_inputs(dict(kind="tanh", nbatch=4, n=64))
+        tf, ts = {}, {}
+        yf = nr.broyden1(fcn, y0.to(dev), (Ar.to(dev),), alpha=-1.0, f_tol=1e-9, trace=tf)
+        ys = nr.broyden1(fcn, y0[l2:h2].to(dev), (Ar[l2:h2].to(dev),), alpha=-1.0, f_tol=1e-9, trace=ts,
+                         process_group=dist.group.WORLD)
+        out["broyden"] = dict(niter=(ts["niter"], tf["niter"]), nfev=(ts["nfev"], tf["nfev"]),
+                              err=(ys - yf[l2:h2]).abs().max().item())
         results[rank] = out
     finally:
         dist.destroy_process_group()
@@ -72,3 +103,8 @@ def test_sharded_davidson_two_ranks_one_gpu():
             assert r["groups"] == (2 if overlap else 1)
             assert r["err"] < 1e-10 * 160 and r["resid"] < 1e-7, r
             assert r["hist"] < 1e-6, r                           # the all-reduced residual IS the global one
+        for meth, r in results[rank]["krylov"].items():
+            assert r["niter"][0] == r["niter"][1], (meth, r)      # global stopping / best-iterate decisions
+            assert r["err"] < 1e-9, (meth, r)
+        r = results[rank]["broyden"]                              # the whole batch is ONE flat system (Q4)
+        assert r["niter"][0] == r["niter"][1] and r["nfev"][0] == r["nfev"][1] and r["err"] < 1e-9, r
