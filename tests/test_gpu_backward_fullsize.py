@@ -158,3 +158,62 @@ def test_no_device_memory_growth(dev):
     torch.cuda.synchronize()
     after = torch.cuda.memory_allocated()
     assert after - before <= 1 << 20, (before, after)
+
+
+@pytest.mark.timeout(600)
+def test_fullsize_config5_shard_fp32_symeig(dev):
+    """Per-GPU shard of BASELINE configs[4] (16 x 32768^2 fp32 = 68.7 GB): fp32 kernels end to end, eigenvalues
+    against the exact closed-form spectrum at fp32 accuracy, residual identity."""
+    B, N, p = 16, 32768, 6
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80e9:
+        pytest.skip("needs ~70 GB of free HBM")
+    mat = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    syn.dense_symmetric(B, N, "S1", dtype=torch.float32, device=dev, out=mat)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    tr = {}
+    with torch.no_grad():
+        ev, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=2e-3, rng_device="device", max_niter=60,
+                       trace=tr)
+    assert ev.dtype == torch.float32 and tr["stop_reason"] == "converged" and tr["groups"] == 2
+    exact = syn.spectrum("S1", N, device=dev)[:p]
+    assert (ev.double() - exact).abs().max().item() <= 5e-4
+    Xp = X.transpose(-2, -1).contiguous()
+    AX = K.dense_mm(mat, Xp)
+    assert (AX - Xp * ev.unsqueeze(-1)).abs().max().item() <= 2e-2
+    del mat
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(600)
+def test_fullsize_config4_shard_rootfinder_backward(dev):
+    """Per-GPU shard of BASELINE configs[3] (64 x 8192^2 fp64, f(y) = tanh(A y + 0.1) + y/2): the root, and the
+    implicit gradient of sum(y) w.r.t. A checked against a finite difference along a random direction."""
+    from xitorch_amd.optimize import rootfinder
+    B, N = 64, 8192
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs ~180 GB of free HBM")
+    A = syn.root_matrix(B, N, device=dev) * 2.0
+    y0 = torch.zeros(B, N, dtype=f64, device=dev)
+
+    def fcn(y, A_):
+        return torch.tanh(xa.LinearOperator.m(A_, is_hermitian=False).mv(y) + 0.1) + y / 2.0
+    kw = dict(method="broyden1", alpha=-1.0, max_rank=32, f_tol=1e-10)
+    Ad = A.clone().requires_grad_()
+    y = rootfinder(fcn, y0, params=(Ad,), bck_options=dict(method="bicgstab", posdef=True, rtol=1e-10), **kw)
+    with torch.no_grad():
+        assert fcn(y, A).abs().max().item() < 1e-8
+    g, = torch.autograd.grad(y.sum(), (Ad,))
+    assert torch.isfinite(g).all()
+    # directional derivative: d/de sum(y(A + e D)) at e = 0 equals <g, D>
+    D = torch.empty_like(A).uniform_(-1.0, 1.0, generator=torch.Generator(device=dev).manual_seed(3)) / N
+    eps = 1e-4
+    with torch.no_grad():
+        yp = rootfinder(fcn, y0, params=(A + eps * D,), **kw)
+        ym = rootfinder(fcn, y0, params=(A - eps * D,), **kw)
+    fd = ((yp.sum() - ym.sum()) / (2 * eps)).item()
+    an = (g * D).sum().item()
+    assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)), (fd, an)
+    del A, Ad, g, D
+    torch.cuda.empty_cache()
