@@ -155,3 +155,35 @@ def test_preconditioned_cg_and_bicgstab(dev):
         assert torch.allclose(x, torch.linalg.solve(Agen, Bm), rtol=1e-7, atol=1e-9), kw
     with pytest.raises(TypeError):
         nk.cg(xa.LinearOperator.m(Asym, True), Bm, precond=torch.eye(n))
+
+
+def test_many_rhs_nonhermitian_goes_through_the_mfma_kernel(dev):
+    # 20 right-hand sides, general dense A: the panel product A X runs on K1w over a transposed copy made once
+    # per solve (the VALU rows kernel would need 3 passes over A per apply); results vs the dense solution
+    from xitorch_amd.linalg._panel import PanelOperator
+    g = torch.Generator().manual_seed(13)
+    B, n, nc = 2, 256, 20
+    R = torch.rand(B, n, n, dtype=torch.float64, generator=g)
+    A = (0.1 * R + torch.diag(torch.linspace(1.0, 3.0, n, dtype=torch.float64))).to(dev)
+    Bm = torch.rand(B, n, nc, dtype=torch.float64, generator=g).to(dev)
+    op = PanelOperator(xa.LinearOperator.m(A, is_hermitian=False), [B], B, n)
+    X = Bm.transpose(-2, -1).contiguous()                       # (B, nc, n) panel
+    out = torch.empty_like(X)
+    op.apply(X, out)
+    assert getattr(op, "_matT", None) is not None               # the transposed copy exists -> K1w path
+    ref = torch.matmul(A, Bm).transpose(-2, -1)
+    assert (out - ref).abs().max().item() <= 1e-12 * ref.abs().max().item() * n ** 0.5
+    op.apply(X, out, trans=True)                                # A^T X: K1w directly
+    refT = torch.matmul(A.transpose(-2, -1), Bm).transpose(-2, -1)
+    assert (out - refT).abs().max().item() <= 1e-12 * refT.abs().max().item() * n ** 0.5
+    x = nk.bicgstab(xa.LinearOperator.m(A, is_hermitian=False), Bm, rtol=1e-11, atol=1e-13, posdef=True)
+    assert torch.allclose(x, torch.linalg.solve(A, Bm), rtol=1e-8, atol=1e-10)
+    # float32, ragged size: falls back to the generic kernels where K1w's tile constraints do not hold
+    A32 = A[:, :250, :250].float().contiguous()
+    B32 = Bm[:, :250, :16].float().contiguous()
+    op32 = PanelOperator(xa.LinearOperator.m(A32, is_hermitian=False), [B], B, 250)
+    X32 = B32.transpose(-2, -1).contiguous()
+    o32 = torch.empty_like(X32)
+    op32.apply(X32, o32)
+    r32 = torch.matmul(A32.double(), B32.double()).transpose(-2, -1)
+    assert (o32.double() - r32).abs().max().item() <= 3e-5 * r32.abs().max().item()
