@@ -20,5 +20,5 @@ Modules
   oracle.ops        operator stand-ins (dense / banded / callable)  -> linop.py
   oracle.symeig     tallqr, initial guess, block Davidson           -> _impls/linalg/symeig.py
   oracle.solve      cg, bicgstab, gmres + problem set-up            -> _impls/linalg/solve.py
-  oracle.rootfinder quasi-Newton driver, Broyden-1 model, Armijo    -> _impls/optimize/root/*.py
+  oracle.rootfinder quasi-Newton driver, Broyden-1 / Broyden-2 / linear-mixing models, Armijo -> _impls/optimize/root/*.py
 """

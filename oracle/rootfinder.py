@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Follows
 xitorch/_impls/optimize/root/rootsolver.py:15-380 (quasi-Newton driver, Armijo
 search, termination test) and _jacobian.py:51-222 (Broyden-1 inverse-Jacobian
-model, low-rank storage), real dtypes only.
+model, Broyden-2 and linear-mixing models, low-rank storage), real dtypes only.
 """
 import warnings
 import torch
