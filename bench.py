@@ -3,21 +3,29 @@
 
 One "step" = one full `symeig(A, neig=6, mode="lowest", method="davidson", min_eps=1e-8)` call
 (native HIP block Davidson) on BASELINE.json configs[1]: a batch of 64 dense symmetric fp64
-operators of size N=16384 per GPU (137.4 GB resident in HBM, synthetic closed-form spectrum S1 —
-SURVEY.md §8d), start block drawn on the device inside the step (seed 12421, like the reference).  Nothing is skipped or
-cached between steps.
+operators of size N=16384 (137.4 GB, synthetic closed-form spectrum S1 — SURVEY.md §8d) resident in
+HBM, start block drawn on the device inside the step (seed 12421, like the reference).  Nothing is
+skipped or cached between steps.
 
   value      = eigenpairs per second, whole job (all ranks), inputs already resident in HBM
-  roofline   = the K1 operator-panel-product kernel (the "Lanczos matvec" of the metric):
-               algorithmic bytes per launch (B*N^2*s + 2*B*N*p*s) / its average duration, measured
-               live with HIP events on the launch stream inside the timed region, vs 8 TB/s
+  roofline   = the dominant kernel = the operator-panel product (the "Lanczos matvec" of the metric),
+               priced on the bytes THAT kernel has to move (K1s reads the upper triangle of the exactly
+               symmetric storage: B*N(N+1)/2*s + 2*B*N*p*s; the general K1: B*N^2*s + 2*B*N*p*s)
+               / its average duration, measured live with HIP events on the launch stream inside the
+               timed region, vs 8 TB/s.  `full_matrix_equivalent_*` restates the same launch with
+               SURVEY 8d's bytes (A counted in full) — a rate, not a roofline fraction.
+  general_k1 = the same workload with the full-matrix panel kernel forced (what an operator that is
+               only allclose-symmetric gets): its own eigpairs/s and roofline, measured after the
+               timed region.
   cpu_baseline = the oracle (CPU restatement of the reference, bit-identical to it) timed on this
                box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
 
-Multi-GPU (launched by torch.distributed.run): the batched-operator dimension is sharded, one
-process per GPU; each rank owns 64 operators (weak scaling, default) or 64/N (--scaling strong).
-The only exchange is the per-iteration all-reduce(MAX) of the residual (RCCL), which keeps the
-reference's global stopping rule.
+Multi-GPU: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one rank per
+GPU, RCCL); launched by torch.distributed.run directly it just runs.  The batched-operator dimension
+is sharded.  Default = STRONG scaling of the metric's batch of 64 (64/N operators per GPU); a short
+weak-scaled run (64 operators per GPU) follows outside the timed region and is reported as
+`weak_extra`.  The only exchange is the per-iteration all-reduce(MAX) of {residual, flag} (RCCL),
+which keeps the reference's global stopping rule.
 """
 import argparse
 import json
@@ -36,13 +44,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="operators per GPU (weak) / in total (strong)")
+    ap.add_argument("--batch", type=int, default=64, help="operators in total (strong, default) / per GPU (weak)")
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--neig", type=int, default=6)
     ap.add_argument("--spectrum", default="S1")
     ap.add_argument("--min-eps", type=float, default=1e-8)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): --batch operators in total, split over the GPUs; weak: --batch per GPU")
+    ap.add_argument("--no-weak-extra", action="store_true", help="N > 1: skip the short weak-scaled extra run")
+    ap.add_argument("--no-general-extra", action="store_true", help="skip the extra run with the full-matrix kernel")
     ap.add_argument("--max-niter", type=int, default=200, help="guard only; ~19 iterations are needed")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one batch group on one stream (default: two groups, panel products on a CU-masked stream)")
@@ -63,7 +74,13 @@ def cpu_baseline(args):
     b, n = [int(v) for v in args.cpu_sample.split("x")]
     # torch-CPU collapses when oversubscribed on these skinny products (256 threads: 300 s for what
     # 32 threads do in seconds), so the baseline uses at most 32 threads and says so in `cores`.
-    cores = min(os.cpu_count() or 1, args.cpu_threads)
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = logical
+    cores = min(logical, args.cpu_threads)
     torch.set_num_threads(cores)
     mat = synthetic.dense_symmetric(b, n, args.spectrum)
     op = oops.DenseOp(mat, True)
@@ -84,149 +101,210 @@ def cpu_baseline(args):
                       "N=%d fp64 neig=%d min_eps=%g, median of %d runs (%.2f s each, %d iterations); "
                       "full config does not fit host RAM" % (args.spectrum, b, n, args.neig, args.min_eps,
                                                              len(times), t, tr["niter"]),
-            "seconds": t, "matvec_GBps": k1_bytes / t / 1e9, "threads": torch.get_num_threads()}
+            "seconds": t, "matvec_GBps": k1_bytes / t / 1e9, "threads": torch.get_num_threads(),
+            "physical_cores": physical, "logical_cpus": logical,
+            "note": "cores = threads actually used (torch-CPU collapses when oversubscribed on these skinny "
+                    "products); the box has physical_cores / logical_cpus"}
+
+
+def _respawn(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _panel_bytes(nb, N, p, esize, symm):
+    """bytes one panel-product launch over nb operators HAS to move (what roofline.achieved is priced on)"""
+    mat = nb * N * (N + 1) // 2 * esize if symm else nb * N * N * esize
+    return mat + 2 * nb * N * p * esize
+
+
+def _k1_roofline(k1_events, N, p, esize, symm, b_local):
+    launches = [(e0.elapsed_time(e1) * 1e-3, nb) for (e0, e1, pc, nb) in k1_events if pc == p]
+    durs = [d for d, _ in launches]
+    nb_launch = launches[0][1] if launches else b_local
+    k1_avg = sum(durs) / max(len(durs), 1)
+    need = _panel_bytes(nb_launch, N, p, esize, symm)
+    full = _panel_bytes(nb_launch, N, p, esize, False)
+    achieved = need / k1_avg / 1e9 if k1_avg > 0 else 0.0
+    if symm:
+        kernel = "K1s xk::dense_symm_tiles (upper-triangle panel product of exactly symmetric storage%s)" % (
+            "; half-batch launch, symm_fold runs beside it on the group's stream" if nb_launch < b_local
+            else " + symm_fold")
+    else:
+        kernel = "K1 xk::dense_rmm_cols + fold_slabs (column-oriented panel product, full matrix)"
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "k1s_pmc_traffic.json" if symm else "k1_pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            rec = json.load(open(pmc_file))
+            if rec.get("N") == N and rec.get("P") == p and rec.get("B"):
+                # PMC record of a launch over rec["B"] members; traffic scales linearly with the batch
+                traffic = rec.get("hbm_bytes_per_launch") * nb_launch / rec["B"]
+        except Exception:
+            traffic = None
+    roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": traffic, "kernel": kernel, "launches_timed": len(durs), "avg_launch_ms": k1_avg * 1e3,
+            "algorithmic_bytes_per_launch": need, "batch_members_per_launch": nb_launch,
+            "bytes_formula": ("B*N*(N+1)/2*s + 2*B*N*p*s (triangle incl. diagonal + panel in + panel out)" if symm
+                              else "B*N^2*s + 2*B*N*p*s (SURVEY 8d)")}
+    if symm:
+        roof["full_matrix_equivalent_bytes_per_launch"] = full
+        roof["full_matrix_equivalent_GBps"] = full / k1_avg / 1e9 if k1_avg > 0 else 0.0
+        roof["note"] = ("frac prices the launch on the bytes the upper-triangle kernel must move; "
+                        "full_matrix_equivalent_GBps = SURVEY 8d's bytes (A counted in full) / the same time: the rate a "
+                        "full-matrix kernel would need to match it, not a roofline fraction")
+    return roof, durs
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _respawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
     if args.gpus != world:
-        # one process per GPU: N > 1 means `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch it with torch.distributed.run "
-                         "(one rank per GPU)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    group = None
+    group, backend, rccl_world = None, None, 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend="nccl", device_id=dev)         # "nccl" == RCCL on ROCm
         group = dist.group.WORLD
+        backend, rccl_world = dist.get_backend(group), dist.get_world_size(group)
 
-    from xitorch_amd import MatrixLinearOperator, LinearOperator, synthetic, kernels as XK
+    from xitorch_amd import LinearOperator, synthetic, kernels as XK
     from xitorch_amd.linalg import symeig
 
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     esize = 8 if args.dtype == "f64" else 4
-    if args.scaling == "weak":
-        b_local, b_total, offset = args.batch, args.batch * world, rank * args.batch
-    else:
-        assert args.batch % world == 0, "strong scaling needs batch % gpus == 0"
-        b_local, b_total, offset = args.batch // world, args.batch, rank * (args.batch // world)
     N, p = args.n, args.neig
-
-    # ---- resident input: the operator batch in HBM (generated on the device, closed form) ----
-    mat = torch.empty((b_local, N, N), dtype=dtype, device=dev)
-    synthetic.dense_symmetric(b_local, N, args.spectrum, dtype=dtype, device=dev, out=mat, batch_offset=offset)
-    # LinearOperator.m scans the matrix (like the reference's symmetry check, linop.py:97-105) and also learns
-    # that the storage is EXACTLY symmetric, which lets the panel product stream only the upper triangle
-    # (K1s).  --k1 general forces the full-matrix kernel.
-    if args.k1 == "general":
-        A = MatrixLinearOperator(mat, is_hermitian=True, symmetric_storage=False)
-    else:
-        A = LinearOperator.m(mat, is_hermitian=True)
-    symm = bool(A.symmetric_storage)
     exact = synthetic.spectrum(args.spectrum, N, torch.float64, dev)[:p]
-
-    k1_events = []
-    traces = []
-
-    def step(timed):
-        tr = {"k1_events": k1_events if timed else None}
-        with torch.no_grad():
-            evals, evecs = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=args.min_eps,
-                                  v_init="randn", rng_device="device", max_niter=args.max_niter,
-                                  overlap=(False if args.no_overlap else "auto"), reserve_cus=args.reserve_cus,
-                                  process_group=group, trace=tr)
-        if timed:
-            traces.append(tr)
-        return evals, evecs
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    step_marks = []
-    for _ in range(args.steps):
-        evals, evecs = step(True)
-        step_marks.append(time.perf_counter())      # host clock only (davidson returns after its last status read)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = tt.item()
+    def make_operator(b_local, offset, k1):
+        # resident input: the operator batch in HBM (generated on the device, closed form).
+        # LinearOperator.m scans the matrix (like the reference's symmetry check, linop.py:97-105) and also learns
+        # that the storage is EXACTLY symmetric, which lets the panel product stream only the upper triangle (K1s).
+        mat = torch.empty((b_local, N, N), dtype=dtype, device=dev)
+        synthetic.dense_symmetric(b_local, N, args.spectrum, dtype=dtype, device=dev, out=mat, batch_offset=offset)
+        A = LinearOperator.m(mat, is_hermitian=True)
+        if k1 == "general":
+            A.symmetric_storage = False          # what a merely allclose-symmetric operator gets: the full-matrix kernel
+        return mat, A
 
-    # ---- result checks (outside the timed region) ----
+    def run(A, steps, warmup, events):
+        """`warmup` untimed + exactly `steps` timed symeig calls between two barrier+synchronize fences; MAX over ranks."""
+        traces = []
+
+        def step(timed):
+            tr = {"k1_events": events if timed else None}
+            with torch.no_grad():
+                evals, evecs = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=args.min_eps,
+                                      v_init="randn", rng_device="device", max_niter=args.max_niter,
+                                      overlap=(False if args.no_overlap else "auto"), reserve_cus=args.reserve_cus,
+                                      process_group=group, trace=tr)
+            if timed:
+                traces.append(tr)
+            return evals, evecs
+        for _ in range(warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        marks = []
+        for _ in range(steps):
+            evals, evecs = step(True)
+            marks.append(time.perf_counter())     # host clock only (davidson returns after its last status read)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            elapsed = tt.item()
+        step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)]
+        return elapsed, evals, traces, step_ms
+
+    def shard(scaling):
+        if scaling == "weak":
+            return args.batch, args.batch * world, rank * args.batch
+        assert args.batch % world == 0, "strong scaling needs batch % gpus == 0"
+        return args.batch // world, args.batch, rank * (args.batch // world)
+
+    # ---------------- the timed job ----------------
+    b_local, b_total, offset = shard(args.scaling)
+    mat, A = make_operator(b_local, offset, args.k1)
+    symm = bool(A.symmetric_storage)
+    k1_events = []
+    elapsed, evals, traces, step_ms = run(A, args.steps, args.warmup, k1_events)
+
+    # result checks (outside the timed region)
     tol = 1e-10 if dtype == torch.float64 else 1e-3
     eval_err = (evals.double() - exact).abs().max().item()
     resid = traces[-1]["best_resid"]
     ok = eval_err <= tol * 100.0 and resid < args.min_eps
+    roofline, durs = _k1_roofline(k1_events, N, p, esize, symm, b_local)
 
-    # ---- K1 roofline from the live HIP events ----
-    # every timed launch of the panel product: (duration, batch members it covered); with the two-group
-    # pipeline a launch covers half of the rank's batch, and launches of the two groups never overlap
-    launches = [(e0.elapsed_time(e1) * 1e-3, nb) for (e0, e1, pc, nb) in k1_events if pc == p]
-    durs = [d for d, _ in launches]
-    nb_launch = launches[0][1] if launches else b_local
-    k1_avg = sum(durs) / max(len(durs), 1)
-    k1_bytes = nb_launch * N * N * esize + 2 * nb_launch * N * p * esize       # A counted in full
-    achieved = k1_bytes / k1_avg / 1e9 if k1_avg > 0 else 0.0
-    kernel_name = ("K1s xk::dense_symm_tiles + symm_fold (upper-triangle panel product, exactly symmetric storage)"
-                   if symm else "K1 xk::dense_rmm_cols + fold_slabs (column-oriented panel product, full matrix)")
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "k1s_pmc_traffic.json" if symm else "k1_pmc_traffic.json")
-    if os.path.exists(pmc_file):
-        try:
-            rec = json.load(open(pmc_file))
-            if rec.get("N") == N and rec.get("P") == p and rec.get("dtype") == args.dtype and rec.get("B"):
-                # PMC record was taken on a launch over rec["B"] members; traffic scales linearly with the batch
-                traffic = rec.get("hbm_bytes_per_launch") * nb_launch / rec["B"]
-        except Exception:
-            traffic = None
-    if symm and nb_launch < b_local:
-        # two-group pipeline: the events bracket the tile kernel on the panel-product stream; its 0.11 ms fold runs
-        # on the group's own stream
-        kernel_name = "K1s xk::dense_symm_tiles (upper-triangle panel product, half-batch launch; symm_fold runs beside it)"
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "kernel": kernel_name, "launches_timed": len(durs),
-                "avg_launch_ms": k1_avg * 1e3, "algorithmic_bytes_per_launch": k1_bytes,
-                "batch_members_per_launch": nb_launch}
-    if symm:
-        # what the upper-triangle kernel must move: the triangle incl. diagonal + the panels in and out
-        tri_bytes = nb_launch * N * (N + 1) // 2 * esize + 2 * nb_launch * N * p * esize
-        roofline["note"] = ("achieved uses SURVEY 8d's algorithmic bytes (A counted in full); K1s reads only the upper "
-                            "triangle of the exactly symmetric operator, so it can exceed the HBM peak; "
-                            "triangle_* fields price the same launch against the bytes it really has to move")
-        roofline["triangle_bytes_per_launch"] = tri_bytes
-        roofline["triangle_achieved"] = tri_bytes / k1_avg / 1e9 if k1_avg > 0 else 0.0
-        roofline["triangle_frac"] = roofline["triangle_achieved"] / 8000.0
-    # the general (full-matrix) K1 on the same resident operator, measured live for reference (untimed region)
-    Xg = torch.randn((b_local, p, N), dtype=dtype, device=dev)
-    Yg = torch.empty_like(Xg)
-    XK.dense_mm(mat, Xg, out=Yg, trans=True)
-    ge = []
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    # ---------------- extra: the full-matrix panel kernel on the same resident operator ----------------
+    general = None
+    if symm and not args.no_general_extra:
+        A.symmetric_storage = False
+        gev = []
+        g_el, g_evals, g_tr, g_ms = run(A, max(1, min(args.steps, 3)), 1, gev)
+        A.symmetric_storage = True
+        g_roof, _ = _k1_roofline(gev, N, p, esize, False, b_local)
+        general = {"value": b_total * p * len(g_ms) / g_el, "unit": "eigpairs/s", "ms_per_step": g_el / len(g_ms) * 1e3,
+                   "steps": len(g_ms), "iterations_per_step": g_tr[-1]["niter"], "roofline": g_roof,
+                   "max_eval_err_vs_exact": (g_evals.double() - exact).abs().max().item(),
+                   "note": "same workload, full-matrix panel kernel (operators whose storage is not exactly symmetric)"}
+    elif not symm:
+        # one whole-batch launch of the general kernel, timed alone (untimed region), bytes of the WHOLE batch
+        Xg = torch.randn((b_local, p, N), dtype=dtype, device=dev)
+        Yg = torch.empty_like(Xg)
         XK.dense_mm(mat, Xg, out=Yg, trans=True)
-        e1.record()
-        ge.append((e0, e1))
-    torch.cuda.synchronize()
-    g_avg = sum(a.elapsed_time(b) for a, b in ge) / len(ge) * 1e-3
-    roofline_general = {"bound": "hbm", "achieved": k1_bytes / g_avg / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": k1_bytes / g_avg / 1e9 / 8000.0, "avg_launch_ms": g_avg * 1e3,
-                        "kernel": "K1 xk::dense_rmm_cols + fold_slabs (full matrix; used for operators whose storage "
-                                  "is not exactly symmetric)", "launches_timed": len(ge)}
+        ge = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            XK.dense_mm(mat, Xg, out=Yg, trans=True)
+            e1.record()
+            ge.append((e0, e1))
+        torch.cuda.synchronize()
+        g_avg = sum(a.elapsed_time(b) for a, b in ge) / len(ge) * 1e-3
+        gb = _panel_bytes(b_local, N, p, esize, False)
+        general = {"standalone_whole_batch_launch": {"achieved": gb / g_avg / 1e9, "frac": gb / g_avg / 1e9 / 8000.0,
+                                                     "avg_launch_ms": g_avg * 1e3, "bytes": gb}}
+
+    # ---------------- extra: weak scaling (64 operators per GPU), N > 1 only ----------------
+    weak_extra = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak_extra:
+        del A, mat
+        torch.cuda.empty_cache()
+        try:
+            wl, wt, woff = shard("weak")
+            wmat, wA = make_operator(wl, woff, args.k1)
+            w_el, _, w_tr, w_ms = run(wA, 2, 1, None)
+            weak_extra = {"scaling": "weak", "value": wt * p * 2 / w_el, "unit": "eigpairs/s", "ms_per_step": w_el / 2 * 1e3,
+                          "global_batch": wt, "batch_per_gpu": wl, "steps": 2, "warmup": 1}
+            del wA, wmat
+        except Exception as err:            # never lose the headline line to the extra
+            weak_extra = {"error": repr(err)}
 
     if rank == 0:
         out = {
@@ -238,16 +316,19 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: linalg.symeig davidson lowest-%d, dense symmetric "
-                                   "LinearOperator N=%d batch=%d/GPU %s (%s spectrum), min_eps=%g"
-                                   % (p, N, b_local, args.dtype, args.spectrum, args.min_eps),
-                       "global_batch": b_total, "parallelism": "batch-sharded x%d (%s)" % (world, args.scaling),
+                                   "LinearOperator N=%d batch=%d (%d per GPU) %s (%s spectrum), min_eps=%g"
+                                   % (p, N, b_total, b_local, args.dtype, args.spectrum, args.min_eps),
+                       "global_batch": b_total, "batch_per_gpu": b_local,
+                       "parallelism": "batch-sharded x%d (%s)" % (world, args.scaling),
+                       "comm_backend": backend, "comm_world_size": rccl_world,
                        "iterations_per_step": traces[-1]["niter"], "panel_products_per_step": traces[-1]["napply"],
-                       "basis_size": traces[-1]["basis_size"]},
+                       "basis_size": traces[-1]["basis_size"], "batch_groups": traces[-1].get("groups")},
             "roofline": roofline,
-            "roofline_general_k1": roofline_general,
+            "general_k1": general,
+            "weak_extra": weak_extra,
             "matvec_fraction_of_step": sum(durs) / elapsed if elapsed > 0 else None,
             "check": {"ok": bool(ok), "max_eval_err_vs_exact": eval_err, "max_resid": resid},
-            "step_ms": [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)],
+            "step_ms": step_ms,
             "k1_ms_first_last": [round(durs[0] * 1e3, 3), round(durs[-1] * 1e3, 3)] if durs else None,
         }
         if world == 1 and not args.no_cpu_baseline:

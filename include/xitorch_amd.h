@@ -162,6 +162,23 @@ int xk_banded_mm_f64(const double* band, const double* X, double* Y, int B, int 
 int xk_banded_mm_f32(const float* band, const float* X, float* Y, int B, int N, int hb, int C,
                      long sBand, long ldx, long sX, long ldy, long sY, int trans, void* stream);
 
+/* ---- operator gradients of the implicit backward passes (streaming writes) -----------------------
+ * The backward of solve / symeig / rootfinder ends with a VJP through the operator apply
+ * (`loss = -A.mm(x)`; `autograd.grad(loss, params, v)`: xitorch/linalg/solve.py:188-195,
+ * linalg/symeig.py:374-379, optimize/rootfinder.py:352-362); in the reference that is torch's matmul / slice
+ * backward.  U, W panel-major (B, C, N), pitches ld*, batch pitches s*.
+ * xk_banded_grad:  G[b,d,i] (+)= sum_c U[b,c,i] W[b,c,i+d-hb]   (DIA band gradient; trans apply: swap U and W)
+ * xk_dense_outer:  G[b,i,j] (+)= sum_c U[b,c,i] W[b,c,j]        (i < M, j < N, row pitch ldg)
+ * accumulate = 1 adds into G. */
+int xk_banded_grad_f64(const double* U, const double* W, double* G, int B, int N, int hb, int C, long ldu,
+                       long sU, long ldw, long sW, long sG, int accumulate, void* stream);
+int xk_banded_grad_f32(const float* U, const float* W, float* G, int B, int N, int hb, int C, long ldu, long sU,
+                       long ldw, long sW, long sG, int accumulate, void* stream);
+int xk_dense_outer_f64(const double* U, const double* W, double* G, int B, int M, int N, int C, long ldu,
+                       long sU, long ldw, long sW, long ldg, long sG, int accumulate, void* stream);
+int xk_dense_outer_f32(const float* U, const float* W, float* G, int B, int M, int N, int C, long ldu, long sU,
+                       long ldw, long sW, long ldg, long sG, int accumulate, void* stream);
+
 /* ---- fused Krylov-loop kernels (K7-K9, K11; xitorch/_impls/linalg/solve.py:143-180, 272-314) ----
  * Vectors are (S, ld) arrays: S systems (batch member x column), pitch ld (16 B multiple, pads 0).
  * P* are partial-sum buffers (S, xk_kry_max_partials()); nblk <= that many blocks per system.

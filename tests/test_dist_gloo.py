@@ -46,6 +46,9 @@ def _worker(rank, world, port, results):
         out["sum"] = xd.allreduce_sum_(t.clone(), grp).tolist()
         assert xd.allreduce_max_(t.clone(), None).tolist() == t.tolist()
 
+        out["agree"] = (xd.all_ranks_agree_true(True, "cpu", grp), xd.all_ranks_agree_true(rank == 0, "cpu", grp),
+                        xd.all_ranks_agree_true(False, "cpu", grp), xd.all_ranks_agree_true(rank == 0, "cpu", None))
+
         # 3. sharded quasi-Newton driver == unsharded driver (the whole batch is ONE flat system, Q4)
         nb, n = 4, 12
         fcn, y0, (A,) = cases.root_inputs(dict(kind="tanh", nbatch=nb, n=n))
@@ -96,6 +99,8 @@ def test_world_size_2_gloo():
         r = results[rank]
         assert r["spans"] == [(0, 3), (3, 5)]
         assert r["max"] == [2.0, 10.0] and r["sum"] == [3.0, 19.0]
+        # a shortcut around a loop with collectives is taken only when EVERY rank wants it
+        assert r["agree"] == (True, False, False, rank == 0)
         assert r["root_err"] < 1e-12
         assert r["root_iters"][0] == r["root_iters"][1] and r["root_iters"][2] == r["root_iters"][3]
         d = r["dot"]

@@ -231,3 +231,47 @@ def test_two_group_pipeline_with_preconditioner_and_odd_batch(dev):
     assert (ev2.cpu() - ref).abs().max().item() < 1e-10 * 400
     Xc = X2.cpu()
     assert (torch.matmul(A, Xc) - Xc * ev2.cpu().unsqueeze(-2)).abs().max().item() < 1e-7
+
+
+def test_two_group_pipeline_full_basis_exact_pairs(dev):
+    # N == nguess + m * neig: with the two-group pipeline the FIRST group is expanded early inside the iteration, so
+    # the "basis became square" test must look at a group that has not been expanded yet — otherwise the loop stops
+    # one Rayleigh-Ritz short of the exact pairs (symeig.py:196-203 breaks only after the RR on the square basis)
+    g = torch.Generator().manual_seed(14)
+    N, neig, B = 24, 3, 4
+    R = torch.randn(B, N, N, dtype=torch.float64, generator=g)
+    mat = (R + R.transpose(-2, -1)) * 0.5
+    exact = torch.linalg.eigvalsh(mat)[:, :neig]
+    for overlap in (False, True):
+        tr = {}
+        ev, X = davidson(xa.LinearOperator.m(mat.to(dev), True), neig, "lowest", min_eps=1e-300, overlap=overlap,
+                         trace=tr)
+        assert tr["stop_reason"] == "full_basis" and tr["basis_size"] == N and tr["groups"] == (2 if overlap else 1)
+        assert (ev.cpu() - exact).abs().max().item() < 1e-10, (overlap, (ev.cpu() - exact).abs().max().item())
+        Xc = X.cpu()
+        assert (torch.matmul(mat, Xc) - Xc * ev.cpu().unsqueeze(-2)).abs().max().item() < 1e-9
+
+
+def test_rank_deficient_start_block_raises(dev):
+    # the reference raises from torch.linalg.cholesky on a rank-deficient guess block (tallqr, tensor.py:16);
+    # here the panel Cholesky flags the non-positive pivot and the host raises
+    g = torch.Generator().manual_seed(15)
+    N = 64
+    R = torch.randn(2, N, N, dtype=torch.float64, generator=g)
+    mat = ((R + R.transpose(-2, -1)) * 0.5).to(dev)
+    V0 = torch.randn(2, N, 3, dtype=torch.float64, generator=g)
+    V0[1, :, 2] = 0.0                                    # member 1: a zero column -> pivot exactly 0
+    with pytest.raises(RuntimeError, match="positive definite"):
+        davidson(xa.LinearOperator.m(mat, True), 3, "lowest", V0=V0.to(dev), max_niter=5)
+    # the flag is sticky: a later factorisation of a healthy panel into the same info buffer (the second CholeskyQR
+    # pass of `start`) must not erase it
+    from xitorch_amd import kernels as K
+    Gbad = torch.eye(3, dtype=torch.float64).repeat(2, 1, 1)
+    Gbad[1, 1, 1] = -1.0
+    W = torch.empty(2, 3, 3, dtype=torch.float64, device=dev)
+    info = torch.zeros(2, dtype=torch.int32, device=dev)
+    K.panel_chol(Gbad.to(dev), W, info, 3)
+    assert info.tolist() == [0, 2]
+    K.panel_chol(torch.eye(3, dtype=torch.float64).repeat(2, 1, 1).to(dev), W, info, 3)
+    assert info.tolist() == [0, 2]
+    assert torch.allclose(W.cpu(), torch.eye(3, dtype=torch.float64).repeat(2, 1, 1))

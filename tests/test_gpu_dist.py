@@ -70,6 +70,23 @@ def _worker(rank, world, port, results):
                                    process_group=dist.group.WORLD, **kw)
             kry[meth] = dict(niter=(ts["niter"], tf["niter"]), err=(Xs - Xf[l2:h2]).abs().max().item())
         out["krylov"] = kry
+        # a rank whose shard of the right-hand side is all zeros (an implicit backward where some batch members
+        # receive no gradient) must stay in the collectives: the zero-rhs shortcut is a group decision
+        Bz = Bm.clone()
+        Bz[:2] = 0.0                                             # rank 0's shard
+        zs = {}
+        for meth in ("bicgstab", "cg"):
+            herm = meth == "cg"
+            Am = (Amat + Amat.transpose(-2, -1)) * 0.5 if herm else Amat
+            Xs = getattr(nk, meth)(xa.LinearOperator.m(Am[l2:h2].contiguous(), herm), Bz[l2:h2].contiguous(),
+                                   process_group=dist.group.WORLD, rtol=1e-10, atol=1e-12, posdef=True)
+            ref = torch.linalg.solve(Am[l2:h2], Bz[l2:h2])
+            zs[meth] = (Xs - ref).abs().max().item()
+        from xitorch_amd.linalg import solve as xsolve
+        Xs = xsolve(xa.LinearOperator.m(Amat[l2:h2].contiguous(), False), Bz[l2:h2].contiguous(), method="bicgstab",
+                    process_group=dist.group.WORLD, rtol=1e-10, atol=1e-12, posdef=True)
+        zs["frontend"] = (Xs - torch.linalg.solve(Amat[l2:h2], Bz[l2:h2])).abs().max().item()
+        out["zero_shard"] = zs
         fcn, y0, (Ar,) = cases.root_inputs(dict(kind="tanh", nbatch=4, n=64))
         tf, ts = {}, {}
         yf = nr.broyden1(fcn, y0.to(dev), (Ar.to(dev),), alpha=-1.0, f_tol=1e-9, trace=tf)
@@ -106,5 +123,7 @@ def test_sharded_davidson_two_ranks_one_gpu():
         for meth, r in results[rank]["krylov"].items():
             assert r["niter"][0] == r["niter"][1], (meth, r)      # global stopping / best-iterate decisions
             assert r["err"] < 1e-9, (meth, r)
+        for meth, err in results[rank]["zero_shard"].items():
+            assert err < 1e-8, (meth, err)
         r = results[rank]["broyden"]                              # the whole batch is ONE flat system (Q4)
         assert r["niter"][0] == r["niter"][1] and r["nfev"][0] == r["nfev"][1] and r["err"] < 1e-9, r

@@ -403,3 +403,31 @@ int main(int argc, char** argv) {
     out = subprocess.check_output([str(exe), _capi.LIB_PATH]).decode().split()
     assert int(out[0]) >= 1
     assert int(out[1]) == 2 * (2 + 2) * 6 * 2048          # (NS + NT) slots of P x N per batch member
+
+
+def test_symmetric_storage_promise_follows_the_tensor():
+    """the exact-symmetry promise (upper-triangle kernel) and the checked-symmetry status (transposed
+    kernel) belong to ONE tensor; swapping `mat` (uselinopparams / setuniqueparams) or writing into it drops them."""
+    import xitorch_amd as xa
+    g = torch.Generator().manual_seed(3)
+    R = torch.rand(2, 6, 6, dtype=torch.float64, generator=g)
+    sym = (R + R.transpose(-2, -1)) * 0.5
+    A = xa.LinearOperator.m(sym.clone())
+    assert A.is_hermitian and A.symmetric_storage and A.hermitian_verified
+    other = R.clone()                                     # not symmetric at all
+    with A.uselinopparams(other):
+        assert not A.symmetric_storage and not A.hermitian_verified
+        assert torch.allclose(A.mm(R), torch.matmul(other, R))            # the reference's mat @ x
+    assert A.symmetric_storage and A.hermitian_verified    # the original tensor is back
+    A.mat.add_(1.0)                                       # in-place write: version counter moves
+    assert not A.symmetric_storage
+    # a directly constructed operator is taken at its word for is_hermitian, never for the storage
+    A2 = xa.MatrixLinearOperator(sym.clone(), True)
+    assert A2.is_hermitian and not A2.symmetric_storage and not A2.hermitian_verified
+    A2.symmetric_storage = True
+    assert A2.symmetric_storage and A2.hermitian_verified
+    # allclose-symmetric but not bitwise: checked, not exact
+    near = sym.clone()
+    near[0, 1, 2] += 1e-12
+    A3 = xa.LinearOperator.m(near)
+    assert A3.is_hermitian and A3.hermitian_verified and not A3.symmetric_storage

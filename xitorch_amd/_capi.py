@@ -83,6 +83,8 @@ def _declare(L):
         sigs["xk_cg_update_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])
         sigs["xk_cg_p_" + sfx] = (I, [P] * 4 + [I, I, Lg, I, D, P])
         sigs["xk_kry_status_" + sfx] = (I, [P] * 4 + [I, I, P])
+        sigs["xk_banded_grad_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
+        sigs["xk_dense_outer_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, P])
     for name, (res, args) in sigs.items():
         if not hasattr(L, name):
             continue  # reported by the symbol test, and by check() at call time

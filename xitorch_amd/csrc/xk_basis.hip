@@ -199,7 +199,9 @@ __global__ void panel_chol_kernel(const T* __restrict__ G, T* __restrict__ W, in
     }
     for (int i = 0; i < P; ++i) Wb[(long)i * P + c] = col[i];
   }
-  info[b] = bad;
+  // sticky: a later pass over the same panel (CholeskyQR2) must not erase an earlier breakdown; the host
+  // allocates info zeroed and raises as soon as it reads a non-zero flag
+  if (bad) info[b] = bad;
 }
 
 // in-place t[c,:] <- sum_{a<=c} W[a,c] t[a,:], W upper triangular (B,P,P) row-major.

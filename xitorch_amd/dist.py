@@ -15,7 +15,7 @@ call per decision and never sit on the bandwidth path.
 """
 import torch
 
-__all__ = ["shard_range", "allreduce_max_", "allreduce_sum_", "is_distributed"]
+__all__ = ["shard_range", "allreduce_max_", "allreduce_sum_", "is_distributed", "all_ranks_agree_true"]
 
 
 def is_distributed():
@@ -48,3 +48,15 @@ def allreduce_sum_(t, group=None):
     if not _trivial(group):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
     return t
+
+
+def all_ranks_agree_true(flag, device, group=None):
+    """True only when `flag` is true on EVERY rank of the group (one tiny all-reduce).  Shortcuts that skip a
+    solver loop containing collectives must be taken by all ranks or by none: a rank that returns early on
+    its own (e.g. its shard of the right-hand side is zero — common in an implicit backward where some batch
+    members receive no gradient) would leave the others blocked in the loop's all-reduce."""
+    if _trivial(group):
+        return bool(flag)
+    t = torch.tensor([0.0 if flag else 1.0], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+    return bool(t.item() == 0.0)

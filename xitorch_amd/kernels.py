@@ -209,6 +209,49 @@ def banded_mm(band, X, out=None, trans=False):
     return out
 
 
+def banded_grad(U, W, nd, out=None, accumulate=False):
+    """G[b,d,i] (+)= sum_c U[b,c,i] * W[b,c,i+d-hb]  — the DIA band gradient of the banded apply
+    (y = A x: U = grad_y, W = x; y = A^T x: U = x, W = grad_y).  U, W panel-major (B, C, N); returns (B, nd, N)."""
+    require_device(U, "panel")
+    require_device(W, "panel")
+    B, C, N = U.shape
+    if W.shape != U.shape or U.dtype != W.dtype or nd % 2 != 1:
+        raise _capi.NativeLibraryError("banded_grad: panels must agree (got %s / %s), nd odd" % (tuple(U.shape), tuple(W.shape)))
+    ldu, sU = _panel_strides(U)
+    ldw, sW = _panel_strides(W)
+    if out is None:
+        out = torch.empty((B, nd, N), dtype=U.dtype, device=U.device)
+        accumulate = False
+    if not out.is_contiguous():
+        raise _capi.NativeLibraryError("banded_grad: output must be contiguous")
+    rc = fn("xk_banded_grad_" + suffix(U.dtype))(ptr(U), ptr(W), ptr(out), B, N, nd // 2, C, ldu, sU, ldw, sW,
+                                                  out.stride(0), 1 if accumulate else 0, stream_ptr())
+    check(rc, "xk_banded_grad")
+    return out
+
+
+def dense_outer(U, W, out=None, accumulate=False):
+    """G[b,i,j] (+)= sum_c U[b,c,i] * W[b,c,j]  — the dense-operator gradient (outer product of two panels).
+    U (B, C, M), W (B, C, N) panel-major; returns (B, M, N) row-major."""
+    require_device(U, "panel")
+    require_device(W, "panel")
+    B, C, M = U.shape
+    N = W.shape[2]
+    if W.shape[0] != B or W.shape[1] != C or U.dtype != W.dtype:
+        raise _capi.NativeLibraryError("dense_outer: panels must agree (got %s / %s)" % (tuple(U.shape), tuple(W.shape)))
+    ldu, sU = _panel_strides(U)
+    ldw, sW = _panel_strides(W)
+    if out is None:
+        out = torch.empty((B, M, N), dtype=U.dtype, device=U.device)
+        accumulate = False
+    if out.stride(2) != 1 and N > 1:
+        raise _capi.NativeLibraryError("dense_outer: output must have unit stride along its last dim")
+    rc = fn("xk_dense_outer_" + suffix(U.dtype))(ptr(U), ptr(W), ptr(out), B, M, N, C, ldu, sU, ldw, sW,
+                                                  out.stride(1), out.stride(0), 1 if accumulate else 0, stream_ptr())
+    check(rc, "xk_dense_outer")
+    return out
+
+
 # --------------------------------------------------------------------------- CU-masked stream
 _MASKED_STREAMS = {}
 

@@ -52,6 +52,7 @@ class PanelOperator:
                 mat, flip = mat.transpose(-2, -1), True           # a transposed view (e.g. A.H)
             if mat.is_contiguous() or mat.dim() == 2 and mat.stride(-1) == 1:
                 self.kind, self.flip = "dense", flip
+                self.herm_verified = bool(getattr(A, "hermitian_verified", False))
                 self.mat = mat.reshape(nA, *mat.shape[-2:]) if mat.dim() > 2 else mat
                 vn = 2 if mat.dtype == torch.float64 else 4
                 # exactly symmetric storage: stream the upper triangle only (K1s)
@@ -136,7 +137,9 @@ class PanelOperator:
             t = (trans != self.flip)
             # a real symmetric matrix equals its transpose: the column-oriented K1 variant (lanes own
             # output columns, panel values are wave-uniform scalars) measured 6.8 vs 6.3 TB/s at p = 6
-            if self.hermitian and not self.flip:
+            # (only for matrices whose symmetry was verified by LinearOperator.m — otherwise the product stays the
+            # reference's mat @ x)
+            if self.hermitian and not self.flip and self.herm_verified:
                 t = True
             if not t and X.shape[1] >= K.WIDE_MIN_P:
                 # many columns in the ROW orientation (A X, non-Hermitian A): the VALU rows kernel would stream

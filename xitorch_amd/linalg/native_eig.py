@@ -252,7 +252,11 @@ class _Group:
 def _sub_operator(A, B, N, b0, b1):
     from xitorch_amd.linop import MatrixLinearOperator
     mat = A.mat.reshape(B, N, N)[b0:b1]
-    return MatrixLinearOperator(mat, A.is_hermitian, symmetric_storage=getattr(A, "symmetric_storage", False))
+    sub = MatrixLinearOperator(mat, A.is_hermitian, symmetric_storage=getattr(A, "symmetric_storage", False))
+    if getattr(A, "hermitian_verified", False):
+        from xitorch_amd.linop import _storage_token
+        sub._herm_token = _storage_token(mat)           # a slice of a verified matrix is verified
+    return sub
 
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
@@ -456,7 +460,9 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         if max_resid < min_eps:
             stop_reason = "converged"
             break
-        if groups[0].k == N:
+        # the LAST group is never expanded early, so its width is the width this iteration's Rayleigh-Ritz ran
+        # on for every group (groups[0] may already have been grown inside the loop above)
+        if groups[G - 1].k == N:
             stop_reason = "full_basis"
             break
         for g in deferred + [G - 1]:

@@ -20,7 +20,7 @@ from xitorch_amd import kernels as K
 from xitorch_amd._capi import NativeLibraryError, fn, ptr, stream_ptr, check, suffix
 from xitorch_amd._util import bcast_shape, pad_shapes, ConvergenceWarning
 from xitorch_amd.linalg._panel import PanelOperator, pad_len, to_panel, from_panel
-from xitorch_amd.dist import allreduce_max_
+from xitorch_amd.dist import allreduce_max_, all_ranks_agree_true
 
 __all__ = ["exactsolve", "custom_exactsolve", "cg", "bicgstab", "gmres", "broyden1_solve", "get_batchdims"]
 
@@ -100,6 +100,7 @@ class _Problem:
             self.E = E.to(self.dtype).expand(*self.bdims, self.nc).reshape(self.Bt, self.nc).contiguous()
         self._tmp = None
         self._tmp2 = None
+        self._scratchP = None
         rhs = to_panel(B.to(self.dtype), self.bdims, self.Bt, self.N)
 
         hermit = A.is_hermitian and (M is None or M.is_hermitian)
@@ -117,25 +118,47 @@ class _Problem:
     def new(self, n=None):
         return torch.zeros((self.Bt, self.nc if n is None else n, self.ld), dtype=self.dtype, device=self.device)
 
-    def _apply1(self, X, out, trans=False):
-        self.opA.apply(X, out, trans=trans)
-        if self.E is not None:
-            if self.opM is not None:
-                if self._tmp2 is None or self._tmp2.shape != X.shape:
-                    self._tmp2 = torch.zeros_like(X)
-                self.opM.apply(X, self._tmp2, trans=trans)
-                out.sub_(self._tmp2 * self.E.unsqueeze(-1))
-            else:
-                out.sub_(X * self.E.unsqueeze(-1))
-        return out
+    def _shift_operand(self, X, trans):
+        """Z of the shift term  - E * Z:  M X (or M^H X), or X itself when there is no M."""
+        if self.opM is None:
+            return X
+        if self._tmp2 is None or self._tmp2.shape != X.shape:
+            self._tmp2 = torch.zeros_like(X)
+        self.opM.apply(X, self._tmp2, trans=trans)
+        return self._tmp2
 
-    def apply(self, X, out):
+    def _shift_now(self, out, Z):
+        """out -= E * Z in place through xk_kry_dots' shift stage (its dot product goes to a scratch partial)."""
+        if self._scratchP is None:
+            self._scratchP = torch.zeros((self.S, 64), dtype=self.dtype, device=self.device)
+        vn = 2 if self.dtype == torch.float64 else 4
+        nblk = max(1, min(fn("xk_kry_max_partials")(), (self.N + 256 * vn * 4 - 1) // (256 * vn * 4)))
+        check(fn("xk_kry_dots_" + suffix(self.dtype))(ptr(out), ptr(out), ptr(None), ptr(None), ptr(Z), ptr(self.E),
+                                                      ptr(self._scratchP), ptr(None), self.S, self.N, self.ld, nblk,
+                                                      stream_ptr()), "xk_kry_dots")
+
+    def _apply1(self, X, out, trans=False, defer=False):
+        """out = A X - E * (M X)  (solve.py:590-604).  defer=True leaves the shift to the caller's next
+        xk_kry_dots launch, which applies it while it streams `out` anyway: returns the operand Z (or None)."""
+        self.opA.apply(X, out, trans=trans)
+        if self.E is None:
+            return None
+        Z = self._shift_operand(X, trans)
+        if defer:
+            return Z
+        self._shift_now(out, Z)
+        return None
+
+    def apply(self, X, out, defer=False):
+        """out = (A - E M) X, or the normal-equation operator.  With defer=True the return value, when not None,
+        is the pending shift operand: pass it as `shift=` to the `_Kry.dots` call that follows."""
         if not self.normal:
-            return self._apply1(X, out)
+            return self._apply1(X, out, defer=defer)
         if self._tmp is None or self._tmp.shape != X.shape:
             self._tmp = torch.zeros_like(X)
         self._apply1(X, self._tmp)
-        return self._apply1(self._tmp, out, trans=True)
+        self._apply1(self._tmp, out, trans=True)
+        return None
 
     @property
     def napply(self):
@@ -160,12 +183,15 @@ class _Problem:
                 if i < 9:
                     x = x / xn
             return xn
-        big = largest(lambda x, y: self._apply1(x, y), x0)
+        def op(x, y):
+            self._apply1(x, y)
+            return y
+        big = largest(op, x0)
         neg = big <= 0
         if bool(torch.all(neg)):
             return False
         offset = torch.clamp(big, min=0.0)
-        mostneg = largest(lambda x, y: self._apply1(x, y).sub_(offset * x), x0)
+        mostneg = largest(lambda x, y: op(x, y).sub_(offset * x), x0)
         return bool(torch.all(torch.logical_or(-mostneg <= offset, neg)).item())
 
     def solution(self, Xp):
@@ -181,6 +207,7 @@ class _Kry:
         vn = 2 if prob.dtype == torch.float64 else 4
         self.nblk = max(1, min(fn("xk_kry_max_partials")(), (prob.N + 256 * vn * 4 - 1) // (256 * vn * 4)))
         self.dtype, self.device = prob.dtype, prob.device
+        self.E = prob.E
         self.status = torch.zeros((2,), dtype=torch.float64, device=prob.device)
         self.rnorm = torch.zeros((prob.S,), dtype=prob.dtype, device=prob.device)
 
@@ -193,9 +220,11 @@ class _Kry:
     def _c(self, name, *args):
         check(fn("xk_%s_%s" % (name, self.sfx))(*args, stream_ptr()), "xk_" + name)
 
-    def dots(self, x1, y1, P1, x2=None, y2=None, P2=None):
-        self._c("kry_dots", ptr(x1), ptr(y1), ptr(x2), ptr(y2), ptr(None), ptr(None), ptr(P1), ptr(P2),
-                self.S, self.N, self.ld, self.nblk)
+    def dots(self, x1, y1, P1, x2=None, y2=None, P2=None, shift=None):
+        """partials of <x1,y1> (and <x2,y2>); shift = Z: first y1 -= E * Z in the same pass (the `- M X E` term of
+        the operator, solve.py:590-595, folded into the reduction that follows every apply)."""
+        self._c("kry_dots", ptr(x1), ptr(y1), ptr(x2), ptr(y2), ptr(shift), ptr(self.E if shift is not None else None),
+                ptr(P1), ptr(P2), self.S, self.N, self.ld, self.nblk)
 
     def bicg_p(self, r, p, v, Prho, rho_old, alpha, omega, rho_store, eps, first):
         self._c("bicg_p", ptr(r), ptr(p), ptr(v), ptr(Prho), ptr(rho_old), ptr(alpha), ptr(omega),
@@ -296,7 +325,8 @@ def bicgstab(A, B, E=None, M=None, posdef=None, precond_l=None, precond_r=None, 
     if max_niter is None:
         max_niter = int(1.5 * nr)
     bdims = get_batchdims(A, B, E, M)
-    if torch.allclose(B, B * 0, rtol=rtol, atol=atol):
+    # (sharded runs: every rank takes this shortcut or none does — the loop below contains collectives)
+    if all_ranks_agree_true(torch.allclose(B, B * 0, rtol=rtol, atol=atol), B.device, process_group):
         return _zeros_like_solution(A, B, bdims)
     prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=False)
     kr = _Kry(prob)
@@ -325,16 +355,16 @@ def bicgstab(A, B, E=None, M=None, posdef=None, precond_l=None, precond_r=None, 
         kr.bicg_p(r, p, v, Prho, rho[(k + 1) % 2], alpha, omega, rho[k % 2], eps, first=(k == 1))
         if pr is not None:
             pr.apply(p, y)
-        prob.apply(y, v)
-        kr.dots(r0, v, Pr0v)
+        sh = prob.apply(y, v, defer=True)
+        kr.dots(r0, v, Pr0v, shift=sh)
         kr.bicg_s(r, v, s, rho[k % 2], Pr0v, alpha, eps)
         if pr is not None:
             pr.apply(s, z)
-        prob.apply(z, t)
+        sh = prob.apply(z, t, defer=(pl is None))
         if pl is not None:
             pl.apply(t, Kt)
             pl.apply(s, Ks)
-        kr.dots(Ks, Kt, Pts, Kt, Kt, Ptt)
+        kr.dots(Ks, Kt, Pts, Kt, Kt, Ptt, shift=sh)
         refresh = resid_calc_every != 0 and k % resid_calc_every == 0
         nxt = ring.next_index()
         kr.bicg_final(ring.bufs[ring.cur], ring.bufs[nxt], y, z, s, t, r, r0, alpha, Pts, Ptt, omega, Prr, Prho,
@@ -391,7 +421,8 @@ def cg(A, B, E=None, M=None, posdef=None, precond=None, max_niter=None, rtol=1e-
     if max_niter is None:
         max_niter = int(1.5 * nr)
     bdims = get_batchdims(A, B, E, M)
-    if torch.allclose(B, B * 0, rtol=rtol, atol=atol):
+    # (sharded runs: every rank takes this shortcut or none does — the loop below contains collectives)
+    if all_ranks_agree_true(torch.allclose(B, B * 0, rtol=rtol, atol=atol), B.device, process_group):
         return _zeros_like_solution(A, B, bdims)
     prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=True)
     kr = _Kry(prob)
@@ -414,8 +445,8 @@ def cg(A, B, E=None, M=None, posdef=None, precond=None, max_niter=None, rtol=1e-
     niter = 0
     for k in range(1, max_niter + 1):
         niter = k
-        prob.apply(p, Ap)
-        kr.dots(p, Ap, PpAp)
+        sh = prob.apply(p, Ap, defer=True)
+        kr.dots(p, Ap, PpAp, shift=sh)
         refresh = resid_calc_every != 0 and k % resid_calc_every == 0
         nxt = ring.next_index()
         kr.cg_update(ring.bufs[ring.cur], ring.bufs[nxt], p, Ap, r, Prz[cur], PpAp, Prr, eps, skip_r=refresh)
@@ -472,7 +503,8 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
         max_niter = int(nr)
     max_niter = min(max_niter, nr)
     bdims = get_batchdims(A, B, E, M)
-    if torch.allclose(B, B * 0, rtol=rtol, atol=atol):
+    # (sharded runs: every rank takes this shortcut or none does — the loop below contains collectives)
+    if all_ranks_agree_true(torch.allclose(B, B * 0, rtol=rtol, atol=atol), B.device, process_group):
         return _zeros_like_solution(A, B, bdims)
     prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=False)
     S, N, ld = prob.S, prob.N, prob.ld
@@ -484,11 +516,13 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
     Q = torch.zeros((S, cap, ld), dtype=dtype, device=dev)
     Q[:, 0] = (r / torch.where(beta == 0, torch.full_like(beta, eps), beta).reshape(S, 1, 1))[:, 0]
     w = torch.zeros((S, 1, ld), dtype=dtype, device=dev)
-    # host-side Givens state per system
-    H = torch.zeros((S, max_niter + 1, max_niter), dtype=torch.float64)
-    cs = torch.zeros((S, max_niter), dtype=torch.float64)
-    sn = torch.zeros((S, max_niter), dtype=torch.float64)
-    g = torch.zeros((S, max_niter + 1), dtype=torch.float64)
+    # host-side Givens state per system; grows with the basis (the default max_niter = N would otherwise ask for
+    # S*(N+1)*N doubles up front — the reference preallocates likewise, solve.py:384, quirk Q12)
+    hcap = cap
+    H = torch.zeros((S, hcap + 1, hcap), dtype=torch.float64)
+    cs = torch.zeros((S, hcap), dtype=torch.float64)
+    sn = torch.zeros((S, hcap), dtype=torch.float64)
+    g = torch.zeros((S, hcap + 1), dtype=torch.float64)
     g[:, 0] = beta.double().cpu()
     converged = False
     niter = 0
@@ -501,6 +535,14 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
             Qn = torch.zeros((S, newcap, ld), dtype=dtype, device=dev)
             Qn[:, :cap].copy_(Q)
             Q, cap = Qn, newcap
+        if k + 1 > hcap:                                          # grow the host-side Hessenberg state
+            nh = min(max_niter, 2 * hcap)
+            Hn = torch.zeros((S, nh + 1, nh), dtype=torch.float64)
+            Hn[:, :hcap + 1, :hcap] = H
+            csn, snn, gn = (torch.zeros((S, nh), dtype=torch.float64), torch.zeros((S, nh), dtype=torch.float64),
+                            torch.zeros((S, nh + 1), dtype=torch.float64))
+            csn[:, :hcap], snn[:, :hcap], gn[:, :hcap + 1] = cs, sn, g
+            H, cs, sn, g, hcap = Hn, csn, snn, gn, nh
         prob.apply(Q[:, k].reshape(prob.Bt, prob.nc, ld), w.reshape(prob.Bt, prob.nc, ld))
         hcol = torch.zeros((S, k + 1), dtype=dtype, device=dev)
         for _ in range(2):                                        # CGS2

@@ -82,7 +82,9 @@ class _SolveFunction(torch.autograd.Function):
         params, mparams = all_params[:na], all_params[na:]
         config = merge_options({}, fwd_options)
         ctx.bck_config = merge_options({}, bck_options)
-        if torch.all(B == 0):
+        from xitorch_amd.dist import all_ranks_agree_true
+        # sharded runs (process_group in the options): the zero-rhs shortcut must be collective, see dist.py
+        if all_ranks_agree_true(bool(torch.all(B == 0)), B.device, config.get("process_group")):
             dims = (*nk.get_batchdims(A, B, E, M), *B.shape[-2:])
             x = torch.zeros(dims, dtype=B.dtype, device=B.device)
         else:

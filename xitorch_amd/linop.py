@@ -68,7 +68,10 @@ class LinearOperator(EditableModule):
                 raise RuntimeError("The linear operator is indicated to be hermitian, but the matrix is not")
         # the symmetry scan above also tells whether the storage is EXACTLY symmetric; only then may the
         # native apply read the upper triangle alone (K1s) without changing the reference's semantics
-        return MatrixLinearOperator(mat, is_hermitian, symmetric_storage=bool(is_hermitian and exact))
+        op = MatrixLinearOperator(mat, is_hermitian, symmetric_storage=bool(is_hermitian and exact))
+        if is_hermitian:
+            op._herm_token = _storage_token(mat)        # symmetry of THIS tensor was checked (allclose) just now
+        return op
 
     def __init__(self, shape, is_hermitian=False, dtype=None, device=None, _suppress_hermit_warning=False):
         super(LinearOperator, self).__init__()
@@ -458,9 +461,62 @@ class _DenseMM(torch.autograd.Function):
             gx = _sum_to_shape(_DenseMM.apply(mat, gy, not ctx.trans), x.shape)
         if ctx.needs_input_grad[0] and _grad_wanted(mat):
             # the B*N^2 outer product is only materialised when this backward call really asks for it
-            outer = torch.matmul(x, gy.transpose(-2, -1)) if ctx.trans else torch.matmul(gy, x.transpose(-2, -1))
-            gmat = _sum_to_shape(outer, mat.shape)
+            gmat = _DenseOuter.apply(x, gy, tuple(mat.shape)) if ctx.trans else \
+                _DenseOuter.apply(gy, x, tuple(mat.shape))
         return gmat, gx, None
+
+
+def _batch_plan(op_batch, *operand_batches):
+    """Batch bookkeeping shared by the native applies and their gradients: pads the batch shapes to a common
+    rank, returns (full batch FB, dims the operator varies along `keep`, dims only the operands vary along `fold`)."""
+    nb = max([len(op_batch)] + [len(b) for b in operand_batches])
+    BAp = [1] * (nb - len(op_batch)) + list(op_batch)
+    padded = [[1] * (nb - len(b)) + list(b) for b in operand_batches]
+    FB = bcast_shape(BAp, *padded)
+    keep = [d for d in range(nb) if BAp[d] == FB[d]]
+    fold = [d for d in range(nb) if BAp[d] != FB[d]]
+    return nb, FB, keep, fold
+
+
+def _to_panel(t, nb, FB, keep, fold):
+    """(*batch, n, r) -> panel-major (prod(keep dims), prod(fold dims) * r, n), contiguous vectors."""
+    n, r = t.shape[-2:]
+    tb = [1] * (nb - (t.dim() - 2)) + list(t.shape[:-2])
+    te = t.reshape(*tb, n, r).expand(*FB, n, r)
+    nkeep = 1
+    for d in keep:
+        nkeep *= FB[d]
+    tp = te.permute(*keep, *fold, nb + 1, nb).reshape(nkeep, -1, n)
+    if tp.stride(-1) != 1 or (tp.shape[1] > 1 and tp.stride(1) < n):
+        tp = tp.contiguous()
+    return tp
+
+
+class _DenseOuter(torch.autograd.Function):
+    """G[..., i, j] = sum_c u[..., i, c] w[..., j, c] reduced to the operator's shape: the gradient of the dense
+    apply w.r.t. the matrix, written by the streaming HIP kernel xk_dense_outer (in the reference: the matmul
+    backward under `torch.autograd.grad(loss, params, ...)`, linalg/solve.py:188-195).  Bilinear, so its own
+    backward is two dense applies and any order of differentiation works."""
+
+    @staticmethod
+    def forward(ctx, u, w, mat_shape):
+        ctx.save_for_backward(u, w)
+        ctx.mat_shape = mat_shape
+        M, N = mat_shape[-2:]
+        nb, FB, keep, fold = _batch_plan(mat_shape[:-2], u.shape[:-2], w.shape[:-2])
+        up, wp = _to_panel(u, nb, FB, keep, fold), _to_panel(w, nb, FB, keep, fold)
+        g = _k.dense_outer(up, wp)                                      # (nkeep, M, N): folded dims summed
+        return g.reshape(*[FB[d] for d in keep], M, N).reshape(mat_shape)
+
+    @staticmethod
+    def backward(ctx, gg):
+        u, w = ctx.saved_tensors
+        gu = gw = None
+        if ctx.needs_input_grad[0]:
+            gu = _sum_to_shape(_DenseMM.apply(gg, w, False), u.shape)
+        if ctx.needs_input_grad[1]:
+            gw = _sum_to_shape(_DenseMM.apply(gg, u, True), w.shape)
+        return gu, gw, None
 
 
 def _dense_mm(mat, x, trans):
@@ -482,8 +538,32 @@ class MatrixLinearOperator(LinearOperator):
                          _suppress_hermit_warning=True)
         self.mat = mat
         # True = the caller (or LinearOperator.m's scan) guarantees mat == mat^T bit for bit; the native
-        # eigensolver / Krylov loops then stream only the upper triangle (xk_dense_symm)
-        self.symmetric_storage = bool(symmetric_storage) and bool(is_hermitian) and not torch.is_complex(mat)
+        # eigensolver / Krylov loops then stream only the upper triangle (xk_dense_symm).  The promise is about
+        # ONE tensor: it is remembered together with that tensor's identity and dropped when `mat` is swapped
+        # (uselinopparams / setuniqueparams put graph-connected clones or user tensors there).
+        self._symm_promise = bool(symmetric_storage) and bool(is_hermitian) and not torch.is_complex(mat)
+        self._symm_token = _storage_token(mat) if self._symm_promise else None
+
+    @property
+    def symmetric_storage(self):
+        """Exactly-symmetric-storage promise, valid only for the tensor it was made about: a different `mat`
+        (other storage, other version counter) falls back to the full-matrix kernels = the reference's
+        `mat @ x` semantics."""
+        return bool(self._symm_promise and self._symm_token == _storage_token(self.mat))
+
+    @property
+    def hermitian_verified(self):
+        """True when the symmetry of the current `mat` was actually checked (LinearOperator.m) — only then may a
+        native apply substitute mat^T x for mat x; a bare `MatrixLinearOperator(mat, True)` is taken at its word
+        for the algorithm choice but its products stay the reference's `mat @ x`."""
+        tok = getattr(self, "_herm_token", None)
+        return bool(self._is_hermitian and tok is not None and tok == _storage_token(self.mat)) or \
+            self.symmetric_storage
+
+    @symmetric_storage.setter
+    def symmetric_storage(self, value):
+        self._symm_promise = bool(value) and bool(self._is_hermitian) and not torch.is_complex(self.mat)
+        self._symm_token = _storage_token(self.mat) if self._symm_promise else None
 
     def __repr__(self):
         return "MatrixLinearOperator with shape %s:\n   %s" % (_shape2str(self.shape), _indent(repr(self.mat), 3))
@@ -540,22 +620,36 @@ class _BandedMM(torch.autograd.Function):
         if ctx.needs_input_grad[1] and _grad_wanted(x):
             gx = _sum_to_shape(_BandedMM.apply(band, gy, not ctx.trans), x.shape)
         if ctx.needs_input_grad[0] and _grad_wanted(band):
-            # d/dband[d,i] = sum_c gy[i,c] x[i+off,c]  (trans: gy[i+off,c] x[i,c]) — one strided product per diagonal
-            nd, n = band.shape[-2:]
-            hb = nd // 2
-            rows = []
-            for d in range(nd):
-                off = d - hb
-                lo, hi = max(0, -off), min(n, n - off)
-                g = torch.zeros((*bcast_shape(gy.shape[:-2], x.shape[:-2]), n), dtype=gy.dtype, device=gy.device)
-                if hi > lo:
-                    if not ctx.trans:
-                        g[..., lo:hi] = (gy[..., lo:hi, :] * x[..., lo + off:hi + off, :]).sum(-1)
-                    else:
-                        g[..., lo:hi] = (gy[..., lo + off:hi + off, :] * x[..., lo:hi, :]).sum(-1)
-                rows.append(g)
-            gband = _sum_to_shape(torch.stack(rows, dim=-2), band.shape)
+            # d/dband[d,i] = sum_c gy[i,c] x[i+off,c]  (trans: x[i,c] gy[i+off,c]) — one streaming HIP kernel
+            gband = _BandGrad.apply(x, gy, tuple(band.shape)) if ctx.trans else \
+                _BandGrad.apply(gy, x, tuple(band.shape))
         return gband, gx, None
+
+
+class _BandGrad(torch.autograd.Function):
+    """G[..., d, i] = sum_c u[..., i, c] w[..., i+d-hb, c] reduced to the band's shape (xk_banded_grad): the
+    gradient of the banded apply w.r.t. the DIA storage — what `torch.autograd.grad(loss, params, v)` of
+    solve_torchfcn.backward (xitorch/linalg/solve.py:188-195) asks of a banded operator.  Bilinear: its
+    backward is two banded applies with G as the band."""
+
+    @staticmethod
+    def forward(ctx, u, w, band_shape):
+        ctx.save_for_backward(u, w)
+        nd, n = band_shape[-2:]
+        nb, FB, keep, fold = _batch_plan(band_shape[:-2], u.shape[:-2], w.shape[:-2])
+        up, wp = _to_panel(u, nb, FB, keep, fold), _to_panel(w, nb, FB, keep, fold)
+        g = _k.banded_grad(up, wp, nd)                                  # (nkeep, nd, n): folded dims summed
+        return g.reshape(*[FB[d] for d in keep], nd, n).reshape(band_shape)
+
+    @staticmethod
+    def backward(ctx, gg):
+        u, w = ctx.saved_tensors
+        gu = gw = None
+        if ctx.needs_input_grad[0]:
+            gu = _sum_to_shape(_BandedMM.apply(gg, w, False), u.shape)
+        if ctx.needs_input_grad[1]:
+            gw = _sum_to_shape(_BandedMM.apply(gg, u, True), w.shape)
+        return gu, gw, None
 
 
 def _banded_native(band, x, trans):
@@ -618,6 +712,12 @@ class BandedLinearOperator(LinearOperator):
 
 
 # ------------------------------------------------------------------------ helpers
+def _storage_token(t):
+    """Identity of a tensor's contents as far as it can be known without reading them: storage address,
+    view geometry and the in-place version counter."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
+
+
 def _is_hermitian_matrix(mat):
     """-> (hermitian within torch.allclose like the reference's check, exactly hermitian bit for bit)."""
     if mat.shape[-2] != mat.shape[-1]:
