@@ -237,6 +237,28 @@ int xk_kry_status_f64(const double* Prr, const double* stop, double* rnorm, doub
 int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double* status, int S, int nblk,
                       void* stream);
 
+/* ---- fused BLAS-1 of the quasi-Newton (Broyden) driver -------------------------------------------------
+ * The reference's _nonlin_solver / LowRankMatrix (xitorch/_impls/optimize/root/rootsolver.py:96-143,
+ * _jacobian.py:99-119,172-189) run torch.dot / .norm() / axpy chains on one flat length-L vector with a host sync
+ * after almost every one.
+ * xk_vec_dots: out[i] = <a_i, b_i>, i < npairs <= 4, in one streaming pass + a fixed-order device fold (double
+ *   results; `partials`: scratch of xk_vec_dots_workspace_elems() doubles).  Replaces the y.norm(), dx.norm(),
+ *   x.norm(), torch.dot calls of rootsolver.py:100,113,286-290,375-380 — the driver reads them with ONE sync.
+ * xk_broyden_axpy: out = g0*u0 + g1*u1 + gamma * sum_{n<k} coef[n]*scale[n] * V[n*ldv + :]  (u0/u1/scale may be
+ *   NULL; out must not alias V).  Replaces LowRankMatrix.mv/rmv's Python loop of axpys (_jacobian.py:172-182) and
+ *   the update formulas of BroydenFirst/Second (_jacobian.py:112-119,132-137); `scale[n]` carries 1/<dy_n, v_n>. */
+long xk_vec_dots_workspace_elems(void);
+int xk_vec_dots_f64(const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
+                    const double* b2, const double* a3, const double* b3, int npairs, long L, double* partials,
+                    long npart, double* out, void* stream);
+int xk_vec_dots_f32(const float* a0, const float* b0, const float* a1, const float* b1, const float* a2,
+                    const float* b2, const float* a3, const float* b3, int npairs, long L, double* partials,
+                    long npart, double* out, void* stream);
+int xk_broyden_axpy_f64(double* out, const double* u0, double g0, const double* u1, double g1, const double* V,
+                        long ldv, const double* coef, const double* scale, int k, double gamma, long L, void* stream);
+int xk_broyden_axpy_f32(float* out, const float* u0, double g0, const float* u1, double g1, const float* V, long ldv,
+                        const float* coef, const float* scale, int k, double gamma, long L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

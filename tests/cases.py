@@ -170,3 +170,44 @@ def root_inputs(case):
     A = syn.root_matrix(case["nbatch"], case["n"]) * 2.0   # eigenvalues in (0, 1]
     y0 = torch.zeros((case["nbatch"], case["n"]), dtype=f64)
     return tanh_fcn_batched, y0, (A,)
+
+
+# ------------------------------------------------------------------ "next" optimiser methods
+def fixed_point_fcn(y, A):
+    # equilibrium problem y = f(y): a contraction built on the config-4 matrices
+    return torch.tanh(torch.einsum("bij,bj->bi", A, y) * 0.4 + 0.1)
+
+
+def quartic_objective(y, A):
+    # minimisation problem for gd / adam: f(y) = sum_b [ 1/2 y^T A_b y + 1/4 |y|^4 - <c, y> ], returns (f, df/dy)
+    c = torch.linspace(-1.0, 1.0, y.shape[-1], dtype=y.dtype, device=y.device)
+    Ay = torch.einsum("bij,bj->bi", A, y)
+    f = 0.5 * (y * Ay).sum() + 0.25 * (y ** 4).sum() - (c * y).sum()
+    g = 0.5 * (Ay + torch.einsum("bji,bj->bi", A, y)) + y ** 3 - c
+    return f, g
+
+
+EXTRA_CASES = [
+    # reference: xitorch/_impls/optimize/equilibrium.py:9-134
+    dict(name="anderson_b3_n40", method="anderson_acc", nbatch=3, n=40,
+         kwargs=dict(msize=5, beta=1.0, lmbda=1e-4, f_tol=1e-10, x_tol=1e-10, maxiter=200)),
+    dict(name="anderson_b2_n24_damped", method="anderson_acc", nbatch=2, n=24,
+         kwargs=dict(msize=3, beta=0.7, lmbda=1e-6, f_tol=1e-9, x_tol=1e-9, maxiter=300)),
+    # reference: xitorch/_impls/optimize/minimizer.py:5-147
+    dict(name="gd_b2_n32", method="gd", nbatch=2, n=32,
+         kwargs=dict(step=5e-2, gamma=0.8, maxiter=600, f_rtol=1e-12, x_rtol=1e-10)),
+    dict(name="adam_b2_n32", method="adam", nbatch=2, n=32,
+         kwargs=dict(step=5e-2, beta1=0.9, beta2=0.99, maxiter=500, f_rtol=1e-12, x_rtol=1e-9)),
+    # reference: rootsolver.py:151-174 + NewtonJacobian (_jacobian.py:27-49)
+    dict(name="newton_b3_n20", method="newton", nbatch=3, n=20, kwargs=dict(f_tol=1e-10, x_tol=1e-10, maxiter=50)),
+]
+
+
+def extra_inputs(case):
+    A = syn.root_matrix(case["nbatch"], case["n"]) * 2.0          # symmetric, eigenvalues in (0, 1]
+    y0 = torch.zeros((case["nbatch"], case["n"]), dtype=f64)
+    if case["method"] == "anderson_acc":
+        return fixed_point_fcn, y0, (A,)
+    if case["method"] in ("gd", "adam"):
+        return quartic_objective, y0 + 0.1, (A,)
+    return tanh_fcn_batched, y0, (A,)

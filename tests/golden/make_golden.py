@@ -173,12 +173,55 @@ def gen_root():
         save("root_" + name, **out)
 
 
+# --------------------------------------------------------------------------- anderson_acc / gd / adam / newton
+def gen_extra():
+    """SURVEY 8f.2 methods.  These are short host loops of torch ops, so the product implementation itself
+    (xitorch_amd.optimize.extra / native_root.newton) runs on CPU tensors and is compared BIT FOR BIT with the
+    reference here; the fixtures then pin the same functions running on the GPU (tests/test_gpu_root.py)."""
+    from xitorch._impls.optimize import equilibrium as ref_eq, minimizer as ref_min
+    from xitorch_amd.optimize import extra as xextra, native_root as xroot
+    for case in cases.EXTRA_CASES:
+        name, meth = case["name"], case["method"]
+        fcn, y0, params = cases.extra_inputs(case)
+        kw = dict(case["kwargs"])
+        ref_fn = {"anderson_acc": ref_eq.anderson_acc, "gd": ref_min.gd, "adam": ref_min.adam,
+                  "newton": ref_root.newton}[meth]
+        own_fn = {"anderson_acc": xextra.anderson_acc, "gd": xextra.gd, "adam": xextra.adam,
+                  "newton": xroot.newton}[meth]
+        counts = []
+        outs = []
+        for fn_ in (ref_fn, own_fn):
+            n = [0]
+
+            def cfcn(y, *p):
+                n[0] += 1
+                return fcn(y, *p)
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter("always")
+                outs.append(fn_(cfcn, y0, list(params), **kw))
+            # the cases must converge: a convergence warning is a bad case
+            assert not [w for w in wlist if "converge" in str(w.message)], (name, [str(w.message) for w in wlist])
+            counts.append(n[0])
+        exact(outs[0], outs[1], name)
+        assert counts[0] == counts[1], (name, counts)
+        y = outs[0]
+        if meth == "anderson_acc":
+            quality = (fcn(y, *params) - y).norm()
+        elif meth == "newton":
+            quality = fcn(y, *params).norm()
+        else:
+            quality = fcn(y, *params)[1].norm()
+        save("extra_" + name, y=y, nfev=counts[0], quality=quality)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["davidson", "solve", "root"]
+    which = sys.argv[1:] or ["davidson", "solve", "root", "extra"]
     if "davidson" in which:
         gen_davidson()
     if "solve" in which:
         gen_solve()
     if "root" in which:
         gen_root()
+    if "extra" in which:
+        gen_extra()
     print("golden fixtures written; reference =", xitorch.__version__, "torch", torch.__version__)

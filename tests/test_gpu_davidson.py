@@ -275,3 +275,50 @@ def test_rank_deficient_start_block_raises(dev):
     K.panel_chol(torch.eye(3, dtype=torch.float64).repeat(2, 1, 1).to(dev), W, info, 3)
     assert info.tolist() == [0, 2]
     assert torch.allclose(W.cpu(), torch.eye(3, dtype=torch.float64).repeat(2, 1, 1))
+
+
+@pytest.mark.parametrize("withM", [False, True])
+def test_panel_orthogonalisation_vs_reference_tallqr(dev, withM):
+    """Row a5 directly: block Gram-Schmidt(x2) + panel CholeskyQR (native) against the reference's full CholeskyQR
+    `tallqr(cat(V, t))` (oracle.symeig.tallqr == xitorch/_utils/tensor.py:8-19): same Q column by column up to
+    rounding, orthonormal to working precision; then a NEARLY dependent residual block, where the reference's one-shot
+    CholeskyQR of the whole basis loses orthogonality like cond^2 * eps — the native path must be no worse."""
+    from xitorch_amd.linalg.native_eig import tallqr_extend
+    g = torch.Generator().manual_seed(41)
+    B, N, k, p = 3, 500, 18, 6
+    Mmat = None
+    if withM:
+        R = torch.rand(B, N, N, dtype=torch.float64, generator=g)
+        Mmat = 0.02 * (R + R.transpose(-2, -1)) + torch.eye(N, dtype=torch.float64)
+    V0 = torch.randn(B, N, k, dtype=torch.float64, generator=g)
+    V, _ = osym.tallqr(V0, torch.matmul(Mmat, V0) if withM else None)            # (M-)orthonormal basis
+    t = torch.randn(B, N, p, dtype=torch.float64, generator=g) + 0.5 * V[..., :p]  # a block with components along V
+    full = torch.cat([V, t], dim=-1)
+    Qref, _ = osym.tallqr(full, torch.matmul(Mmat, full) if withM else None)
+    Mop = xa.LinearOperator.m(Mmat.to(dev), True) if withM else None
+    Q = tallqr_extend(V.to(dev), t.to(dev), M=Mop).cpu()
+    assert torch.equal(Q[..., :k], V)                                             # the old basis is untouched
+    assert (Q[..., k:] - Qref[..., k:]).abs().max().item() < 1e-11                # same vectors, same signs
+    MQ = torch.matmul(Mmat, Q) if withM else Q
+    eye = torch.eye(k + p, dtype=torch.float64)
+    assert (torch.matmul(Q.transpose(-2, -1), MQ) - eye).abs().max().item() < 1e-13
+    # nearly dependent block: column 1 = column 0 + 1e-6 * noise
+    t2 = t.clone()
+    t2[..., 1] = t2[..., 0] + 1e-6 * torch.randn(B, N, dtype=torch.float64, generator=g)
+    full2 = torch.cat([V, t2], dim=-1)
+    Qr2, _ = osym.tallqr(full2, torch.matmul(Mmat, full2) if withM else None)
+    Q2 = tallqr_extend(V.to(dev), t2.to(dev), M=Mop).cpu()
+    MQ2 = torch.matmul(Mmat, Q2) if withM else Q2
+    MQr2 = torch.matmul(Mmat, Qr2) if withM else Qr2
+    loss_native = (torch.matmul(Q2.transpose(-2, -1), MQ2) - eye).abs().max().item()
+    loss_ref = (torch.matmul(Qr2.transpose(-2, -1), MQr2) - eye).abs().max().item()
+    assert loss_native <= max(10.0 * loss_ref, 1e-12), (loss_native, loss_ref)
+    # both span the same space: projector difference at the level of the lost orthogonality
+    P1 = torch.matmul(Q2, MQ2.transpose(-2, -1))
+    P2 = torch.matmul(Qr2, MQr2.transpose(-2, -1))
+    assert (P1 - P2).abs().max().item() < 1e3 * max(loss_ref, loss_native, 1e-13)
+    # an exactly dependent block is refused, like torch.linalg.cholesky does in the reference
+    t3 = t.clone()
+    t3[..., 2] = 0.0
+    with pytest.raises(RuntimeError):
+        tallqr_extend(V.to(dev), t3.to(dev), M=Mop)

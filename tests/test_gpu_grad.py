@@ -49,7 +49,7 @@ def test_banded_grad_kernel_vs_torch(dev, dtype, tol, B, N, hb, C):
     # accumulate = True adds into the output
     out2 = out.clone()
     K.banded_grad(Ud, Wd, nd, out=out2, accumulate=True)
-    assert torch.allclose(out2, 2 * out, rtol=1e-6 if dtype == torch.float32 else 1e-14, atol=0)
+    assert (out2 - 2 * out).abs().max().item() <= 4 * tol * scale * C
 
 
 @pytest.mark.parametrize("dtype,tol", [(f64, 1e-13), (torch.float32, 2e-5)])
@@ -64,7 +64,8 @@ def test_dense_outer_kernel_vs_torch(dev, dtype, tol, B, M, N, C):
     assert (out.double().cpu() - ref).abs().max().item() <= tol * ref.abs().max().item() * C
     out2 = out.clone()
     K.dense_outer(U.to(dev, dtype), W.to(dev, dtype), out=out2, accumulate=True)
-    assert torch.allclose(out2, 2 * out, rtol=1e-6 if dtype == torch.float32 else 1e-14, atol=0)
+    # (C > 8 runs as two accumulating passes, so the sums associate differently: rounding-level agreement)
+    assert (out2 - 2 * out).abs().max().item() <= 4 * tol * ref.abs().max().item() * C
 
 
 def test_dense_and_banded_apply_gradients_any_order(dev):
@@ -183,7 +184,7 @@ def test_fullsize_config3_bicgstab_implicit_backward(dev):
         # a random part and a part aligned with the gradient's sign pattern (so that <g, D> is far above the noise
         # floor of the two solves: |loss error| <= |w| |dx| ~ 1e-5, divided by 2 eps)
         D = torch.empty_like(gband).uniform_(-1.0, 1.0, generator=gen).add_(torch.sign(gband), alpha=0.2).mul_(0.05)
-        an = torch.dot(gband.reshape(-1), D.reshape(-1)).item()
+        an = sum((gband[b] * D[b]).sum().item() for b in range(B))          # (torch.dot stops at 2^31 elements)
         eps = 1e-3
         bd = band.detach()
         bd.add_(D, alpha=eps)

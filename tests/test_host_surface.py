@@ -431,3 +431,35 @@ def test_symmetric_storage_promise_follows_the_tensor():
     near[0, 1, 2] += 1e-12
     A3 = xa.LinearOperator.m(near)
     assert A3.is_hermitian and A3.hermitian_verified and not A3.symmetric_storage
+
+
+def _run_extra(case, device):
+    import xitorch_amd.optimize.extra as xextra
+    from xitorch_amd.optimize import native_root as xroot
+    from tests import cases as _cases
+    fcn, y0, params = _cases.extra_inputs(case)
+    fn = {"anderson_acc": xextra.anderson_acc, "gd": xextra.gd, "adam": xextra.adam, "newton": xroot.newton}[case["method"]]
+    n = [0]
+
+    def cfcn(y, *p):
+        n[0] += 1
+        return fcn(y, *p)
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", message=".*converge.*")
+        y = fn(cfcn, y0.to(device), [p.to(device) for p in params], **case["kwargs"])
+    return y.detach(), n[0]
+
+
+def test_extra_methods_match_reference_goldens_on_cpu():
+    """anderson_acc / gd / adam / newton are short host loops of torch ops: on CPU tensors they must
+    reproduce the reference's outputs (tests/golden/extra_*.npz, written by make_golden.py after a bit-for-bit
+    comparison with xitorch/_impls/optimize/{equilibrium,minimizer}.py and root/rootsolver.py:151-174)."""
+    import os
+    import numpy as np
+    from tests import cases as _cases
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    for case in _cases.EXTRA_CASES:
+        gold = np.load(os.path.join(gold_dir, "extra_%s.npz" % case["name"]))
+        y, nfev = _run_extra(case, "cpu")
+        assert nfev == int(gold["nfev"]), (case["name"], nfev, int(gold["nfev"]))
+        assert np.abs(y.detach().numpy() - gold["y"]).max() <= 1e-12, case["name"]

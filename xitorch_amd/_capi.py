@@ -85,6 +85,10 @@ def _declare(L):
         sigs["xk_kry_status_" + sfx] = (I, [P] * 4 + [I, I, P])
         sigs["xk_banded_grad_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
         sigs["xk_dense_outer_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, P])
+    sigs["xk_vec_dots_workspace_elems"] = (Lg, [])
+    for sfx in ("f64", "f32"):
+        sigs["xk_vec_dots_" + sfx] = (I, [P] * 8 + [I, Lg, P, Lg, P, P])
+        sigs["xk_broyden_axpy_" + sfx] = (I, [P, P, D, P, D, P, Lg, P, P, I, D, Lg, P])
     for name, (res, args) in sigs.items():
         if not hasattr(L, name):
             continue  # reported by the symbol test, and by check() at call time

@@ -252,6 +252,55 @@ def dense_outer(U, W, out=None, accumulate=False):
     return out
 
 
+# --------------------------------------------------------------------------- fused BLAS-1 of the Broyden driver
+_vd_scratch = {}
+
+
+def vec_dots(pairs, out=None):
+    """out[i] = <a_i, b_i> for up to 4 pairs of equal-length contiguous device vectors, one streaming pass and a
+    deterministic device-side fold.  Returns a float64 device tensor of len(pairs) entries — NO host sync; read it
+    with a single `.tolist()` when the values are needed (rootsolver.py:100,113,286-290,375-380 take one sync each)."""
+    a0 = pairs[0][0]
+    require_device(a0, "vector")
+    L = a0.numel()
+    np_ = len(pairs)
+    if not 1 <= np_ <= 4:
+        raise _capi.NativeLibraryError("vec_dots takes 1..4 pairs")
+    flat = []
+    for (a, b) in pairs:
+        if a.numel() != L or b.numel() != L or a.dtype != a0.dtype or b.dtype != a0.dtype or \
+                not a.is_contiguous() or not b.is_contiguous():
+            raise _capi.NativeLibraryError("vec_dots: vectors must be contiguous, of one length and dtype")
+        flat += [a, b]
+    while len(flat) < 8:
+        flat.append(None)
+    key = (a0.device, torch.cuda.current_stream().cuda_stream)
+    scratch = _vd_scratch.get(key)
+    nws = fn("xk_vec_dots_workspace_elems")()
+    if scratch is None:
+        scratch = torch.empty(nws, dtype=torch.float64, device=a0.device)
+        _vd_scratch[key] = scratch
+    if out is None:
+        out = torch.empty(np_, dtype=torch.float64, device=a0.device)
+    rc = fn("xk_vec_dots_" + suffix(a0.dtype))(*[ptr(t) for t in flat], np_, L, ptr(scratch), nws, ptr(out), stream_ptr())
+    check(rc, "xk_vec_dots")
+    return out
+
+
+def broyden_axpy(out, u0=None, g0=0.0, u1=None, g1=0.0, V=None, coef=None, scale=None, k=0, gamma=1.0):
+    """out = g0*u0 + g1*u1 + gamma * sum_{n<k} coef[n]*scale[n] * V[n]   (flat length-L vectors; V (>=k, ldv) rows).
+    The low-rank apply and the rank-1 update of the Broyden inverse-Jacobian model (_jacobian.py:112-119,172-182)."""
+    require_device(out, "vector")
+    L = out.numel()
+    ldv = V.stride(-2) if (V is not None and k > 0) else 0
+    rc = fn("xk_broyden_axpy_" + suffix(out.dtype))(ptr(out), ptr(u0), float(g0), ptr(u1), float(g1),
+                                                     ptr(V) if k > 0 else ptr(None), ldv,
+                                                     ptr(coef) if k > 0 else ptr(None), ptr(scale), int(k), float(gamma),
+                                                     L, stream_ptr())
+    check(rc, "xk_broyden_axpy")
+    return out
+
+
 # --------------------------------------------------------------------------- CU-masked stream
 _MASKED_STREAMS = {}
 

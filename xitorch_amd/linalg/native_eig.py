@@ -32,7 +32,7 @@ from xitorch_amd._util import bcast_shape
 from xitorch_amd.linalg._panel import PanelOperator, pad_len
 from xitorch_amd.dist import allreduce_max_
 
-__all__ = ["davidson", "exacteig", "take_eigpairs"]
+__all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend"]
 
 
 def take_eigpairs(evals, evecs, neig, mode):
@@ -247,6 +247,34 @@ class _Group:
         self.extend_T(k, nadd)
         end()
         self.k = k + nadd
+
+
+def tallqr_extend(V, t, M=None, orth_passes=2):
+    """Orthonormal extension of a basis on the device: given ``V (B, N, k)`` with (M-)orthonormal columns and a new
+    block ``t (B, N, p)``, return ``Q (B, N, k+p)`` whose first k columns are V and whose last p columns span
+    ``t`` minus its components along V, (M-)orthonormal — what the reference obtains from the full CholeskyQR
+    ``tallqr(cat(V, t))`` (xitorch/_utils/tensor.py:8-19, _impls/linalg/symeig.py:207-220), computed here like in
+    the Davidson loop: block Gram–Schmidt (``orth_passes`` times) of the new panel against the basis + CholeskyQR of
+    the panel alone.  In exact arithmetic the two agree column by column, since
+    chol([[I, C], [C^T, G]]) = [[I, C], [0, chol(G - C^T C)]].  Raises RuntimeError when the panel Gram matrix is
+    not positive definite (the reference raises from torch.linalg.cholesky)."""
+    B, N, k = V.shape
+    p = t.shape[-1]
+    dev, dtype = V.device, V.dtype
+    opM = _PanelOperator(M, [B], B, N) if M is not None else None
+    grp = _Group(None, opM, B, N, _pad(N, dtype), p, k, dtype, dev, "lowest", "native", orth_passes)
+    grp.grow(k + p)
+    grp.Vs[:, :k, :N].copy_(V.transpose(-2, -1))
+    grp.Vs[:, k:k + p, :N].copy_(t.transpose(-2, -1))
+    if opM is not None:
+        opM.apply(grp.Vs[:, :k], grp.MVs[:, :k])
+    for _ in range(max(1, orth_passes)):
+        grp.project_out(k, p)
+    grp.cholqr(k, p)
+    if int(grp.info.max().item()) != 0:
+        raise RuntimeError("xitorch_amd tallqr_extend: the panel Gram matrix is not positive definite "
+                           "(linearly dependent vectors)")
+    return grp.Vs[:, :k + p, :N].transpose(-2, -1)
 
 
 def _sub_operator(A, B, N, b0, b1):

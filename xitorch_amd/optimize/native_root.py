@@ -14,9 +14,14 @@ c_n, d_n as Python lists and applies G with a Python loop of rank x (torch.dot +
     G v   = alpha v + C^T (D v)      ->  one multi-dot  (xk_dense_mm, split-contraction path)
     G^T v = alpha v + D^T (C v)          + one multi-axpy (xk_lincomb)
 
-so an apply is two streaming passes over 2*rank*L elements regardless of the rank.  With a
-``process_group`` the flat vector is sharded over the ranks (batch sharding) and every inner
-product / norm is completed by ONE small all-reduce(SUM) (RCCL) — the rank-vector of the
+so an apply is two streaming passes over 2*rank*L elements regardless of the rank; the rank-1
+update writes v = G^T dx and c = dx - G dy straight into the new rows of the buffers, and the
+division d = v / <dy, v> (_jacobian.py:118) is a per-term scalar applied to the multi-dot's
+coefficients, never a pass over L.  The driver's norms and dot products (rootsolver.py:100,113,
+286-290,375-380) come from the fused reduction xk_vec_dots: an outer iteration whose first trial
+step is accepted reads {|f|^2, |dx|^2, |x|^2} with ONE host sync (the reference: about eight).
+With a ``process_group`` the flat vector is sharded over the ranks (batch sharding) and every
+group of inner products is completed by ONE small all-reduce(SUM) (RCCL) — the rank-vector of the
 multi-dot travels as a single message.
 """
 import warnings
@@ -31,8 +36,14 @@ __all__ = ["broyden1", "broyden2", "linearmixing", "newton"]
 
 
 # ------------------------------------------------------------------------------ reductions
+def _native_vec(t):
+    return t.is_cuda and t.dtype in (torch.float64, torch.float32)
+
+
 class _Reduce:
-    """Global inner products of (possibly sharded) flat vectors."""
+    """Global inner products of (possibly sharded) flat vectors.  Device vectors go through the fused HIP
+    reduction (several products per pass, result left on the device); host vectors — the driver itself is
+    device-agnostic and also serves CPU callers of newton / linearmixing — through torch."""
 
     def __init__(self, group):
         self.group = group
@@ -40,13 +51,24 @@ class _Reduce:
     def _sum(self, t):
         return allreduce_sum_(t, self.group)
 
+    def dots_dev(self, pairs):
+        """device tensor (float64) of <a_i, b_i>, all-reduced over the group; no host sync"""
+        a0 = pairs[0][0]
+        if _native_vec(a0):
+            t = K.vec_dots([(a.reshape(-1), b.reshape(-1)) for a, b in pairs])
+        else:
+            t = torch.stack([torch.dot(a.reshape(-1), b.reshape(-1)).double() for a, b in pairs])
+        return self._sum(t)
+
+    def dots(self, pairs):
+        """the same as host floats: ONE sync for all of them"""
+        return self.dots_dev(pairs).tolist()
+
     def dot(self, a, b):
-        return self._sum(torch.dot(a, b).reshape(1))[0]
+        return self.dots_dev([(a, b)])[0]
 
     def norm(self, a):
-        if self.group is None:
-            return a.norm()
-        return torch.sqrt(self._sum(torch.dot(a, a).reshape(1))[0])
+        return torch.sqrt(self.dots_dev([(a, a)])[0])
 
     def total_numel(self, a):
         if self.group is None:
@@ -55,10 +77,18 @@ class _Reduce:
         return int(self._sum(t).item())
 
 
+def _axpy(u0, g0, u1=None, g1=0.0):
+    """g0*u0 + g1*u1 as a new flat vector (native kernel on the device)."""
+    if _native_vec(u0) and u0.is_contiguous() and (u1 is None or u1.is_contiguous()):
+        return K.broyden_axpy(torch.empty_like(u0), u0, g0, u1, g1)
+    return u0 * g0 if u1 is None else u0 * g0 + u1 * g1
+
+
 # ------------------------------------------------------------------------------ low-rank model
 class _LowRank:
-    """G = alpha*I + sum_n c_n d_n^T in two growing device buffers (reference: LowRankMatrix /
-    FullRankMatrix, _jacobian.py:156-222)."""
+    """G = alpha*I + sum_n c_n d_n^T with d_n = v_n * inv_n, in two growing device buffers (rows c_n / v_n) and
+    a device vector of the per-term scalars inv_n (reference: LowRankMatrix / FullRankMatrix,
+    _jacobian.py:156-222, where c_n, d_n are Python lists and every apply loops over them)."""
 
     def __init__(self, alpha, uv0, L, dtype, device, red, total_L):
         if device.type != "cuda":
@@ -73,10 +103,10 @@ class _LowRank:
         self.cap, self.rank = 8, 0
         self.C = torch.zeros((1, self.cap, self.Lp), dtype=dtype, device=device)
         self.D = torch.zeros((1, self.cap, self.Lp), dtype=dtype, device=device)
+        self.dinv = torch.ones((self.cap,), dtype=dtype, device=device)
         self.dense = None
-        self._buf = torch.zeros((1, 1, self.Lp), dtype=dtype, device=device)
         if uv0 is not None:
-            self.append(uv0[0], uv0[1])
+            self.append_rows(uv0[0], uv0[1], None)
 
     def _grow(self):
         new = self.cap * 2
@@ -85,55 +115,78 @@ class _LowRank:
             buf = torch.zeros((1, new, self.Lp), dtype=self.dtype, device=self.device)
             buf[:, :self.cap].copy_(old)
             setattr(self, name, buf)
-        self.cap = new
+        dn = torch.ones((new,), dtype=self.dtype, device=self.device)
+        dn[:self.cap].copy_(self.dinv)
+        self.dinv, self.cap = dn, new
 
-    def _apply(self, first, second, v):
-        # alpha v + second^T (first v)
-        if self.dense is not None:
-            raise AssertionError
-        L = self.L
-        vin = self._buf
-        vin[0, 0, :L].copy_(v)
-        out = torch.zeros((1, 1, self.Lp), dtype=self.dtype, device=self.device)
-        out[0, 0, :L].copy_(v)
-        if self.rank == 0:
-            return out[0, 0, :L] * self.alpha
-        coef = K.dense_mm(first[:, :self.rank, :L], vin[:, :, :L])          # (1, 1, rank): <first_n, v>
+    def _vec(self, v):
+        """(1, 1, L) view of a flat vector for the multi-dot (contiguous, 16 B aligned rows)"""
+        v = v.reshape(-1)
+        if not v.is_contiguous():
+            v = v.contiguous()
+        return v.reshape(1, 1, -1)
+
+    def _coef(self, rows, v):
+        """coefficients <rows_n, v> for n < rank, all-reduced over the shards: one multi-dot (K1, split-contraction)"""
+        coef = K.dense_mm(rows[:, :self.rank, :self.L], self._vec(v))          # (1, 1, rank)
         if self.red.group is not None:
             self.red._sum(coef)
-        K.lincomb(second, coef, out, self.rank, 1, coef_layout="ca", alpha=1.0, beta=self.alpha)
-        return out[0, 0, :L]
+        return coef
 
-    def mv(self, v):
+    def apply_into(self, out, v, transpose=False, g_v=None, extra=None, g_extra=0.0, gamma=1.0):
+        """out = g_v * v + g_extra * extra + gamma * (low-rank part of G (or G^T)) v.
+        G v = alpha v + sum_n c_n inv_n <v_n, v>;  G^T v = alpha v + sum_n v_n inv_n <c_n, v>."""
+        first, second = (self.C, self.D) if transpose else (self.D, self.C)
+        v = v.reshape(-1)
+        if self.rank == 0:
+            return K.broyden_axpy(out, v, g_v, extra, g_extra)
+        coef = self._coef(first, v)
+        return K.broyden_axpy(out, v, g_v, extra, g_extra, V=second[0], coef=coef, scale=self.dinv, k=self.rank,
+                              gamma=gamma)
+
+    def mv(self, v, sign=1.0):
         if self.dense is not None:
-            return torch.matmul(self.dense, v)
-        return self._apply(self.D, self.C, v)
+            return torch.matmul(self.dense, v) * sign
+        out = torch.empty(self.L, dtype=self.dtype, device=self.device)
+        return self.apply_into(out, v, False, g_v=sign * self.alpha, gamma=sign)
 
     def rmv(self, v):
         if self.dense is not None:
             return torch.matmul(self.dense.T, v)
-        return self._apply(self.C, self.D, v)
+        out = torch.empty(self.L, dtype=self.dtype, device=self.device)
+        return self.apply_into(out, v, True, g_v=self.alpha)
 
-    def append(self, c, d):
-        if self.dense is not None:                                    # FullRankMatrix.append
-            self.dense += torch.outer(c, d)
-            return
+    def new_rows(self):
+        """views of the next free rows of C and D (growing the buffers when full)"""
         if self.rank == self.cap:
             self._grow()
-        self.C[0, self.rank, :self.L].copy_(c)
-        self.D[0, self.rank, :self.L].copy_(d)
+        return self.C[0, self.rank, :self.L], self.D[0, self.rank, :self.L]
+
+    def commit(self, inv):
+        """the rows handed out by new_rows() are filled: make them term number `rank`; inv: device scalar or None (= 1)"""
+        if inv is None:
+            self.dinv[self.rank] = 1.0
+        else:
+            self.dinv[self.rank] = inv.to(self.dtype)
         self.rank += 1
-        if self.rank >= self.total_L and self.red.group is None:       # _jacobian.py:187-188
+        if self.rank >= self.total_L and self.red.group is None:       # _jacobian.py:187-188: dense from here on
             n = self.L
             mat = torch.eye(n, dtype=self.dtype, device=self.device) * self.alpha
-            mat += torch.matmul(self.C[0, :self.rank, :n].T, self.D[0, :self.rank, :n])
+            mat += torch.matmul(self.C[0, :self.rank, :n].T, self.D[0, :self.rank, :n] * self.dinv[:self.rank, None])
             self.dense = mat
+
+    def append_rows(self, c, v, inv):
+        if self.dense is not None:                                    # FullRankMatrix.append
+            self.dense += torch.outer(c, v if inv is None else v * inv.to(self.dtype))
+            return
+        crow, drow = self.new_rows()
+        crow.copy_(c)
+        drow.copy_(v)
+        self.commit(inv)
 
     def reduce(self, max_rank):
         # "restart": forget everything once the rank EXCEEDS max_rank (checked before appending)
         if self.dense is None and self.rank > max_rank:
-            self.C[:, :self.rank].zero_()
-            self.D[:, :self.rank].zero_()
             self.rank = 0
 
 
@@ -149,8 +202,9 @@ class _BroydenFirst:
         if self.max_rank is None:
             self.max_rank = float("inf")
         if self.alpha is None:                                        # _jacobian.py:76-82 (Q2)
-            ny0 = float(red.norm(y0))
-            self.alpha = 0.5 * max(float(red.norm(x0)), 1.0) / ny0 if ny0 else 1.0
+            y2, x2 = red.dots([(y0, y0), (x0, x0)])
+            ny0 = y2 ** 0.5
+            self.alpha = 0.5 * max(x2 ** 0.5, 1.0) / ny0 if ny0 else 1.0
         if isinstance(self.uv0, str) and self.uv0 == "svd":
             self.uv0 = _svd_uv0(func, x0)
         self.Gm = _LowRank(-float(self.alpha), self.uv0, x0.numel(), x0.dtype, x0.device, red,
@@ -159,18 +213,27 @@ class _BroydenFirst:
     def solve(self, v, tol=0):
         return self.Gm.mv(v)
 
+    def neg_solve(self, v, tol=0):
+        """-G v in one pass (the driver's dx = -jacobian.solve(y), rootsolver.py:98)"""
+        return self.Gm.mv(v, sign=-1.0)
+
     def update(self, x, y):
-        dy = y - self.y_prev
-        dx = x - self.x_prev
+        dy = _axpy(y, 1.0, self.y_prev, -1.0)
+        dx = _axpy(x, 1.0, self.x_prev, -1.0)
         self._update(dx, dy)
         self.y_prev, self.x_prev = y, x
 
     def _update(self, dx, dy):
-        self.Gm.reduce(self.max_rank)
-        v = self.Gm.rmv(dx)
-        c = dx - self.Gm.mv(dy)
-        d = v / self.red.dot(dy, v)
-        self.Gm.append(c, d)
+        Gm = self.Gm
+        Gm.reduce(self.max_rank)
+        if Gm.dense is not None:
+            v = Gm.rmv(dx)
+            Gm.append_rows(dx - Gm.mv(dy), v, 1.0 / self.red.dot(dy, v))
+            return
+        crow, vrow = Gm.new_rows()
+        Gm.apply_into(vrow, dx, transpose=True, g_v=Gm.alpha)                                  # v = G^T dx
+        Gm.apply_into(crow, dy, transpose=False, g_v=-Gm.alpha, extra=dx, g_extra=1.0, gamma=-1.0)   # c = dx - G dy
+        Gm.commit(1.0 / self.red.dot(dy, vrow))                                                # d = v / <dy, v>
 
     @property
     def rank(self):
@@ -181,10 +244,16 @@ class _BroydenSecond(_BroydenFirst):
     """reference: BroydenSecond, _jacobian.py:121-137."""
 
     def _update(self, dx, dy):
-        self.Gm.reduce(self.max_rank)
-        c = dx - self.Gm.mv(dy)
-        dyn = self.red.norm(dy)
-        self.Gm.append(c, dy / (dyn * dyn))
+        Gm = self.Gm
+        Gm.reduce(self.max_rank)
+        inv = 1.0 / self.red.dot(dy, dy)                              # d = dy / |dy|^2
+        if Gm.dense is not None:
+            Gm.append_rows(dx - Gm.mv(dy), dy, inv)
+            return
+        crow, vrow = Gm.new_rows()
+        Gm.apply_into(crow, dy, transpose=False, g_v=-Gm.alpha, extra=dx, g_extra=1.0, gamma=-1.0)   # c = dx - G dy
+        vrow.copy_(dy)
+        Gm.commit(inv)
 
 
 class _LinearMixing:
@@ -236,55 +305,75 @@ def _svd_uv0(func, x0):
 
 
 # ------------------------------------------------------------------------------ line search
-def _armijo(phi, phi0, derphi0, c1=1e-4, alpha0=1.0, amin=0.0, max_niter=20):
-    """Backtracking with quadratic then cubic interpolation (reference: _scalar_search_armijo,
-    rootsolver.py:312-357).  Scalars are host floats."""
-    phi_a0 = phi(alpha0)
-    if phi_a0 <= phi0 + c1 * alpha0 * derphi0:
-        return alpha0, phi_a0
-    alpha1 = -(derphi0) * alpha0 ** 2 / 2.0 / (phi_a0 - phi0 - derphi0 * alpha0)
-    phi_a1 = phi(alpha1)
-    if phi_a1 <= phi0 + c1 * alpha1 * derphi0:
-        return alpha1, phi_a1
-    niter = 0
-    alpha2, phi_a2 = alpha1, phi_a1
-    while alpha1 > amin and niter < max_niter:
-        factor = alpha0 ** 2 * alpha1 ** 2 * (alpha1 - alpha0)
-        a = alpha0 ** 2 * (phi_a1 - phi0 - derphi0 * alpha1) - alpha1 ** 2 * (phi_a0 - phi0 - derphi0 * alpha0)
-        a = a / factor
-        b = -alpha0 ** 3 * (phi_a1 - phi0 - derphi0 * alpha1) + alpha1 ** 3 * (phi_a0 - phi0 - derphi0 * alpha0)
-        b = b / factor
-        alpha2 = (-b + abs(b ** 2 - 3 * a * derphi0) ** 0.5) / (3.0 * a)
-        phi_a2 = phi(alpha2)
-        if phi_a2 <= phi0 + c1 * alpha2 * derphi0:
-            return alpha2, phi_a2
-        if (alpha1 - alpha2) > alpha1 / 2.0 or (1 - alpha2 / alpha1) < 0.96:
-            alpha2 = alpha1 / 2.0
-        alpha0, alpha1, phi_a0, phi_a1 = alpha1, alpha2, phi_a1, phi_a2
-        niter += 1
-    if niter == max_niter:
-        return alpha2, phi_a2
-    return None, phi_a1
+def _cubic_backtrack(s_old, f_old, s_new, f_new, f0, slope0):
+    """Minimiser of the cubic that interpolates f(0) = f0, f'(0) = slope0, f(s_old) = f_old, f(s_new) = f_new
+    (Nocedal & Wright, Numerical Optimization, eq. 3.59; the expression order follows SciPy's
+    `scalar_search_armijo`, from which the reference's line search derives, so that the trial steps — and with
+    them the number of function evaluations — are bit-identical to the reference's)."""
+    d_old = f_old - f0 - slope0 * s_old
+    d_new = f_new - f0 - slope0 * s_new
+    scale = s_old ** 2 * s_new ** 2 * (s_new - s_old)
+    c3 = (s_old ** 2 * d_new - s_new ** 2 * d_old) / scale
+    c2 = (-s_old ** 3 * d_new + s_new ** 3 * d_old) / scale
+    return (-c2 + abs(c2 ** 2 - 3 * c3 * slope0) ** 0.5) / (3.0 * c3)
 
 
-def _line_search(func, x, y, dx, red, smin=1e-2):
-    """reference: _nonline_line_search, rootsolver.py:272-310."""
-    state = {"s": 0.0, "y": y, "phi": float(red.dot(y, y))}
+def _armijo(phi, phi0, slope0, c1=1e-4, first_step=1.0, smallest=0.0, max_cubic=20):
+    """Armijo backtracking on the scalar function ``phi``: accept the first trial step s with
+    phi(s) <= phi0 + c1 s slope0.  Trials: the full step, the minimiser of the interpolating quadratic, then
+    minimisers of interpolating cubics, each safeguarded to lie in [s/2 .. 0.96 s] of its predecessor
+    (behaviour of the reference's `_scalar_search_armijo`, rootsolver.py:312-357, itself SciPy's
+    scalar_search_armijo).  Returns (step or None, phi at the last trial).  Scalars are host floats."""
+    def acceptable(s, val):
+        return val <= phi0 + c1 * s * slope0
+
+    s_old, f_old = first_step, phi(first_step)
+    if acceptable(s_old, f_old):
+        return s_old, f_old
+    s_new = -slope0 * s_old ** 2 / 2.0 / (f_old - phi0 - slope0 * s_old)      # quadratic through f0, slope0, f_old
+    f_new = phi(s_new)
+    if acceptable(s_new, f_new):
+        return s_new, f_new
+    trial, f_trial = s_new, f_new
+    for _ in range(max_cubic):
+        if not s_new > smallest:
+            return None, f_new              # the step shrank below the floor: give up (caller takes the full step)
+        trial = _cubic_backtrack(s_old, f_old, s_new, f_new, phi0, slope0)
+        f_trial = phi(trial)
+        if acceptable(trial, f_trial):
+            return trial, f_trial
+        if (s_new - trial) > s_new / 2.0 or (1 - trial / s_new) < 0.96:
+            trial = s_new / 2.0             # too far from / too close to the previous trial: halve instead
+        s_old, f_old, s_new, f_new = s_new, f_new, trial, f_trial
+    return trial, f_trial                   # out of cubic trials: hand back the last one
+
+
+def _line_search(func, x, y, dx, red, phi0, smin=1e-2):
+    """Armijo search along dx on phi(s) = |f(x + s dx)|^2 (reference: _nonline_line_search, rootsolver.py:272-310).
+    Every trial costs one function evaluation and ONE host sync: the fused reduction delivers |f|^2 together with
+    |x + s dx|^2 and (first trial only) |dx|^2, which is everything the termination test needs afterwards.
+    Returns (s, xnew, ynew, {"y2", "x2", "dx2"})."""
+    state = {"s": 0.0, "y": y, "x": x, "phi": phi0, "x2": None, "dx2": None}
 
     def phi(s):
         if s == state["s"]:
             return state["phi"]
-        v = func(x + s * dx)
-        p = float(red.dot(v, v))
-        state.update(s=s, y=v, phi=p)
+        xt = _axpy(x, 1.0, dx, s)
+        v = func(xt)
+        if state["dx2"] is None:
+            p, x2, dx2 = red.dots([(v, v), (xt, xt), (dx, dx)])
+            state["dx2"] = dx2
+        else:
+            p, x2 = red.dots([(v, v), (xt, xt)])
+        state.update(s=s, y=v, x=xt, phi=p, x2=x2)
         return p
 
-    s, _ = _armijo(phi, state["phi"], -state["phi"], amin=smin)
+    s, _ = _armijo(phi, phi0, -phi0, smallest=smin)
     if s is None:
         s = 1.0
-    xn = x + s * dx
-    yn = state["y"] if s == state["s"] else func(xn)
-    return s, xn, yn, float(red.norm(yn))
+    if s != state["s"]:                     # the accepted step is not the last one evaluated: evaluate it
+        phi(s)
+    return s, state["x"], state["y"], {"y2": state["phi"], "x2": state["x2"], "dx2": state["dx2"]}
 
 
 class _Termination:
@@ -297,10 +386,13 @@ class _Termination:
         self.x_rtol = float("inf") if x_rtol is None else x_rtol
         self.f0_norm, self.red = f0_norm, red
 
-    def check(self, x, y, dx):
-        xn, yn, dxn = float(self.red.norm(x)), float(self.red.norm(y)), float(self.red.norm(dx))
+    def check_norms(self, xn, yn, dxn):
         return (dxn < self.x_tol) and (dxn < self.x_rtol * xn) and (yn < self.f_tol) and \
             (yn < self.f_rtol * self.f0_norm)
+
+    def check(self, x, y, dx):
+        x2, y2, dx2 = self.red.dots([(x, x), (y, y), (dx, dx)])
+        return self.check_norms(x2 ** 0.5, y2 ** 0.5, dx2 ** 0.5)
 
 
 # ------------------------------------------------------------------------------ driver
@@ -347,35 +439,42 @@ def _nonlin_solver(fcn, x0, params, jacobian, maxiter=None, f_tol=None, f_rtol=N
 
     x = x0.reshape(-1)
     y = cfunc(x)
-    y_norm = float(red.norm(y))
+    y2, x2 = red.dots([(y, y), (x, x)])
+    y_norm = y2 ** 0.5
     stop_cond = custom_terminator if custom_terminator is not None else \
         _Termination(f_tol, f_rtol, y_norm, x_tol, x_rtol, red)
     if y_norm == 0:
         return x.reshape(xshape)
     jacobian.setup(x, y, cfunc, red)
+    neg_solve = getattr(jacobian, "neg_solve", None)
 
     gamma, eta_max, eta_threshold, eta = 0.9, 0.9999, 0.1, 1e-3
     converge = False
-    best_ynorm, best_x, best_dxnorm, best_iter = y_norm, x, float(red.norm(x)), 0
+    best_ynorm, best_x, best_dxnorm, best_iter = y_norm, x, x2 ** 0.5, 0
     niter = 0
     for i in range(maxiter):
         niter = i + 1
-        dx = -jacobian.solve(y, tol=min(eta, eta * y_norm))
-        dx_norm = float(red.norm(dx))
+        tol = min(eta, eta * y_norm)
+        dx = neg_solve(y, tol=tol) if neg_solve is not None else -jacobian.solve(y, tol=tol)
+        if line_search:
+            s, xnew, ynew, st = _line_search(cfunc, x, y, dx, red, y_norm * y_norm)
+        else:
+            s = 1.0
+            xnew = _axpy(x, 1.0, dx, 1.0)
+            ynew = cfunc(xnew)
+            st = dict(zip(("y2", "x2", "dx2"), red.dots([(ynew, ynew), (xnew, xnew), (dx, dx)])))
+        # the norms of this iteration, all from the one reduction that the accepted trial step produced
+        y_norm_new, x_norm_new, dx_norm = st["y2"] ** 0.5, st["x2"] ** 0.5, st["dx2"] ** 0.5
         if dx_norm == 0:
             raise ValueError("Jacobian inversion yielded zero vector. "
                              "This indicates a bug in the Jacobian approximation.")
-        if line_search:
-            s, xnew, ynew, y_norm_new = _line_search(cfunc, x, y, dx, red)
-        else:
-            s = 1.0
-            xnew = x + dx
-            ynew = cfunc(xnew)
-            y_norm_new = float(red.norm(ynew))
         if y_norm_new < best_ynorm:
             best_x, best_dxnorm, best_ynorm, best_iter = xnew, dx_norm, y_norm_new, i + 1
-        jacobian.update(xnew.clone(), ynew)
-        to_stop = stop_cond.check(xnew, ynew, dx)
+        jacobian.update(xnew, ynew)
+        if isinstance(stop_cond, _Termination):
+            to_stop = stop_cond.check_norms(x_norm_new, y_norm_new, dx_norm)
+        else:
+            to_stop = stop_cond.check(xnew, ynew, dx)
         if verbose and (i < 10 or i % 10 == 0 or to_stop):
             print("%6d: |dx|=%.3e, |f|=%.3e" % (i, dx_norm, y_norm))
         if to_stop:
