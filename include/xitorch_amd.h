@@ -237,6 +237,51 @@ int xk_kry_status_f64(const double* Prr, const double* stop, double* rnorm, doub
 int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double* status, int S, int nblk,
                       void* stream);
 
+/* ---- the same fused Krylov kernels for COMPLEX systems (complex64 = _c64, complex128 = _c128) ----------
+ * The reference runs cg / bicgstab on complex operators with conjugated inner products
+ * (xitorch/_impls/linalg/solve.py:441-445; _tests/test_linop_fcns.py:474-524, 631-676).  Pointers address
+ * INTERLEAVED (re, im) storage (torch.view_as_real of a complex panel); N and ld count complex elements; the
+ * per-system scalars (rho, alpha, omega, E) are (S, 2) arrays; partials of complex products are
+ * (S, xk_kry_max_partials(), 2); |r|^2 partials (Prr) stay real (S, xk_kry_max_partials()) and are consumed by
+ * xk_kry_status_f32/_f64.  <x, y> = sum conj(x) y; xk_kry_dots_c*: conj1 = 1 stores conj(<x1,y1>) = <y1,x1>
+ * in P1 (BiCGStab's omega = <t, s> / <t, t>, solve.py:286, with the shift applied to y1 = t). */
+int xk_kry_dots_c128(const double* x1, double* y1, const double* x2, const double* y2, const double* shiftz,
+                     const double* E, double* P1, double* P2, int S, int N, long ld, int nblk, int conj1, void* stream);
+int xk_kry_dots_c64(const float* x1, float* y1, const float* x2, const float* y2, const float* shiftz, const float* E,
+                    float* P1, float* P2, int S, int N, long ld, int nblk, int conj1, void* stream);
+int xk_bicg_p_c128(const double* r, double* p, const double* v, const double* Prho_new, const double* rho_old,
+                   const double* alpha, const double* omega, double* rho_store, int S, int N, long ld, int nblk,
+                   double eps, int first, void* stream);
+int xk_bicg_p_c64(const float* r, float* p, const float* v, const float* Prho_new, const float* rho_old,
+                  const float* alpha, const float* omega, float* rho_store, int S, int N, long ld, int nblk, double eps,
+                  int first, void* stream);
+int xk_bicg_s_c128(const double* r, const double* v, double* s, const double* rho, const double* Pr0v,
+                   double* alpha_store, int S, int N, long ld, int nblk, double eps, void* stream);
+int xk_bicg_s_c64(const float* r, const float* v, float* s, const float* rho, const float* Pr0v, float* alpha_store,
+                  int S, int N, long ld, int nblk, double eps, void* stream);
+int xk_bicg_final_c128(const double* x, double* xout, const double* yd, const double* zd, const double* s,
+                       const double* t, double* r, const double* r0, const double* alpha, const double* Pts,
+                       const double* Ptt, double* omega_store, double* Prr, double* Prho, int S, int N, long ld,
+                       int nblk, double eps, int skip_r, void* stream);
+int xk_bicg_final_c64(const float* x, float* xout, const float* yd, const float* zd, const float* s, const float* t,
+                      float* r, const float* r0, const float* alpha, const float* Pts, const float* Ptt,
+                      float* omega_store, float* Prr, float* Prho, int S, int N, long ld, int nblk, double eps,
+                      int skip_r, void* stream);
+int xk_kry_resid_c128(const double* b, const double* y, double* r, const double* r0, double* Prr, double* Prho,
+                      int S, int N, long ld, int nblk, void* stream);
+int xk_kry_resid_c64(const float* b, const float* y, float* r, const float* r0, float* Prr, float* Prho, int S, int N,
+                     long ld, int nblk, void* stream);
+int xk_cg_update_c128(const double* x, double* xout, const double* p, const double* Ap, double* r, const double* Prz,
+                      const double* PpAp, double* Prr, int S, int N, long ld, int nblk, double eps, int skip_r,
+                      void* stream);
+int xk_cg_update_c64(const float* x, float* xout, const float* p, const float* Ap, float* r, const float* Prz,
+                     const float* PpAp, float* Prr, int S, int N, long ld, int nblk, double eps, int skip_r,
+                     void* stream);
+int xk_cg_p_c128(const double* z, double* p, const double* Prz_new, const double* Prz_old, int S, int N, long ld,
+                 int nblk, double eps, void* stream);
+int xk_cg_p_c64(const float* z, float* p, const float* Prz_new, const float* Prz_old, int S, int N, long ld, int nblk,
+                double eps, void* stream);
+
 /* ---- fused BLAS-1 of the quasi-Newton (Broyden) driver -------------------------------------------------
  * The reference's _nonlin_solver / LowRankMatrix (xitorch/_impls/optimize/root/rootsolver.py:96-143,
  * _jacobian.py:99-119,172-189) run torch.dot / .norm() / axpy chains on one flat length-L vector with a host sync

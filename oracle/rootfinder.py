@@ -153,9 +153,19 @@ def nonlin_solve(fcn, x0, params, jacobian, maxiter=None, f_tol=None, f_rtol=Non
     if maxiter is None:
         maxiter = 100 * (x0.numel() + 1)
     xshape = x0.shape
-    func = lambda x: fcn(x.reshape(xshape), *params).reshape(-1)
+    # complex unknowns: real vector [Re x; Im x] of twice the length (rootsolver.py:52-73)
+    if torch.is_complex(x0):
+        ravel = lambda t: torch.cat((t.real, t.imag), dim=0).reshape(-1)
+
+        def pack(v):
+            n = len(v) // 2
+            return (v[:n] + 1j * v[n:]).reshape(xshape)
+    else:
+        ravel = lambda t: t.reshape(-1)
+        pack = lambda v: v.reshape(xshape)
+    func = lambda x: ravel(fcn(pack(x), *params))
     nfev = [1]
-    x = x0.reshape(-1)
+    x = ravel(x0)
     y = func(x)
     y_norm = y.norm()
     f_tol = 1e-6 if f_tol is None else f_tol
@@ -201,7 +211,7 @@ def nonlin_solve(fcn, x0, params, jacobian, maxiter=None, f_tol=None, f_rtol=Non
     if not converged:
         warnings.warn(OracleConvergenceWarning("rootfinder: no convergence after %d iterations" % maxiter))
         x = best_x
-    return x.reshape(xshape)
+    return pack(x)
 
 
 class BroydenSecond(BroydenFirst):

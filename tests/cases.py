@@ -105,6 +105,20 @@ SOLVE_CASES = [
          ncols=2, spread=True, precond=("precond_r",), kwargs=dict(rtol=1e-10, posdef=True)),
     dict(name="bicgstab_nonsym120_jacobi_l", method="bicgstab", op="dense", hermitian=False, n=120, batch=(2,),
          ncols=2, spread=True, precond=("precond_l",), kwargs=dict(rtol=1e-10, posdef=True)),
+    # complex128 operators: the reference's own solver tests run cg / bicgstab on complex Hermitian matrices, with and
+    # without E, M (xitorch/_tests/test_linop_fcns.py:474-524, 631-676); conjugated inner products (solve.py:441-445)
+    dict(name="cg_herm100_c128", method="cg", op="dense", hermitian=True, n=100, batch=(2,), ncols=3, cplx=True,
+         kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="bicgstab_herm100_c128", method="bicgstab", op="dense", hermitian=True, n=100, batch=(2,), ncols=3,
+         cplx=True, kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="bicgstab_nonherm80_c128", method="bicgstab", op="dense", hermitian=False, n=80, batch=(2,), ncols=2,
+         cplx=True, kwargs=dict(rtol=1e-9, posdef=True)),
+    dict(name="cg_nonsym60_normal_eq_c128", method="cg", op="dense", hermitian=False, n=60, batch=(2,), ncols=2,
+         cplx=True, kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="cg_herm_AEM_c128", method="cg", op="dense", hermitian=True, n=80, batch=(2,), ncols=3, E=True, M=True,
+         cplx=True, kwargs=dict(rtol=1e-8, posdef=True)),
+    dict(name="bicgstab_herm_AEM_c128", method="bicgstab", op="dense", hermitian=True, n=80, batch=(2,), ncols=3,
+         E=True, M=True, cplx=True, kwargs=dict(rtol=1e-8, posdef=True)),
 ]
 
 
@@ -115,6 +129,21 @@ def solve_inputs(case):
         A = syn.banded(batch[0], n, hb=63)
         xs = syn.banded_rhs_solution(batch[0], n)
         B = syn.banded_apply_reference(A, xs)
+    elif case.get("cplx"):
+        c128 = torch.complex128
+        crand = lambda *shape: torch.complex(torch.rand(shape, dtype=f64, generator=g),
+                                             torch.rand(shape, dtype=f64, generator=g))
+        A = 0.1 * crand(*batch, n, n) + torch.eye(n, dtype=c128)
+        if case["hermitian"]:
+            A = (A + A.transpose(-2, -1).conj()) * 0.5
+        B = crand(*batch, n, nc) + 0.1
+        E = M = None
+        if case.get("E"):
+            E = crand(*batch, nc) * 0.1
+        if case.get("M"):
+            M = crand(*batch, n, n) * 0.05 + torch.eye(n, dtype=c128) * 0.5
+            M = (M + M.transpose(-2, -1).conj()) * 0.5
+        return A, B, E, M
     else:
         R = torch.rand((*batch, n, n), dtype=f64, generator=g)
         A = 0.1 * R + (torch.diag(torch.linspace(1.0, 50.0, n, dtype=f64)) if case.get("spread")
@@ -151,6 +180,11 @@ def tanh_fcn_batched(y, A):
     return torch.tanh(torch.einsum("bij,bj->bi", A, y) + 0.1) + y / 2.0
 
 
+def ctanh_fcn_batched(y, A):
+    # complex variant: f(y) = tanh(A_b y + 0.1 + 0.05i) + y/2 with complex A_b, y
+    return torch.tanh(torch.einsum("bij,bj->bi", A, y) + (0.1 + 0.05j)) + y / 2.0
+
+
 ROOT_CASES = [
     dict(name="readme2", kind="readme", grad=True, kwargs=dict()),
     dict(name="tanh_b4_n64", kind="tanh", nbatch=4, n=64, kwargs=dict(alpha=-1.0, max_rank=None, f_tol=1e-8)),
@@ -160,6 +194,9 @@ ROOT_CASES = [
          kwargs=dict(alpha=-1.0, max_rank=None, f_tol=1e-8)),
     dict(name="tanh_b2_n48_linearmixing", kind="tanh", nbatch=2, n=48, method="linearmixing",
          kwargs=dict(alpha=-1.0, f_tol=1e-8, maxiter=400)),
+    # complex unknowns: solved as [Re; Im] of twice the length (rootsolver.py:52-73; the reference tests run
+    # rootfinder on complex128, _tests/test_optimize.py:118-155, 312-344)
+    dict(name="ctanh_b3_n32_c128", kind="ctanh", nbatch=3, n=32, kwargs=dict(alpha=-1.0, max_rank=None, f_tol=1e-9)),
 ]
 
 
@@ -169,6 +206,9 @@ def root_inputs(case):
         return tanh_fcn, torch.zeros((2, 1), dtype=f64), (A,)
     A = syn.root_matrix(case["nbatch"], case["n"]) * 2.0   # eigenvalues in (0, 1]
     y0 = torch.zeros((case["nbatch"], case["n"]), dtype=f64)
+    if case["kind"] == "ctanh":
+        Ac = torch.complex(A, 0.3 * A.flip(-1))
+        return ctanh_fcn_batched, torch.complex(y0, y0), (Ac,)
     return tanh_fcn_batched, y0, (A,)
 
 

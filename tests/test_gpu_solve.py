@@ -63,7 +63,7 @@ def test_krylov_vs_golden_and_oracle(dev, case):
     if case["name"].startswith("cg_nonsym"):
         pass      # normal equations: the stopping test is on A^T(AX - B); checked through X below
     else:
-        lim = torch.max(rtol * B.norm(dim=-2), torch.tensor(atol, dtype=B.dtype))
+        lim = torch.clamp(rtol * B.norm(dim=-2), min=atol)
         assert torch.all((AX - B).norm(dim=-2) <= lim * 1.001)
     # (2) against the reference's own output and the dense solution
     Xg, Xe = torch.from_numpy(gold["X"]), torch.from_numpy(gold["X_exact"])

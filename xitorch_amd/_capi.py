@@ -85,6 +85,14 @@ def _declare(L):
         sigs["xk_kry_status_" + sfx] = (I, [P] * 4 + [I, I, P])
         sigs["xk_banded_grad_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
         sigs["xk_dense_outer_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, P])
+    for sfx in ("c64", "c128"):
+        sigs["xk_kry_dots_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, I, P])
+        sigs["xk_bicg_p_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])
+        sigs["xk_bicg_s_" + sfx] = (I, [P] * 6 + [I, I, Lg, I, D, P])
+        sigs["xk_bicg_final_" + sfx] = (I, [P] * 14 + [I, I, Lg, I, D, I, P])
+        sigs["xk_kry_resid_" + sfx] = (I, [P] * 6 + [I, I, Lg, I, P])
+        sigs["xk_cg_update_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])
+        sigs["xk_cg_p_" + sfx] = (I, [P] * 4 + [I, I, Lg, I, D, P])
     sigs["xk_vec_dots_workspace_elems"] = (Lg, [])
     for sfx in ("f64", "f32"):
         sigs["xk_vec_dots_" + sfx] = (I, [P] * 8 + [I, Lg, P, Lg, P, P])
@@ -117,6 +125,10 @@ def suffix(dtype):
         return "f64"
     if dtype == torch.float32:
         return "f32"
+    if dtype == torch.complex128:
+        return "c128"
+    if dtype == torch.complex64:
+        return "c64"
     raise NativeLibraryError("xitorch_amd native kernels support float64/float32, got %s" % dtype)
 
 

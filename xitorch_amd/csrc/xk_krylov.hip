@@ -310,6 +310,310 @@ __global__ __launch_bounds__(256) void kry_status_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Complex systems (complex64 / complex128): the same fused passes on INTERLEAVED (re, im) storage — what
+// torch.view_as_real of a complex panel is.  T is the underlying real type; N, ld count COMPLEX elements; a
+// 16 B vector holds CV = VN/2 complex numbers.  Inner products are conj(x).y (the reference's `_dot`,
+// xitorch/_impls/linalg/solve.py:441-445), per-system scalars (rho, alpha, omega, E) are complex pairs, the
+// partial sums of complex products are stored as pairs ((S, KRY_MAX_PART, 2)); |r|^2 partials stay REAL in the
+// (S, KRY_MAX_PART) layout, so xk_kry_status serves both families.  `_safedenom` (solve.py:437-439) replaces an
+// exact complex zero by eps + 0i.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct cx { T re, im; };
+template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+template <typename T> __device__ __forceinline__ cx<T> cdiv(cx<T> a, cx<T> b) {
+  const T d = b.re * b.re + b.im * b.im;
+  return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+template <typename T> __device__ __forceinline__ cx<T> csafe(cx<T> v, T eps) {
+  return (v.re == T(0) && v.im == T(0)) ? cx<T>{eps, T(0)} : v;
+}
+template <typename T> __device__ __forceinline__ cx<T> cload(const T* p, int s) { return {p[2 * (long)s], p[2 * (long)s + 1]}; }
+
+template <typename T>
+__device__ __forceinline__ cx<T> reduce_partials_c(const T* __restrict__ part, int s, int nblk, T* sh2) {
+  if (threadIdx.x < 64) {
+    T vr = (int)threadIdx.x < nblk ? part[((long)s * KRY_MAX_PART + threadIdx.x) * 2] : T(0);
+    T vi = (int)threadIdx.x < nblk ? part[((long)s * KRY_MAX_PART + threadIdx.x) * 2 + 1] : T(0);
+    vr = wave_sum(vr);
+    vi = wave_sum(vi);
+    if (threadIdx.x == 0) { sh2[0] = vr; sh2[1] = vi; }
+  }
+  __syncthreads();
+  const cx<T> r = {sh2[0], sh2[1]};
+  __syncthreads();
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void block_store_partial_c(cx<T> v, T* __restrict__ part, int s, int blk, T* sh8) {
+  const T vr = wave_sum(v.re), vi = wave_sum(v.im);
+  if ((threadIdx.x & 63) == 0) { sh8[(threadIdx.x >> 6) * 2] = vr; sh8[(threadIdx.x >> 6) * 2 + 1] = vi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((long)s * KRY_MAX_PART + blk) * 2] = (sh8[0] + sh8[2]) + (sh8[4] + sh8[6]);
+    part[((long)s * KRY_MAX_PART + blk) * 2 + 1] = (sh8[1] + sh8[3]) + (sh8[5] + sh8[7]);
+  }
+  __syncthreads();
+}
+
+// complex prologue: [lo, hi) in COMPLEX elements, `base` in real elements
+#define XK_KRYC_PROLOGUE                                   \
+  typedef typename Vec16<T>::type VT;                      \
+  constexpr int VN = Vec16<T>::n;                          \
+  constexpr int CV = VN / 2;                               \
+  const int s = blockIdx.x / nblk;                         \
+  const int blk = blockIdx.x - s * nblk;                   \
+  int lo, hi;                                              \
+  block_range(N, nblk, blk, CV, lo, hi);                   \
+  const long base = (long)s * ld * 2;
+#define XK_CLOOP for (int j = lo + threadIdx.x * CV; j < hi; j += 256 * CV)
+#define XK_LDV(ptr) (*reinterpret_cast<const VT*>((ptr) + base + 2 * (long)j))
+#define XK_STV(ptr, val) (*reinterpret_cast<VT*>((ptr) + base + 2 * (long)j) = (val))
+
+template <typename T>
+__global__ __launch_bounds__(256) void kry_dots_c_kernel(
+    const T* __restrict__ x1, T* __restrict__ y1, const T* __restrict__ x2, const T* __restrict__ y2,
+    const T* __restrict__ shiftz, const T* __restrict__ E, T* __restrict__ P1, T* __restrict__ P2,
+    int N, long ld, int nblk, int y1_is_x1, int conj1) {
+  __shared__ T sh8[8];
+  XK_KRYC_PROLOGUE
+  const cx<T> e = (E != nullptr) ? cload(E, s) : cx<T>{T(0), T(0)};
+  cx<T> a1 = {T(0), T(0)}, a2 = {T(0), T(0)};
+  XK_CLOOP {
+    VT yv = XK_LDV(y1);
+    if (E != nullptr) {
+      const VT zv = XK_LDV(shiftz);
+#pragma unroll
+      for (int q = 0; q < CV; ++q) {
+        const cx<T> ez = cmul(e, cx<T>{zv[2 * q], zv[2 * q + 1]});
+        yv[2 * q] -= ez.re;
+        yv[2 * q + 1] -= ez.im;
+      }
+      XK_STV(y1, yv);
+    }
+    const VT xv = y1_is_x1 ? yv : XK_LDV(x1);
+#pragma unroll
+    for (int q = 0; q < CV; ++q) {          // conj(x) * y
+      a1.re += xv[2 * q] * yv[2 * q] + xv[2 * q + 1] * yv[2 * q + 1];
+      a1.im += xv[2 * q] * yv[2 * q + 1] - xv[2 * q + 1] * yv[2 * q];
+    }
+    if (P2 != nullptr) {
+      const VT x2v = (x2 == y1) ? yv : XK_LDV(x2);
+      const VT y2v = (y2 == y1) ? yv : XK_LDV(y2);
+#pragma unroll
+      for (int q = 0; q < CV; ++q) {
+        a2.re += x2v[2 * q] * y2v[2 * q] + x2v[2 * q + 1] * y2v[2 * q + 1];
+        a2.im += x2v[2 * q] * y2v[2 * q + 1] - x2v[2 * q + 1] * y2v[2 * q];
+      }
+    }
+  }
+  if (conj1) a1.im = -a1.im;               // P1 <- conj(y1).x1 instead of conj(x1).y1
+  block_store_partial_c(a1, P1, s, blk, sh8);
+  if (P2 != nullptr) block_store_partial_c(a2, P2, s, blk, sh8);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bicg_p_c_kernel(
+    const T* __restrict__ r, T* __restrict__ p, const T* __restrict__ v, const T* __restrict__ Prho_new,
+    const T* __restrict__ rho_old, const T* __restrict__ alpha, const T* __restrict__ omega,
+    T* __restrict__ rho_store, int N, long ld, int nblk, T eps, int first) {
+  __shared__ T sh2[2];
+  XK_KRYC_PROLOGUE
+  const cx<T> rho_new = reduce_partials_c(Prho_new, s, nblk, sh2);
+  cx<T> beta = {T(0), T(0)}, om = {T(0), T(0)};
+  if (!first) {
+    om = csafe(cload(omega, s), eps);
+    beta = cmul(cdiv(rho_new, csafe(cload(rho_old, s), eps)), cdiv(cload(alpha, s), om));
+  }
+  XK_CLOOP {
+    const VT rv = XK_LDV(r);
+    VT o = rv;
+    if (!first) {
+      const VT pv = XK_LDV(p);
+      const VT vv = XK_LDV(v);
+#pragma unroll
+      for (int q = 0; q < CV; ++q) {
+        const cx<T> ov = cmul(om, cx<T>{vv[2 * q], vv[2 * q + 1]});
+        const cx<T> t = cmul(beta, cx<T>{pv[2 * q] - ov.re, pv[2 * q + 1] - ov.im});
+        o[2 * q] = rv[2 * q] + t.re;
+        o[2 * q + 1] = rv[2 * q + 1] + t.im;
+      }
+    }
+    XK_STV(p, o);
+  }
+  if (blk == 0 && threadIdx.x == 0) { rho_store[2 * (long)s] = rho_new.re; rho_store[2 * (long)s + 1] = rho_new.im; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bicg_s_c_kernel(
+    const T* __restrict__ r, const T* __restrict__ v, T* __restrict__ sv, const T* __restrict__ rho,
+    const T* __restrict__ Pr0v, T* __restrict__ alpha_store, int N, long ld, int nblk, T eps) {
+  __shared__ T sh2[2];
+  XK_KRYC_PROLOGUE
+  const cx<T> r0v = reduce_partials_c(Pr0v, s, nblk, sh2);
+  const cx<T> al = cdiv(cload(rho, s), csafe(r0v, eps));
+  XK_CLOOP {
+    const VT rv = XK_LDV(r);
+    const VT vv = XK_LDV(v);
+    VT o;
+#pragma unroll
+    for (int q = 0; q < CV; ++q) {
+      const cx<T> av = cmul(al, cx<T>{vv[2 * q], vv[2 * q + 1]});
+      o[2 * q] = rv[2 * q] - av.re;
+      o[2 * q + 1] = rv[2 * q + 1] - av.im;
+    }
+    XK_STV(sv, o);
+  }
+  if (blk == 0 && threadIdx.x == 0) { alpha_store[2 * (long)s] = al.re; alpha_store[2 * (long)s + 1] = al.im; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bicg_final_c_kernel(
+    const T* __restrict__ x, T* __restrict__ xout, const T* __restrict__ yd, const T* __restrict__ zd,
+    const T* __restrict__ sv, const T* __restrict__ t, T* __restrict__ r, const T* __restrict__ r0,
+    const T* __restrict__ alpha, const T* __restrict__ Pts, const T* __restrict__ Ptt,
+    T* __restrict__ omega_store, T* __restrict__ Prr, T* __restrict__ Prho, int N, long ld, int nblk,
+    T eps, int skip_r) {
+  __shared__ T sh2[2];
+  __shared__ T sh8[8];
+  __shared__ T sh4[4];
+  XK_KRYC_PROLOGUE
+  const cx<T> ts = reduce_partials_c(Pts, s, nblk, sh2);
+  const cx<T> tt = reduce_partials_c(Ptt, s, nblk, sh2);
+  const cx<T> omega = cdiv(ts, csafe(tt, eps));
+  const cx<T> al = cload(alpha, s);
+  T arr = T(0);
+  cx<T> arho = {T(0), T(0)};
+  XK_CLOOP {
+    const VT xv = XK_LDV(x);
+    const VT yv = XK_LDV(yd);
+    const VT zv = XK_LDV(zd);
+    VT o;
+#pragma unroll
+    for (int q = 0; q < CV; ++q) {
+      const cx<T> ay = cmul(al, cx<T>{yv[2 * q], yv[2 * q + 1]});
+      const cx<T> oz = cmul(omega, cx<T>{zv[2 * q], zv[2 * q + 1]});
+      o[2 * q] = (xv[2 * q] + ay.re) + oz.re;
+      o[2 * q + 1] = (xv[2 * q + 1] + ay.im) + oz.im;
+    }
+    XK_STV(xout, o);
+    if (!skip_r) {
+      const VT s2 = (sv == zd) ? zv : XK_LDV(sv);
+      const VT tv = XK_LDV(t);
+      const VT r0v = XK_LDV(r0);
+      VT rn;
+#pragma unroll
+      for (int q = 0; q < CV; ++q) {
+        const cx<T> ot = cmul(omega, cx<T>{tv[2 * q], tv[2 * q + 1]});
+        rn[2 * q] = s2[2 * q] - ot.re;
+        rn[2 * q + 1] = s2[2 * q + 1] - ot.im;
+        arr += rn[2 * q] * rn[2 * q] + rn[2 * q + 1] * rn[2 * q + 1];
+        arho.re += r0v[2 * q] * rn[2 * q] + r0v[2 * q + 1] * rn[2 * q + 1];
+        arho.im += r0v[2 * q] * rn[2 * q + 1] - r0v[2 * q + 1] * rn[2 * q];
+      }
+      XK_STV(r, rn);
+    }
+  }
+  if (!skip_r) {
+    block_store_partial(arr, Prr, s, blk, sh4);
+    block_store_partial_c(arho, Prho, s, blk, sh8);
+  }
+  if (blk == 0 && threadIdx.x == 0) { omega_store[2 * (long)s] = omega.re; omega_store[2 * (long)s + 1] = omega.im; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kry_resid_c_kernel(
+    const T* __restrict__ b, const T* __restrict__ y, T* __restrict__ r, const T* __restrict__ r0,
+    T* __restrict__ Prr, T* __restrict__ Prho, int N, long ld, int nblk) {
+  __shared__ T sh8[8];
+  __shared__ T sh4[4];
+  XK_KRYC_PROLOGUE
+  T arr = T(0);
+  cx<T> arho = {T(0), T(0)};
+  XK_CLOOP {
+    const VT bv = XK_LDV(b);
+    const VT yv = XK_LDV(y);
+    VT rn;
+#pragma unroll
+    for (int q = 0; q < VN; ++q) { rn[q] = bv[q] - yv[q]; arr += rn[q] * rn[q]; }
+    if (r0 != nullptr) {
+      const VT r0v = XK_LDV(r0);
+#pragma unroll
+      for (int q = 0; q < CV; ++q) {
+        arho.re += r0v[2 * q] * rn[2 * q] + r0v[2 * q + 1] * rn[2 * q + 1];
+        arho.im += r0v[2 * q] * rn[2 * q + 1] - r0v[2 * q + 1] * rn[2 * q];
+      }
+    }
+    XK_STV(r, rn);
+  }
+  block_store_partial(arr, Prr, s, blk, sh4);
+  if (Prho != nullptr) block_store_partial_c(r0 != nullptr ? arho : cx<T>{arr, T(0)}, Prho, s, blk, sh8);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cg_update_c_kernel(
+    const T* __restrict__ x, T* __restrict__ xout, const T* __restrict__ p, const T* __restrict__ Ap,
+    T* __restrict__ r, const T* __restrict__ Prz, const T* __restrict__ PpAp, T* __restrict__ Prr,
+    int N, long ld, int nblk, T eps, int skip_r) {
+  __shared__ T sh2[2];
+  __shared__ T sh4[4];
+  XK_KRYC_PROLOGUE
+  const cx<T> rz = reduce_partials_c(Prz, s, nblk, sh2);
+  const cx<T> pap = reduce_partials_c(PpAp, s, nblk, sh2);
+  const cx<T> al = cdiv(rz, csafe(pap, eps));
+  T arr = T(0);
+  XK_CLOOP {
+    const VT xv = XK_LDV(x);
+    const VT pv = XK_LDV(p);
+    VT o;
+#pragma unroll
+    for (int q = 0; q < CV; ++q) {
+      const cx<T> ap = cmul(al, cx<T>{pv[2 * q], pv[2 * q + 1]});
+      o[2 * q] = xv[2 * q] + ap.re;
+      o[2 * q + 1] = xv[2 * q + 1] + ap.im;
+    }
+    XK_STV(xout, o);
+    if (!skip_r) {
+      VT rv = XK_LDV(r);
+      const VT av = XK_LDV(Ap);
+#pragma unroll
+      for (int q = 0; q < CV; ++q) {
+        const cx<T> aa = cmul(al, cx<T>{av[2 * q], av[2 * q + 1]});
+        rv[2 * q] -= aa.re;
+        rv[2 * q + 1] -= aa.im;
+        arr += rv[2 * q] * rv[2 * q] + rv[2 * q + 1] * rv[2 * q + 1];
+      }
+      XK_STV(r, rv);
+    }
+  }
+  if (!skip_r) block_store_partial(arr, Prr, s, blk, sh4);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cg_p_c_kernel(
+    const T* __restrict__ z, T* __restrict__ p, const T* __restrict__ Prz_new, const T* __restrict__ Prz_old,
+    int N, long ld, int nblk, T eps) {
+  __shared__ T sh2[2];
+  XK_KRYC_PROLOGUE
+  const cx<T> rzn = reduce_partials_c(Prz_new, s, nblk, sh2);
+  const cx<T> rzo = reduce_partials_c(Prz_old, s, nblk, sh2);
+  const cx<T> beta = cdiv(rzn, csafe(rzo, eps));
+  XK_CLOOP {
+    const VT zv = XK_LDV(z);
+    VT pv = XK_LDV(p);
+#pragma unroll
+    for (int q = 0; q < CV; ++q) {
+      const cx<T> bp = cmul(beta, cx<T>{pv[2 * q], pv[2 * q + 1]});
+      pv[2 * q] = zv[2 * q] + bp.re;
+      pv[2 * q + 1] = zv[2 * q + 1] + bp.im;
+    }
+    XK_STV(p, pv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Banded operator, DIA storage band[b, d, i] = A_b[i, i + d - hb]   (nd = 2*hb+1 diagonals)
 //   trans=0: y[b,c,i] = sum_d band[b,d,i] * x[b,c,i+d-hb]
 //   trans=1: y[b,c,j] = sum_d band[b,d,j-(d-hb)] * x[b,c,j-(d-hb)]
@@ -534,5 +838,70 @@ int xk_kry_max_partials(void) { return xk::KRY_MAX_PART; }
 
 XK_DEFINE_KRY(f64, double)
 XK_DEFINE_KRY(f32, float)
+
+// complex families: T* arguments point at interleaved (re, im) storage; N, ld in complex elements; eps real
+#define XK_DEFINE_KRYC(SUF, T)                                                                            \
+  int xk_kry_dots_##SUF(const T* x1, T* y1, const T* x2, const T* y2, const T* shiftz, const T* E, T* P1, \
+                        T* P2, int S, int N, long ld, int nblk, int conj1, void* stream) {                \
+    XK_CHECK_KRY                                                                                          \
+    hipLaunchKernelGGL((xk::kry_dots_c_kernel<T>), XK_GRID(S, nblk), x1, y1, x2, y2, shiftz, E, P1, P2, N, \
+                       ld, nblk, (x1 == y1) ? 1 : 0, conj1);                                              \
+    XK_LAUNCH_CHECK();                                                                                    \
+    return XK_OK;                                                                                         \
+  }                                                                                                       \
+  int xk_bicg_p_##SUF(const T* r, T* p, const T* v, const T* Prho_new, const T* rho_old, const T* alpha,  \
+                      const T* omega, T* rho_store, int S, int N, long ld, int nblk, double eps,          \
+                      int first, void* stream) {                                                          \
+    XK_CHECK_KRY                                                                                          \
+    hipLaunchKernelGGL((xk::bicg_p_c_kernel<T>), XK_GRID(S, nblk), r, p, v, Prho_new, rho_old, alpha,      \
+                       omega, rho_store, N, ld, nblk, (T)eps, first);                                     \
+    XK_LAUNCH_CHECK();                                                                                    \
+    return XK_OK;                                                                                         \
+  }                                                                                                       \
+  int xk_bicg_s_##SUF(const T* r, const T* v, T* sv, const T* rho, const T* Pr0v, T* alpha_store, int S,   \
+                      int N, long ld, int nblk, double eps, void* stream) {                               \
+    XK_CHECK_KRY                                                                                          \
+    hipLaunchKernelGGL((xk::bicg_s_c_kernel<T>), XK_GRID(S, nblk), r, v, sv, rho, Pr0v, alpha_store, N,    \
+                       ld, nblk, (T)eps);                                                                 \
+    XK_LAUNCH_CHECK();                                                                                    \
+    return XK_OK;                                                                                         \
+  }                                                                                                       \
+  int xk_bicg_final_##SUF(const T* x, T* xout, const T* yd, const T* zd, const T* sv, const T* t, T* r,    \
+                          const T* r0, const T* alpha, const T* Pts, const T* Ptt, T* omega_store,        \
+                          T* Prr, T* Prho, int S, int N, long ld, int nblk, double eps, int skip_r,       \
+                          void* stream) {                                                                 \
+    XK_CHECK_KRY                                                                                          \
+    hipLaunchKernelGGL((xk::bicg_final_c_kernel<T>), XK_GRID(S, nblk), x, xout, yd, zd, sv, t, r, r0,      \
+                       alpha, Pts, Ptt, omega_store, Prr, Prho, N, ld, nblk, (T)eps, skip_r);             \
+    XK_LAUNCH_CHECK();                                                                                    \
+    return XK_OK;                                                                                         \
+  }                                                                                                       \
+  int xk_kry_resid_##SUF(const T* b, const T* y, T* r, const T* r0, T* Prr, T* Prho, int S, int N,         \
+                         long ld, int nblk, void* stream) {                                               \
+    XK_CHECK_KRY                                                                                          \
+    hipLaunchKernelGGL((xk::kry_resid_c_kernel<T>), XK_GRID(S, nblk), b, y, r, r0, Prr, Prho, N, ld,       \
+                       nblk);                                                                             \
+    XK_LAUNCH_CHECK();                                                                                    \
+    return XK_OK;                                                                                         \
+  }                                                                                                       \
+  int xk_cg_update_##SUF(const T* x, T* xout, const T* p, const T* Ap, T* r, const T* Prz, const T* PpAp,  \
+                         T* Prr, int S, int N, long ld, int nblk, double eps, int skip_r, void* stream) { \
+    XK_CHECK_KRY                                                                                          \
+    hipLaunchKernelGGL((xk::cg_update_c_kernel<T>), XK_GRID(S, nblk), x, xout, p, Ap, r, Prz, PpAp, Prr,   \
+                       N, ld, nblk, (T)eps, skip_r);                                                      \
+    XK_LAUNCH_CHECK();                                                                                    \
+    return XK_OK;                                                                                         \
+  }                                                                                                       \
+  int xk_cg_p_##SUF(const T* z, T* p, const T* Prz_new, const T* Prz_old, int S, int N, long ld,           \
+                    int nblk, double eps, void* stream) {                                                 \
+    XK_CHECK_KRY                                                                                          \
+    hipLaunchKernelGGL((xk::cg_p_c_kernel<T>), XK_GRID(S, nblk), z, p, Prz_new, Prz_old, N, ld, nblk,      \
+                       (T)eps);                                                                           \
+    XK_LAUNCH_CHECK();                                                                                    \
+    return XK_OK;                                                                                         \
+  }
+
+XK_DEFINE_KRYC(c128, double)
+XK_DEFINE_KRYC(c64, float)
 
 }  // extern "C"

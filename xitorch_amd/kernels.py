@@ -301,6 +301,76 @@ def broyden_axpy(out, u0=None, g0=0.0, u1=None, g1=0.0, V=None, coef=None, scale
     return out
 
 
+# --------------------------------------------------------------------------- complex operators (real embedding)
+def _as_real_matrix(A):
+    """zero-copy real view (.., M, 2N) of a complex matrix (.., M, N): row i = (Re A_i0, Im A_i0, Re A_i1, ...)"""
+    Ar = torch.view_as_real(A)
+    return Ar.reshape(*A.shape[:-1], 2 * A.shape[-1])
+
+
+def dense_mm_complex(A, X, adjoint=False, conj_io=False, out=None):
+    """Complex operator-panel product on the REAL kernels (K1): the interleaved storage of A (B, M, N) complex is
+    a real (B, M, 2N) matrix, and
+
+        A x       : Re y = A~ . real(conj x),   Im y = A~ . real(i conj x)      -> xk_dense_mm(trans=0), 2P columns
+        A^H x     : Z = A~^T [Re x; Im x];  Re y_j = Z[re, 2j] + Z[im, 2j+1],  Im y_j = Z[im, 2j] - Z[re, 2j+1]
+                                                                                 -> xk_dense_mm(trans=1), 2P columns
+
+    so the operator is streamed ONCE per product, exactly like the real case, and never copied or split.
+    conj_io conjugates input and output (serves A^T x = conj(A^H conj x) and conj(A) x = conj(A conj x), i.e.
+    transposed / conjugated *views* of the stored matrix).  X: (B, P, n_in) complex panel-major; returns
+    (B, P, n_out) complex.  Replaces torch.matmul(mat, x) of MatrixLinearOperator for complex dtypes
+    (xitorch/_core/linop.py:692-702; reference tests: _tests/test_linop_fcns.py:474-524)."""
+    require_device(A, "operator matrix")
+    require_device(X, "panel")
+    if A.is_conj() or X.is_conj():
+        raise _capi.NativeLibraryError("dense_mm_complex takes resolved tensors (conjugate views are expressed "
+                                       "through adjoint/conj_io)")
+    B, P = X.shape[0], X.shape[1]
+    Ar = _as_real_matrix(A)
+    M, N = A.shape[-2], A.shape[-1]
+    rdtype = Ar.dtype
+    if conj_io:
+        X = X.conj().resolve_conj()
+    if not adjoint:
+        xc = X.conj().resolve_conj()
+        U = torch.empty((B, 2 * P, 2 * N), dtype=rdtype, device=X.device)
+        Uv = U.view(B, 2 * P, N, 2)
+        Uv[:, :P, :, 0] = xc.real
+        Uv[:, :P, :, 1] = xc.imag          # real(conj x)   = (xr, -xi)
+        Uv[:, P:, :, 0] = X.imag
+        Uv[:, P:, :, 1] = X.real           # real(i conj x) = (xi,  xr)
+        Y = dense_mm(Ar, U, trans=False)                                  # (B, 2P, M)
+        res = torch.complex(Y[:, :P], Y[:, P:])
+    else:
+        U = torch.cat([X.real, X.imag], dim=1).contiguous()                # (B, 2P, M)
+        Z = dense_mm(Ar, U, trans=True).view(B, 2 * P, N, 2)               # (B, 2P, 2N)
+        res = torch.complex(Z[:, :P, :, 0] + Z[:, P:, :, 1], Z[:, P:, :, 0] - Z[:, :P, :, 1])
+    if conj_io:
+        res = res.conj().resolve_conj()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def dense_outer_complex(U, W):
+    """G[b,i,j] = sum_c U[b,c,i] conj(W[b,c,j])  (complex panels) through the real streaming kernel xk_dense_outer:
+    in the interleaved storage G~[i, 2j] = sum Ur Wr + Ui Wi, G~[i, 2j+1] = sum Ui Wr - Ur Wi — a real outer product
+    with 2C columns.  The operator gradient gy x^H of the complex dense apply."""
+    B, C, M = U.shape
+    N = W.shape[2]
+    Ur = torch.cat([U.real, U.imag], dim=1).contiguous()                   # (B, 2C, M)
+    Wr = torch.empty((B, 2 * C, 2 * N), dtype=Ur.dtype, device=U.device)
+    Wv = Wr.view(B, 2 * C, N, 2)
+    Wv[:, :C, :, 0] = W.real
+    Wv[:, :C, :, 1] = -W.imag            # rows paired with Re U:  (Wr, -Wi)
+    Wv[:, C:, :, 0] = W.imag
+    Wv[:, C:, :, 1] = W.real             # rows paired with Im U:  (Wi,  Wr)
+    G = dense_outer(Ur, Wr)                                                # (B, M, 2N) real
+    return torch.view_as_complex(G.view(B, M, N, 2))
+
+
 # --------------------------------------------------------------------------- CU-masked stream
 _MASKED_STREAMS = {}
 

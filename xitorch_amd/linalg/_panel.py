@@ -45,9 +45,17 @@ class PanelOperator:
         for d in A.shape[:-2]:
             nA *= d
         native_t = lambda t: t.is_cuda and t.dtype in (torch.float64, torch.float32)
-        if isinstance(A, MatrixLinearOperator) and native_t(A.mat) and (nA == Bt or nA == 1):
+        native_c = lambda t: t.is_cuda and t.dtype in (torch.complex128, torch.complex64)
+        self.cplx, self.cj = False, False
+        if isinstance(A, MatrixLinearOperator) and (native_t(A.mat) or native_c(A.mat)) and (nA == Bt or nA == 1):
             mat = A.mat
             flip = False
+            if native_c(mat):
+                # complex operator: applied by the real K1 kernels on its interleaved storage (K.dense_mm_complex);
+                # lazily conjugated / transposed views (A.H = mat^T.conj()) only set orientation flags
+                self.cplx = True
+                if mat.is_conj():
+                    mat, self.cj = mat.conj(), True
             if mat.dim() >= 2 and mat.stride(-1) != 1 and mat.stride(-2) == 1:
                 mat, flip = mat.transpose(-2, -1), True           # a transposed view (e.g. A.H)
             if mat.is_contiguous() or mat.dim() == 2 and mat.stride(-1) == 1:
@@ -57,7 +65,7 @@ class PanelOperator:
                 vn = 2 if mat.dtype == torch.float64 else 4
                 # exactly symmetric storage: stream the upper triangle only (K1s)
                 self.symm = bool(getattr(A, "symmetric_storage", False)) and N % vn == 0 and \
-                    self.mat.stride(-2) % vn == 0
+                    self.mat.stride(-2) % vn == 0 and not self.cplx
         elif isinstance(A, BandedLinearOperator) and native_t(A.band) and (nA == Bt or nA == 1) \
                 and A.band.is_contiguous():
             self.kind = "banded"
@@ -131,6 +139,11 @@ class PanelOperator:
 
     def _native(self, X, out, trans):
         N = self.N
+        if self.kind == "dense" and self.cplx:
+            # stored matrix S, operator = S / S^T / conj(S) / S^H by (flip, cj); trans asks for the operator's adjoint
+            K.dense_mm_complex(self.mat if self.mat.dim() == 3 else self.mat.unsqueeze(0), X[:, :, :N],
+                               adjoint=(self.flip != trans), conj_io=(self.flip != self.cj), out=out[:, :, :N])
+            return out
         if self.kind == "dense" and self.symm and X.shape[1] < K.WIDE_MIN_P:
             K.dense_symm(self.mat, X[:, :, :N], out=out[:, :, :N])
         elif self.kind == "dense":

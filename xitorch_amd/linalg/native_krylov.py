@@ -82,9 +82,14 @@ class _Problem:
         if dev.type != "cuda":
             raise NativeLibraryError("xitorch_amd native solvers run on a HIP device only (operator is on %s); "
                                      "there is no CPU fallback" % dev)
-        if A.dtype not in (torch.float64, torch.float32):
-            raise NativeLibraryError("xitorch_amd native solvers support float64/float32, got %s" % A.dtype)
+        if A.dtype not in (torch.float64, torch.float32, torch.complex128, torch.complex64):
+            raise NativeLibraryError("xitorch_amd native solvers support float64/float32/complex128/complex64, "
+                                     "got %s" % A.dtype)
         self.dtype, self.device = A.dtype, dev
+        self.cplx = A.dtype.is_complex
+        # element type of the kernels' scalars / partials, and complex elements per 16 B vector (block sizing)
+        self.rdtype = {torch.complex128: torch.float64, torch.complex64: torch.float32}.get(A.dtype, A.dtype)
+        self.vec_elems = {torch.float64: 2, torch.float32: 4, torch.complex128: 1, torch.complex64: 2}[A.dtype]
         self.bdims = list(bdims)
         self.N = A.shape[-1]
         self.nc = B.shape[-1]
@@ -97,7 +102,7 @@ class _Problem:
         self.opM = PanelOperator(M, self.bdims, self.Bt, self.N) if (M is not None and E is not None) else None
         self.E = None
         if E is not None:
-            self.E = E.to(self.dtype).expand(*self.bdims, self.nc).reshape(self.Bt, self.nc).contiguous()
+            self.E = E.to(self.dtype).expand(*self.bdims, self.nc).reshape(self.Bt, self.nc).resolve_conj().contiguous()
         self._tmp = None
         self._tmp2 = None
         self._scratchP = None
@@ -127,15 +132,18 @@ class _Problem:
         self.opM.apply(X, self._tmp2, trans=trans)
         return self._tmp2
 
+    def nblk(self):
+        vn = self.vec_elems
+        return max(1, min(fn("xk_kry_max_partials")(), (self.N + 256 * vn * 4 - 1) // (256 * vn * 4)))
+
     def _shift_now(self, out, Z):
         """out -= E * Z in place through xk_kry_dots' shift stage (its dot product goes to a scratch partial)."""
         if self._scratchP is None:
-            self._scratchP = torch.zeros((self.S, 64), dtype=self.dtype, device=self.device)
-        vn = 2 if self.dtype == torch.float64 else 4
-        nblk = max(1, min(fn("xk_kry_max_partials")(), (self.N + 256 * vn * 4 - 1) // (256 * vn * 4)))
+            self._scratchP = torch.zeros((self.S, 64, 2 if self.cplx else 1), dtype=self.rdtype, device=self.device)
+        extra = (0,) if self.cplx else ()
         check(fn("xk_kry_dots_" + suffix(self.dtype))(ptr(out), ptr(out), ptr(None), ptr(None), ptr(Z), ptr(self.E),
-                                                      ptr(self._scratchP), ptr(None), self.S, self.N, self.ld, nblk,
-                                                      stream_ptr()), "xk_kry_dots")
+                                                      ptr(self._scratchP), ptr(None), self.S, self.N, self.ld,
+                                                      self.nblk(), *extra, stream_ptr()), "xk_kry_dots")
 
     def _apply1(self, X, out, trans=False, defer=False):
         """out = A X - E * (M X)  (solve.py:590-604).  defer=True leaves the shift to the caller's next
@@ -199,32 +207,45 @@ class _Problem:
 
 
 class _Kry:
-    """ctypes plumbing of the fused Krylov kernels on (S, ld) arrays."""
+    """ctypes plumbing of the fused Krylov kernels on (S, ld) arrays (real or interleaved complex)."""
 
     def __init__(self, prob):
         self.S, self.N, self.ld = prob.S, prob.N, prob.ld
-        self.sfx = suffix(prob.dtype)
-        vn = 2 if prob.dtype == torch.float64 else 4
-        self.nblk = max(1, min(fn("xk_kry_max_partials")(), (prob.N + 256 * vn * 4 - 1) // (256 * vn * 4)))
-        self.dtype, self.device = prob.dtype, prob.device
+        self.sfx = suffix(prob.dtype)                      # f64 / f32 / c128 / c64: the vector kernels
+        self.rsfx = suffix(prob.rdtype)                    # the (real) status kernel
+        self.cplx = prob.cplx
+        self.nblk = prob.nblk()
+        self.dtype, self.rdtype, self.device = prob.dtype, prob.rdtype, prob.device
         self.E = prob.E
         self.status = torch.zeros((2,), dtype=torch.float64, device=prob.device)
-        self.rnorm = torch.zeros((prob.S,), dtype=prob.dtype, device=prob.device)
+        self.rnorm = torch.zeros((prob.S,), dtype=prob.rdtype, device=prob.device)
 
     def partial(self):
-        return torch.zeros((self.S, 64), dtype=self.dtype, device=self.device)
+        """block partials of an inner product: (S, 64) real, or (S, 64, 2) for complex products"""
+        shape = (self.S, 64, 2) if self.cplx else (self.S, 64)
+        return torch.zeros(shape, dtype=self.rdtype, device=self.device)
+
+    def partial_real(self):
+        """block partials of |r|^2 (always real, consumed by xk_kry_status)"""
+        return torch.zeros((self.S, 64), dtype=self.rdtype, device=self.device)
 
     def scalar(self, val=0.0):
-        return torch.full((self.S,), val, dtype=self.dtype, device=self.device)
+        if not self.cplx:
+            return torch.full((self.S,), val, dtype=self.dtype, device=self.device)
+        t = torch.zeros((self.S, 2), dtype=self.rdtype, device=self.device)
+        t[:, 0] = val
+        return t
 
     def _c(self, name, *args):
         check(fn("xk_%s_%s" % (name, self.sfx))(*args, stream_ptr()), "xk_" + name)
 
-    def dots(self, x1, y1, P1, x2=None, y2=None, P2=None, shift=None):
-        """partials of <x1,y1> (and <x2,y2>); shift = Z: first y1 -= E * Z in the same pass (the `- M X E` term of
-        the operator, solve.py:590-595, folded into the reduction that follows every apply)."""
+    def dots(self, x1, y1, P1, x2=None, y2=None, P2=None, shift=None, conj1=False):
+        """partials of <x1,y1> (and <x2,y2>), <x,y> = sum conj(x) y; shift = Z: first y1 -= E * Z in the same pass
+        (the `- M X E` term of the operator, solve.py:590-595, folded into the reduction that follows every apply);
+        conj1 (complex only): P1 <- <y1,x1> instead."""
+        extra = ((1 if conj1 else 0),) if self.cplx else ()
         self._c("kry_dots", ptr(x1), ptr(y1), ptr(x2), ptr(y2), ptr(shift), ptr(self.E if shift is not None else None),
-                ptr(P1), ptr(P2), self.S, self.N, self.ld, self.nblk)
+                ptr(P1), ptr(P2), self.S, self.N, self.ld, self.nblk, *extra)
 
     def bicg_p(self, r, p, v, Prho, rho_old, alpha, omega, rho_store, eps, first):
         self._c("bicg_p", ptr(r), ptr(p), ptr(v), ptr(Prho), ptr(rho_old), ptr(alpha), ptr(omega),
@@ -239,7 +260,17 @@ class _Kry:
                 ptr(Pts), ptr(Ptt), ptr(omega), ptr(Prr), ptr(Prho), self.S, self.N, self.ld, self.nblk,
                 float(eps), 1 if skip_r else 0)
 
-    def resid(self, b, y, r, r0, Prr, Prho):
+    def resid(self, b, y, r, r0, Prr, Prho, init=False):
+        """r = b - y with partials |r|^2 -> Prr (real) and <r0, r> -> Prho; init=True: only the partials of the
+        vector `b` itself (y is taken as zero: the kernel is run with y = a zero panel once)."""
+        if init:
+            if getattr(self, "_zero", None) is None or self._zero.shape != b.shape:
+                self._zero = torch.zeros_like(b)
+            self._scr = torch.empty_like(b)
+            self._c("kry_resid", ptr(b), ptr(self._zero), ptr(self._scr), ptr(r0), ptr(Prr), ptr(Prho), self.S,
+                    self.N, self.ld, self.nblk)
+            self._scr = None
+            return
         self._c("kry_resid", ptr(b), ptr(y), ptr(r), ptr(r0), ptr(Prr), ptr(Prho), self.S, self.N, self.ld,
                 self.nblk)
 
@@ -253,8 +284,8 @@ class _Kry:
 
     def check_status(self, Prr, stop, process_group=None):
         """-> (max residual norm over all systems, number of unconverged systems): the one host sync."""
-        check(fn("xk_kry_status_" + self.sfx)(ptr(Prr), ptr(stop), ptr(self.rnorm), ptr(self.status), self.S,
-                                              self.nblk, stream_ptr()), "xk_kry_status")
+        check(fn("xk_kry_status_" + self.rsfx)(ptr(Prr), ptr(stop), ptr(self.rnorm), ptr(self.status), self.S,
+                                               self.nblk, stream_ptr()), "xk_kry_status")
         # MAX over the ranks of both entries: max residual, and "someone is unconverged" (count > 0)
         allreduce_max_(self.status, process_group)
         mx, nbad = self.status.tolist()
@@ -342,11 +373,12 @@ def bicgstab(A, B, E=None, M=None, posdef=None, precond_l=None, precond_r=None, 
     Ks = prob.new() if pl is not None else s
     tmp = prob.new()
     ring = _XRing(prob)
-    Prho, Pr0v, Pts, Ptt, Prr = (kr.partial() for _ in range(5))
+    Prho, Pr0v, Pts, Ptt = (kr.partial() for _ in range(4))
+    Prr = kr.partial_real()
     rho = [kr.scalar(), kr.scalar()]
     alpha, omega = kr.scalar(1.0), kr.scalar(1.0)
 
-    kr.dots(r, r, Prr, r0, r, Prho)
+    kr.resid(r, None, None, r0, Prr, Prho, init=True)              # |r|^2 and <r0, r> of the initial residual
     best, _ = kr.check_status(Prr, stop, process_group)
     converged = False
     niter = 0
@@ -364,7 +396,7 @@ def bicgstab(A, B, E=None, M=None, posdef=None, precond_l=None, precond_r=None, 
         if pl is not None:
             pl.apply(t, Kt)
             pl.apply(s, Ks)
-        kr.dots(Ks, Kt, Pts, Kt, Kt, Ptt, shift=sh)
+        kr.dots(Ks, Kt, Pts, Kt, Kt, Ptt, shift=sh, conj1=True)    # <t, s> (solve.py:286) and <t, t>
         refresh = resid_calc_every != 0 and k % resid_calc_every == 0
         nxt = ring.next_index()
         kr.bicg_final(ring.bufs[ring.cur], ring.bufs[nxt], y, z, s, t, r, r0, alpha, Pts, Ptt, omega, Prr, Prho,
@@ -437,8 +469,9 @@ def cg(A, B, E=None, M=None, posdef=None, precond=None, max_niter=None, rtol=1e-
     Ap, tmp = prob.new(), prob.new()
     ring = _XRing(prob)
     Prz = [kr.partial(), kr.partial()]
-    PpAp, Prr = kr.partial(), kr.partial()
-    kr.dots(r, r, Prr, r, z, Prz[0])
+    PpAp, Prr = kr.partial(), kr.partial_real()
+    kr.resid(r, None, None, None, Prr, None, init=True)            # |r|^2 of the initial residual
+    kr.dots(r, z, Prz[0])
     best, _ = kr.check_status(Prr, stop, process_group)
     converged = False
     cur = 0
@@ -499,6 +532,9 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
         Replacement of exact zeros in denominators
     """
     nr, ncols = A.shape[-1], B.shape[-1]
+    if A.dtype.is_complex:
+        # the reference's own gmres is real-only as well (its tests xfail complex input, test_linop_fcns.py:479-481)
+        raise NativeLibraryError("xitorch_amd gmres supports real operators only, like the reference's gmres")
     if max_niter is None:
         max_niter = int(nr)
     max_niter = min(max_niter, nr)

@@ -377,7 +377,14 @@ class MulLinearOperator(LinearOperator):
 
 
 # ------------------------------------------------------------------------ native dense operator
+_NATIVE_DTYPES = (torch.float64, torch.float32, torch.complex128, torch.complex64)
+
+
 def _native_dtype(t):
+    return t.is_cuda and t.dtype in _NATIVE_DTYPES
+
+
+def _native_real_dtype(t):
     return t.is_cuda and t.dtype in (torch.float64, torch.float32)
 
 
@@ -410,33 +417,37 @@ def _sum_to_shape(t, shape):
 
 
 def dense_apply(mat, x, trans=False):
-    """``mat @ x`` (or ``mat^T @ x``) through the K1 HIP kernel for HIP float tensors.
+    """``mat @ x`` (or ``mat^H @ x``) through the K1 HIP kernel for HIP float / complex tensors.
 
     mat ``(*BA, M, N)``, x ``(*BX, n_in, r)`` with broadcastable batch dims.  Batch dims along
     which only ``x`` varies are folded into the panel width so the operator is streamed once.
-    Never copies ``mat`` when it is contiguous or a transposed view of a contiguous matrix.
+    Never copies ``mat`` when it is contiguous or a transposed / conjugated view of a contiguous matrix:
+    views flip the kernel's orientation flags instead.
     """
-    if mat.stride(-1) != 1 and mat.stride(-2) == 1 and mat.dim() >= 2:
+    cplx = mat.is_complex()
+    conj_io = False
+    if cplx:
+        cj = mat.is_conj()
+        if cj:
+            mat = mat.conj()                              # drops the lazy-conjugation bit: the stored numbers
+        flip = mat.dim() >= 2 and mat.stride(-1) != 1 and mat.stride(-2) == 1
+        if flip:
+            mat = mat.transpose(-2, -1)
+        trans = (trans != flip)                            # adjoint of the STORED matrix wanted?
+        conj_io = (flip != cj)                             # A^T x = conj(A^H conj x), conj(A) x = conj(A conj x)
+        x = x.resolve_conj()
+    elif mat.stride(-1) != 1 and mat.stride(-2) == 1 and mat.dim() >= 2:
         mat, trans = mat.transpose(-2, -1), not trans      # a transposed view: flip the kernel
     M, N = mat.shape[-2:]
     n_in, n_out = (M, N) if trans else (N, M)
     r = x.shape[-1]
-    BA, BX = list(mat.shape[:-2]), list(x.shape[:-2])
-    nb = max(len(BA), len(BX))
-    BAp = [1] * (nb - len(BA)) + BA
-    BXp = [1] * (nb - len(BX)) + BX
-    FB = bcast_shape(BAp, BXp)
-    keep = [d for d in range(nb) if BAp[d] == FB[d]]
-    fold = [d for d in range(nb) if BAp[d] != FB[d]]
-    nkeep = 1
-    for d in keep:
-        nkeep *= FB[d]
-    xe = x.reshape(*BXp, n_in, r).expand(*FB, n_in, r)
-    xp = xe.permute(*keep, *fold, nb + 1, nb).reshape(nkeep, -1, n_in)      # panel-major copy
-    if xp.stride(-1) != 1 or (xp.shape[1] > 1 and xp.stride(1) < n_in):
-        xp = xp.contiguous()
+    nb, FB, keep, fold = _batch_plan(list(mat.shape[:-2]), list(x.shape[:-2]))
+    xp = _to_panel(x, nb, FB, keep, fold)                                    # panel-major (copy only if needed)
     matf = mat.reshape(-1, M, N) if mat.is_contiguous() else mat.contiguous().reshape(-1, M, N)
-    y = _k.dense_mm(matf, xp, trans=trans)                                   # (nkeep, P, n_out)
+    if cplx:
+        y = _k.dense_mm_complex(matf, xp, adjoint=trans, conj_io=conj_io)    # (nkeep, P, n_out)
+    else:
+        y = _k.dense_mm(matf, xp, trans=trans)
     y = y.reshape(*[FB[d] for d in keep], *[FB[d] for d in fold], r, n_out)
     inv = [0] * (nb + 2)
     for pos, d in enumerate(keep + fold + [nb + 1, nb]):
@@ -505,7 +516,10 @@ class _DenseOuter(torch.autograd.Function):
         M, N = mat_shape[-2:]
         nb, FB, keep, fold = _batch_plan(mat_shape[:-2], u.shape[:-2], w.shape[:-2])
         up, wp = _to_panel(u, nb, FB, keep, fold), _to_panel(w, nb, FB, keep, fold)
-        g = _k.dense_outer(up, wp)                                      # (nkeep, M, N): folded dims summed
+        if u.is_complex():
+            g = _k.dense_outer_complex(up.resolve_conj(), wp.resolve_conj())    # sum_c u conj(w): gy x^H
+        else:
+            g = _k.dense_outer(up, wp)                                  # (nkeep, M, N): folded dims summed
         return g.reshape(*[FB[d] for d in keep], M, N).reshape(mat_shape)
 
     @staticmethod
@@ -524,14 +538,14 @@ def _dense_mm(mat, x, trans):
         if not x.is_cuda:
             raise RuntimeError("operator lives on %s but the operand on %s" % (mat.device, x.device))
         return _DenseMM.apply(mat, x, trans)
-    # host tensors / complex dtypes: plain torch (not the accelerated path)
+    # host tensors / mixed dtypes: plain torch (not the accelerated path)
     op = mat.transpose(-2, -1).conj() if trans else mat
     return torch.matmul(op, x)
 
 
 class MatrixLinearOperator(LinearOperator):
-    """Dense operator.  HIP float32/float64 matrices are applied by the K1 kernel
-    (replaces linop.py:676-708 of the reference)."""
+    """Dense operator.  HIP float32/float64 matrices are applied by the K1 kernel, complex64/complex128 ones by
+    the same kernel on their interleaved (real-embedded) storage (replaces linop.py:676-708 of the reference)."""
 
     def __init__(self, mat, is_hermitian, symmetric_storage=False):
         super().__init__(shape=mat.shape, is_hermitian=is_hermitian, dtype=mat.dtype, device=mat.device,
@@ -691,7 +705,7 @@ class BandedLinearOperator(LinearOperator):
         self.band = band
 
     def _apply(self, x, trans):
-        if _native_dtype(self.band) and x.dtype == self.band.dtype:
+        if _native_real_dtype(self.band) and x.dtype == self.band.dtype:
             return _BandedMM.apply(self.band, x, trans)
         return banded_apply_torch(self.band, x, trans)
 

@@ -427,24 +427,37 @@ def _nonlin_solver(fcn, x0, params, jacobian, maxiter=None, f_tol=None, f_rtol=N
         line_search = "armijo"
     elif line_search is False:
         line_search = None
-    if torch.is_complex(x0):
-        raise NativeLibraryError("complex variables are not supported by the native root solvers")
     xshape = x0.shape
-    func = lambda x: fcn(x.reshape(xshape), *params).reshape(-1)
+    if torch.is_complex(x0):
+        # a complex unknown is solved as the real vector [Re x; Im x] of twice the length, exactly like the
+        # reference (rootsolver.py:52-73): real parts first, then imaginary parts
+        def ravel(t):
+            return torch.cat((t.real, t.imag), dim=0).reshape(-1)
+
+        def pack(v):
+            n = v.numel() // 2
+            return torch.complex(v[:n], v[n:]).reshape(xshape)
+    else:
+        def ravel(t):
+            return t.reshape(-1)
+
+        def pack(v):
+            return v.reshape(xshape)
+    func = lambda x: ravel(fcn(pack(x), *params))
     nfev = [0]
 
     def cfunc(x):
         nfev[0] += 1
         return func(x)
 
-    x = x0.reshape(-1)
+    x = ravel(x0)
     y = cfunc(x)
     y2, x2 = red.dots([(y, y), (x, x)])
     y_norm = y2 ** 0.5
     stop_cond = custom_terminator if custom_terminator is not None else \
         _Termination(f_tol, f_rtol, y_norm, x_tol, x_rtol, red)
     if y_norm == 0:
-        return x.reshape(xshape)
+        return pack(x)
     jacobian.setup(x, y, cfunc, red)
     neg_solve = getattr(jacobian, "neg_solve", None)
 
@@ -492,7 +505,7 @@ def _nonlin_solver(fcn, x0, params, jacobian, maxiter=None, f_tol=None, f_rtol=N
                                          "Best |dx|=%.3e, |f|=%.3e at iter %d"
                                          % (maxiter, best_dxnorm, best_ynorm, best_iter)))
         x = best_x
-    return x.reshape(xshape)
+    return pack(x)
 
 
 def newton(fcn, x0, params=(), *, solver_method="exactsolve", solver_kwargs=None, **kwargs):
