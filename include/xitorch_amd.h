@@ -152,6 +152,20 @@ int xk_small_eigh_f64(const double* T, double* lam, double* Y, double* ws, long 
 int xk_small_eigh_f32(const float* T, float* lam, float* Y, float* ws, long ws_elems, int* sweeps,
                       int B, int k, int p, int uppest, int max_sweeps, long ldt, long sT, void* stream);
 
+/* ---- K3t: the same p eigenpairs by Householder tridiagonalisation + bisection + inverse iteration ------
+ * (the LAPACK dsyevx route), one workgroup per matrix, LDS-resident: the O(k^3) work is ONE tridiagonalisation
+ * instead of ~8 Jacobi sweeps over the whole matrix, which is what the Davidson loop — interested in p << k
+ * pairs only (symeig.py:174-175, 255-264) — needs.  Same outputs as xk_small_eigh_*; info[b] != 0 flags a
+ * batch member whose result failed the kernel's residual / orthogonality check (caller re-runs on the Jacobi
+ * kernel).  Returns XK_ERR_UNSUPPORTED when xk_small_eigh_tri_lds_bytes(k, p, elem_size) exceeds 160 KiB. */
+long xk_small_eigh_tri_lds_bytes(int k, int p, int elem_size);
+int xk_small_eigh_tri_set_threads(int nthreads);   /* tuning knob: workgroup size (multiple of 64), 0 = default */
+int xk_small_eigh_tri_set_profile(long long* device_buf);   /* profiling: cycle stamps of the kernel's phases (NULL = off) */
+int xk_small_eigh_tri_f64(const double* T, double* lam, double* Y, int* info, int B, int k, int p, int uppest,
+                          long ldt, long sT, void* stream);
+int xk_small_eigh_tri_f32(const float* T, float* lam, float* Y, int* info, int B, int k, int p, int uppest, long ldt,
+                          long sT, void* stream);
+
 /* ---- banded operator (DIA storage) -------------------------------------------------------------
  * band (B, 2*hb+1, N), band[b,d,i] = A_b[i, i+d-hb]; entries outside the matrix are ignored.
  * trans=0: Y[b,c,i] = sum_d band[b,d,i] X[b,c,i+d-hb];  trans=1: the transposed operator.

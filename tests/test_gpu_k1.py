@@ -173,3 +173,86 @@ def test_exact_symmetry_detection_large_batched(dev):
     y2 = PanelOperator(A2, [5], 5, 2048).apply(Xp, torch.zeros_like(Xp))
     assert PanelOperator(A, [5], 5, 2048).symm and not PanelOperator(A2, [5], 5, 2048).symm
     assert torch.allclose(y1, y2, rtol=1e-12, atol=1e-9)
+
+
+def _tri_case(kind, B, k, g):
+    """projected matrices for the tridiagonalisation kernel: generic, Davidson-like (isolated low eigenvalues +
+    a dense bulk), tight clusters, exact multiplicities, already-tridiagonal / diagonal input (zero reflectors)"""
+    f64 = torch.float64
+    if kind == "generic":
+        R = torch.randn(B, k, k, dtype=f64, generator=g)
+        return (R + R.transpose(-2, -1)) * 0.5 + torch.diag(torch.arange(k, dtype=f64))
+    Q, _ = torch.linalg.qr(torch.randn(B, k, k, dtype=f64, generator=g))
+    if kind == "davidson":
+        d = torch.cat([torch.arange(1.0, 7.0, dtype=f64), 50.0 + 50.0 * torch.rand(max(k - 6, 0), dtype=f64, generator=g)])[:k]
+    elif kind == "cluster":
+        d = torch.linspace(1.0, 90.0, k, dtype=f64)
+        d[:min(4, k)] = 1.0 + 1e-9 * torch.arange(min(4, k), dtype=f64)       # four eigenvalues within 3e-9
+    elif kind == "multiple":
+        d = torch.linspace(3.0, 40.0, k, dtype=f64)
+        d[:min(3, k)] = 2.0                                                   # an exactly triple eigenvalue
+        d[-2:] = 77.0
+    elif kind == "diagonal":
+        return torch.diag_embed(torch.rand(B, k, dtype=f64, generator=g) * 10.0 - 3.0)
+    elif kind == "tridiagonal":
+        T = torch.diag_embed(torch.rand(B, k, dtype=f64, generator=g) * 10.0)
+        e = torch.rand(B, k - 1, dtype=f64, generator=g)
+        return T + torch.diag_embed(e, offset=1) + torch.diag_embed(e, offset=-1)
+    T = Q @ torch.diag_embed(d.expand(B, k)) @ Q.transpose(-2, -1)
+    return (T + T.transpose(-2, -1)) * 0.5
+
+
+@pytest.mark.parametrize("kind", ["generic", "davidson", "cluster", "multiple", "diagonal", "tridiagonal"])
+@pytest.mark.parametrize("B,k,p,uppest,dtype", [(3, 12, 6, False, torch.float64), (2, 37, 4, True, torch.float64),
+                                                 (5, 108, 6, False, torch.float64), (2, 112, 10, True, torch.float64),
+                                                 (64, 54, 6, False, torch.float64), (2, 33, 3, False, torch.float32),
+                                                 (1, 1, 1, False, torch.float64), (2, 2, 2, True, torch.float64),
+                                                 (2, 3, 1, False, torch.float64), (2, 7, 7, False, torch.float64),
+                                                 (3, 65, 6, True, torch.float64), (2, 128, 2, False, torch.float64)])
+def test_small_eigh_tridiagonalisation_kernel(dev, kind, B, k, p, uppest, dtype):
+    """K3t (Householder tridiagonalisation + bisection + inverse iteration) against CPU LAPACK eigh — what the oracle
+    calls at symeig.py:174 — : eigenvalues, residuals, orthonormality, ascending order, self-check flags"""
+    if kind == "tridiagonal" and k < 2:
+        pytest.skip("needs an off-diagonal")
+    if not K.small_eigh_tri_ok(k, p, dtype):
+        pytest.skip("beyond the LDS capacity of the kernel for this (k, p)")
+    g = torch.Generator().manual_seed(k * 11 + p)
+    T = _tri_case(kind, B, k, g)
+    cap = k + 3
+    Tbuf = torch.full((B, cap, cap), 777.0, dtype=torch.float64)
+    Tbuf[:, :k, :k] = torch.tril(T) + torch.triu(torch.full((k, k), 99.0, dtype=torch.float64), 1)
+    Td = Tbuf.to(dev).to(dtype)
+    Tq = torch.tril(Td[:, :k, :k]).cpu().double()
+    Tq = Tq + torch.tril(Tq, -1).transpose(-2, -1)                            # the matrix the kernel really sees
+    lam_ref = torch.linalg.eigvalsh(Tq)
+    sl = slice(k - p, k) if uppest else slice(0, p)
+    lam, Y, info = K.small_eigh(Td, k, p, uppest=uppest, method="tri")
+    assert info.cpu().abs().max().item() == 0, info
+    lam, Y = lam.cpu().double(), Y.cpu().double()
+    tol = 1e-13 if dtype == torch.float64 else 5e-6
+    scale = max(lam_ref.abs().max().item(), 1.0)
+    assert (lam - lam_ref[:, sl]).abs().max().item() <= tol * scale * 20
+    assert torch.all(lam[:, 1:] >= lam[:, :-1])
+    Yc = Y.transpose(-2, -1)
+    res = torch.matmul(Tq, Yc) - Yc * lam.unsqueeze(-2)
+    assert res.abs().max().item() <= tol * scale * 200
+    G = torch.matmul(Yc.transpose(-2, -1), Yc)
+    assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() <= tol * 2000
+    # same invariant subspace as LAPACK's vectors (clusters / multiplicities: compare projectors)
+    _, Yr = torch.linalg.eigh(Tq)
+    Yr = Yr[..., sl]
+    gapped = True
+    if p < k:
+        edge = (lam_ref[:, p] - lam_ref[:, p - 1]) if not uppest else (lam_ref[:, k - p] - lam_ref[:, k - p - 1])
+        gapped = bool((edge > 1e-6 * scale).all())
+    if gapped:
+        P1, P2 = Yc @ Yc.transpose(-2, -1), Yr @ Yr.transpose(-2, -1)
+        assert (P1 - P2).abs().max().item() <= (1e-8 if dtype == torch.float64 else 1e-2)
+
+
+def test_small_eigh_tri_flags_garbage(dev):
+    """a matrix containing NaN cannot pass the kernel's self-check: the flag is what sends the call to the fallback"""
+    T = torch.eye(20, dtype=torch.float64).repeat(2, 1, 1)
+    T[1, 5, 3] = float("nan")                      # lower triangle: the part that is read
+    lam, Y, info = K.small_eigh(T.to(dev), 20, 3, method="tri")
+    assert info.cpu().tolist()[1] != 0 and info.cpu().tolist()[0] == 0

@@ -63,6 +63,11 @@ def _declare(L):
         sigs["xk_diag_precond_" + sfx] = (I, [P, P, P, P, I, I, I, Lg, Lg, Lg, Lg, Lg, D, P])
         sigs["xk_small_eigh_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, I, Lg, Lg, P])
     sigs["xk_small_eigh_workspace_elems"] = (Lg, [I, I, I])
+    sigs["xk_small_eigh_tri_lds_bytes"] = (Lg, [I, I, I])
+    sigs["xk_small_eigh_tri_set_threads"] = (I, [I])
+    sigs["xk_small_eigh_tri_set_profile"] = (I, [P])
+    for sfx in ("f64", "f32"):
+        sigs["xk_small_eigh_tri_" + sfx] = (I, [P, P, P, P, I, I, I, I, Lg, Lg, P])
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
     sigs["xk_dense_wide_workspace_elems"] = (Lg, [I, I, I, I, I])

@@ -166,9 +166,22 @@ SMALL_EIGH_MAX_K = 128
 SMALL_EIGH_MAX_P = 16
 
 
-def small_eigh(T, k, p, uppest=False, max_sweeps=16):
+SMALL_EIGH_TRI_MIN_K = 16        # below this order the Jacobi kernel's fixed costs are lower
+
+
+def small_eigh_tri_ok(k, p, dtype):
+    """does the tridiagonalisation kernel (K3t) serve order k with p wanted pairs?  (LDS-resident: <= 160 KiB)"""
+    if k > SMALL_EIGH_MAX_K or p > SMALL_EIGH_MAX_P or p > k:
+        return False
+    esize = 8 if dtype == torch.float64 else 4
+    return fn("xk_small_eigh_tri_lds_bytes")(k, p, esize) <= 160 * 1024
+
+
+def small_eigh(T, k, p, uppest=False, max_sweeps=16, method="jacobi"):
     """Lowest / uppermost `p` eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower
-    triangle is read).  Returns lam (B, p) ascending and Y (B, p, k) with Y[b, c] the c-th eigenvector.
+    triangle is read).  Returns lam (B, p) ascending, Y (B, p, k) with Y[b, c] the c-th eigenvector, and an int32
+    (B,) tensor: Jacobi sweeps (method "jacobi") or the failure flags of the self-check (method "tri": K3t,
+    Householder tridiagonalisation + bisection + inverse iteration; nonzero -> redo that call with "jacobi").
     Native replacement of `torch.linalg.eigh` + `_take_eigpairs` (symeig.py:174-175)."""
     require_device(T, "projected matrix")
     B = T.shape[0]
@@ -176,14 +189,19 @@ def small_eigh(T, k, p, uppest=False, max_sweeps=16):
         raise _capi.NativeLibraryError("T must have unit stride along its last dim")
     lam = torch.empty((B, p), dtype=T.dtype, device=T.device)
     Y = torch.empty((B, p, k), dtype=T.dtype, device=T.device)
-    sweeps = torch.empty((B,), dtype=torch.int32, device=T.device)
+    aux = torch.empty((B,), dtype=torch.int32, device=T.device)
+    if method == "tri":
+        rc = fn("xk_small_eigh_tri_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(aux), B, k, p, 1 if uppest else 0,
+                                                         T.stride(1), T.stride(0), stream_ptr())
+        check(rc, "xk_small_eigh_tri")
+        return lam, Y, aux
     nws = fn("xk_small_eigh_workspace_elems")(B, k, max_sweeps)
     ws = _workspace(nws, T.dtype, T.device)
-    rc = fn("xk_small_eigh_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(ws), nws, ptr(sweeps), B, k, p,
+    rc = fn("xk_small_eigh_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(ws), nws, ptr(aux), B, k, p,
                                                  1 if uppest else 0, max_sweeps, T.stride(1), T.stride(0),
                                                  stream_ptr())
     check(rc, "xk_small_eigh")
-    return lam, Y, sweeps
+    return lam, Y, aux
 
 
 # --------------------------------------------------------------------------- banded operator

@@ -101,7 +101,7 @@ class _Group:
         self.T = z(B, self.cap, self.cap)
         self.Wflat = torch.empty((B * 32 * 32,), dtype=dtype, device=device)
         self.info = torch.zeros((B,), dtype=torch.int32, device=device)
-        self.status = torch.zeros((2,), dtype=torch.float64, device=device)
+        self.status = torch.zeros((3,), dtype=torch.float64, device=device)   # max|resid|, chol flag, K3t self-check flag
         self.rmax = z(B)
         self.Xbuf = [z(B, p, Npad), z(B, p, Npad)]
         self.k = 0
@@ -190,13 +190,22 @@ class _Group:
         self.extend_T(0, k)
         self.k = k
 
-    def small(self):
-        """Rayleigh-Ritz on the current basis: K3 + fused rotation/residual; leaves {max|resid|, flag} in
-        self.status (device) and the next panel in the basis.  No host sync."""
+    def small(self, force_jacobi=False):
+        """Rayleigh-Ritz on the current basis: K3 + fused rotation/residual; leaves {max|resid|, Cholesky flag,
+        K3t self-check flag} in self.status (device) and the next panel in the basis.  No host sync.  Re-runnable:
+        the driver repeats it with force_jacobi=True when the tridiagonalisation kernel flagged its own result."""
         k, p, N = self.k, self.p, self.N
-        if self.small_eigh == "native" and k <= K.SMALL_EIGH_MAX_K and p <= K.SMALL_EIGH_MAX_P:
+        tri_flag = None
+        if self.small_eigh in ("native", "jacobi", "tri") and k <= K.SMALL_EIGH_MAX_K and p <= K.SMALL_EIGH_MAX_P:
             end = self._mark("k3")
-            lam, Yt, _ = K.small_eigh(self.T, k, p, uppest=(self.mode != "lowest"))      # K3: LDS Jacobi kernel
+            # K3t (tridiagonalisation + bisection + inverse iteration) from order 16 on: the O(k^3) work is done
+            # once instead of ~8 Jacobi sweeps; small orders and anything K3t cannot hold in LDS go to Jacobi
+            use_tri = (not force_jacobi) and self.small_eigh != "jacobi" and \
+                (k >= K.SMALL_EIGH_TRI_MIN_K or self.small_eigh == "tri") and K.small_eigh_tri_ok(k, p, self.dtype)
+            if use_tri:
+                lam, Yt, tri_flag = K.small_eigh(self.T, k, p, uppest=(self.mode != "lowest"), method="tri")
+            else:
+                lam, Yt, _ = K.small_eigh(self.T, k, p, uppest=(self.mode != "lowest"))  # K3: LDS Jacobi kernel
             end()
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
         else:
@@ -230,6 +239,7 @@ class _Group:
         self.lam = lam
         self.status[0] = self.rmax.max()
         self.status[1] = self.info.max()
+        self.status[2] = tri_flag.max() if tri_flag is not None else 0.0
         end_ritz()
 
     def expand(self):
@@ -315,8 +325,11 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         reference's CPU path bit for bit; ``"device"``: drawn on the operator's device, which is what
         the reference does for a GPU-resident operator
     small_eigh: str
-        (extension) ``"native"`` (default): the Rayleigh–Ritz matrix is diagonalised by the LDS Jacobi
-        kernel while the basis has <= 128 vectors; ``"library"``: always ``torch.linalg.eigh``
+        (extension) ``"native"`` (default): while the basis has <= 128 vectors the wanted eigenpairs of the
+        Rayleigh–Ritz matrix come from the LDS-resident kernels — Householder tridiagonalisation + bisection +
+        inverse iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's
+        self-check flags a result; ``"jacobi"`` / ``"tri"`` force one of them; ``"library"``: always
+        ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
         products of both groups run back to back on one stream whose CU mask leaves ``reserve_cus`` compute
@@ -445,7 +458,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     stop_reason = "max_niter"
     niter = 0
     distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
-    gstat = torch.zeros((2,), dtype=torch.float64, device=device) if distributed else None
+    gstat = torch.zeros((3,), dtype=torch.float64, device=device) if distributed else None
+    n_fallback = [0]
     for it in range(max_niter):
         niter = it + 1
         local_max, bad = 0.0, 0.0
@@ -453,7 +467,12 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         for g in range(G):
             with torch.cuda.stream(streams[g]):
                 groups[g].small()
-                st_g, bad_g = groups[g].status.tolist()               # host waits for THIS group's stream only
+                st_g, bad_g, tri_g = groups[g].status.tolist()        # host waits for THIS group's stream only
+                if tri_g != 0:
+                    # the tridiagonalisation kernel's self-check failed for some member: same step on Jacobi
+                    groups[g].small(force_jacobi=True)
+                    st_g, bad_g, tri_g = groups[g].status.tolist()
+                    n_fallback[0] += 1
             if st_g != st_g:
                 st_g = float("inf")
             local_max, bad = max(local_max, st_g), max(bad, bad_g)
@@ -472,7 +491,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                 # device, one all-reduce (MAX) over the ranks, one read
                 torch.amax(torch.stack([grp.status for grp in groups]), dim=0, out=gstat)
                 allreduce_max_(gstat, process_group)
-                max_resid, bad = gstat.tolist()
+                max_resid, bad, _ = gstat.tolist()
             if max_resid != max_resid:
                 max_resid = float("inf")
         if bad != 0:
@@ -512,7 +531,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         evals, Xall = groups[0].best_evals, groups[0].Xbuf[groups[0].best_slot]
     if trace is not None:
         trace.update(niter=niter, napply=sum(op.napply for op in ops) // G, resid_history=history,
-                     basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G)
+                     basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G,
+                     k3_fallbacks=n_fallback[0])
     evals = evals.reshape(*bdims, p)
     evecs = Xall[:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
     return evals, evecs
