@@ -46,6 +46,45 @@ __device__ __forceinline__ T wave_sum(T v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_t(v, m);
   return v;
 }
+// ---------------------------------------------------------------------------
+// Low-latency wave reduction on the DPP path (no LDS crossbar).
+//
+// `__shfl_xor` lowers to ds_bpermute_b32 (two per double), ~100+ cycles each through the LDS pipeline, so a
+// butterfly all-reduce of a double is a ~12-deep chain of them: fine in streaming kernels that have other waves
+// to run, but the whole critical path of latency-bound single-workgroup kernels (the small eigensolver makes two
+// reductions per Householder step).  Here: row_shr 1/2/4/8 inside each 16-lane row, row_bcast:15 / row_bcast:31
+// across the rows (gfx9 DPP controls), total read from lane 63 — six dependent VALU stages.
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_or_zero(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift_or_zero(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ double readlane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane63(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// sum over the 64 lanes, every lane gets the (bit-identical) total
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+  v += dpp_shift_or_zero<0x111, 0xf>(v);      // row_shr:1
+  v += dpp_shift_or_zero<0x112, 0xf>(v);      // row_shr:2
+  v += dpp_shift_or_zero<0x114, 0xf>(v);      // row_shr:4
+  v += dpp_shift_or_zero<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_shift_or_zero<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v += dpp_shift_or_zero<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return readlane63(v);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll

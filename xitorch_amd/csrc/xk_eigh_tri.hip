@@ -30,13 +30,36 @@ template <> struct EpsT<float> { static constexpr float eps = 1.1920929e-07f; st
 
 constexpr int TRI_MAXP = 16;
 
+// wave-uniform lane index -> v_readlane (scalar result, no LDS crossbar trip like a variable-index shuffle)
+__device__ __forceinline__ double readlane_t(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_t(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// reciprocal to ~1-2 ulp: hardware estimate + Newton steps (a full IEEE division costs ~4x as much on the
+// sequential critical paths of the Sturm count and of the triangular solves)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  r = fmaf(fmaf(-x, r, 1.0f), r, r);
+  return r;
+}
+
 template <typename T>
 __device__ __forceinline__ int sturm_count(const T* __restrict__ dd, const T* __restrict__ e2, int n, T sigma, T pivmin) {
   T q = dd[0] - sigma;
   if (fabs(q) < pivmin) q = -pivmin;
   int cnt = q < T(0) ? 1 : 0;
   for (int i = 1; i < n; ++i) {
-    q = dd[i] - sigma - e2[i - 1] / q;
+    q = dd[i] - sigma - e2[i - 1] * fast_rcp(q);
     if (fabs(q) < pivmin) q = -pivmin;
     cnt += q < T(0) ? 1 : 0;
   }
@@ -67,7 +90,8 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
   T* lu = Z + (long)p * n;                            // 5 x n x p: dl, d, du, du2, swap flag (index [a][i][j])
   const int b = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  const int lane = tid & 63, nw = nt >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (scalar row indices)
   const T* Tb = Tin + (long)b * sT;
   const T eps = EpsT<T>::eps;
 
@@ -92,8 +116,8 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
     const int c0 = j + 1 + lane, c1 = c0 + 64;        // this lane's rows == columns of the trailing block
     const T x0 = c0 < n ? S[c0 * ld + j] : T(0);
     const T x1 = c1 < n ? S[c1 * ld + j] : T(0);
-    const T sigma = wave_sum((lane > 0 ? x0 * x0 : T(0)) + x1 * x1);
-    const T alpha = __shfl(x0, 0, 64);
+    const T sigma = wave_sum_dpp((lane > 0 ? x0 * x0 : T(0)) + x1 * x1);
+    const T alpha = readlane_t(x0, 0);
     T tj = T(0), scale = T(0), beta = alpha;
     if (!(sigma == T(0))) {                           // (a NaN column must poison the result, not be skipped)
       const T nrm = sqrt(alpha * alpha + sigma);
@@ -108,8 +132,8 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
       int i = j + 1 + wave;
       for (; i + nw < n; i += 2 * nw) {               // two rows per trip: independent chains
         const int r0 = i - j - 1, r1 = r0 + nw;
-        const T vi0 = __shfl(r0 < 64 ? v0 : v1, r0 & 63, 64);
-        const T vi1 = __shfl(r1 < 64 ? v0 : v1, r1 & 63, 64);
+        const T vi0 = readlane_t(r0 < 64 ? v0 : v1, r0 & 63);
+        const T vi1 = readlane_t(r1 < 64 ? v0 : v1, r1 & 63);
         const T s00 = c0 < n ? S[i * ld + c0] : T(0), s01 = c1 < n ? S[i * ld + c1] : T(0);
         const T s10 = c0 < n ? S[(i + nw) * ld + c0] : T(0), s11 = c1 < n ? S[(i + nw) * ld + c1] : T(0);
         a0 += s00 * vi0; a1 += s01 * vi0;
@@ -117,7 +141,7 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
       }
       if (i < n) {
         const int r0 = i - j - 1;
-        const T vi0 = __shfl(r0 < 64 ? v0 : v1, r0 & 63, 64);
+        const T vi0 = readlane_t(r0 < 64 ? v0 : v1, r0 & 63);
         a0 += (c0 < n ? S[i * ld + c0] : T(0)) * vi0;
         a1 += (c1 < n ? S[i * ld + c1] : T(0)) * vi0;
       }
@@ -132,12 +156,12 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
         if (c1 < n) w1 += part[ww_ * n + c1];
       }
       w0 *= tj; w1 *= tj;
-      const T K = T(0.5) * tj * wave_sum(w0 * v0 + w1 * v1);
+      const T K = T(0.5) * tj * wave_sum_dpp(w0 * v0 + w1 * v1);
       const T q0 = w0 - K * v0, q1 = w1 - K * v1;
       for (int i = j + 1 + wave; i < n; i += nw) {
         const int r0 = i - j - 1;
-        const T vi = __shfl(r0 < 64 ? v0 : v1, r0 & 63, 64);
-        const T qi = __shfl(r0 < 64 ? q0 : q1, r0 & 63, 64);
+        const T vi = readlane_t(r0 < 64 ? v0 : v1, r0 & 63);
+        const T qi = readlane_t(r0 < 64 ? q0 : q1, r0 & 63);
         if (c0 < n) S[i * ld + c0] -= vi * q0 + qi * v0;
         if (c1 < n) S[i * ld + c1] -= vi * q1 + qi * v1;
       }
@@ -226,11 +250,11 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
       const T li = AT(dl, i);
       if (fabs(di) >= fabs(li)) {
         if (fabs(di) < pfloor) { di = di < T(0) ? -pfloor : pfloor; AT(dg, i) = di; }
-        const T fact = li / di;
+        const T fact = li * fast_rcp(di);
         AT(dl, i) = fact;
         AT(dg, i + 1) -= fact * AT(du, i);
       } else {
-        const T fact = di / li;
+        const T fact = di * fast_rcp(li);
         AT(dg, i) = li;
         AT(dl, i) = fact;
         const T tmp = AT(du, i);
@@ -249,6 +273,8 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
       T dl_ = AT(dg, n - 1);
       if (fabs(dl_) < pfloor) AT(dg, n - 1) = dl_ < T(0) ? -pfloor : pfloor;
     }
+    // the triangular solves multiply by the reciprocal pivots (one reciprocal here instead of three divisions later)
+    for (int i = 0; i < n; ++i) AT(dg, i) = fast_rcp(AT(dg, i));
     // start vector: deterministic pseudo-random in (-1, 1)
     T* z = Z + (long)j * n;
     for (int i = 0; i < n; ++i) {
@@ -275,15 +301,15 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
         else { z[i] = nxt; cur = cur - l * nxt; }
       }
       // back substitution
-      T zp1 = cur / AT(dg, n - 1), zp2 = T(0);
+      T zp1 = cur * AT(dg, n - 1), zp2 = T(0);
       z[n - 1] = zp1;
       if (n > 1) {
-        const T t = (z[n - 2] - AT(du, n - 2) * zp1) / AT(dg, n - 2);
+        const T t = (z[n - 2] - AT(du, n - 2) * zp1) * AT(dg, n - 2);
         z[n - 2] = t;
         zp2 = zp1; zp1 = t;
       }
       for (int i = n - 3; i >= 0; --i) {
-        const T t = (z[i] - AT(du, i) * zp1 - AT(du2, i) * zp2) / AT(dg, i);
+        const T t = (z[i] - AT(du, i) * zp1 - AT(du2, i) * zp2) * AT(dg, i);
         z[i] = t;
         zp2 = zp1; zp1 = t;
       }
@@ -305,12 +331,12 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
           const T* zq = Z + (long)q * n;
           T dp = T(0);
           for (int i = lane; i < n; i += 64) dp += zq[i] * zj[i];
-          dp = wave_sum(dp);
+          dp = wave_sum_dpp(dp);
           for (int i = lane; i < n; i += 64) zj[i] -= dp * zq[i];
         }
         T nn = T(0);
         for (int i = lane; i < n; i += 64) nn += zj[i] * zj[i];
-        nn = wave_sum(nn);
+        nn = wave_sum_dpp(nn);
         const T inv = nn > T(0) ? rsqrt(nn) : T(0);
         for (int i = lane; i < n; i += 64) zj[i] *= inv;
       }
@@ -341,7 +367,7 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
         const T* zq = Z + (long)(j - 1) * n;
         T dp = T(0);
         for (int i = lane; i < n; i += 64) dp += zq[i] * zj[i];
-        dp = fabs(wave_sum(dp));
+        dp = fabs(wave_sum_dpp(dp));
         if (!(dp < T(INFINITY))) nonfinite = 1;
         worst = fmax(worst, dp * tnorm);
       }
@@ -369,7 +395,7 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
       const T v0 = (lane >= n || lane <= r) ? T(0) : (lane == r + 1 ? T(1) : S[lane * ld + r]);
       const int i1 = lane + 64;
       const T v1 = (i1 >= n || i1 <= r) ? T(0) : (i1 == r + 1 ? T(1) : S[i1 * ld + r]);
-      const T dp = wave_sum(v0 * y0 + v1 * y1);
+      const T dp = wave_sum_dpp(v0 * y0 + v1 * y1);
       y0 -= tr * dp * v0;
       y1 -= tr * dp * v1;
     }
@@ -415,9 +441,10 @@ long xk_small_eigh_tri_lds_bytes(int k, int p, int elem_size) {
     hipError_t e = hipFuncSetAttribute((const void*)xk::tridiag_eigh_kernel<T>,                              \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
     if (e != hipSuccess) return (int)e;                                                                      \
-    /* threads: measured 64 / 128 / 256 / 512 / 1024 -> 3.90 / 2.13 / 1.29 / 0.86 / 0.79 ms at k = 108: the   */  \
-    /* LDS-latency chains of each step want many waves to hide behind                                        */  \
-    int nthr = xk_tri_threads > 0 ? xk_tri_threads : (k >= 64 ? 1024 : 512);                                 \
+    /* threads: 512 (8 waves) measured best at every order: 64 / 128 / 256 -> 2.9x / 1.7x / 1.2x slower (the    */  \
+    /* LDS-latency chains of a step want other waves to hide behind), 1024 -> 1.1x slower (barrier skew and the  */  \
+    /* reflector arithmetic that every wave repeats)                                                              */  \
+    int nthr = xk_tri_threads > 0 ? xk_tri_threads : 512;                                                    \
     hipLaunchKernelGGL((xk::tridiag_eigh_kernel<T>), dim3(B), dim3(nthr), (size_t)lds, (hipStream_t)stream,  \
                        Tin, lam, Y, info, k, p, uppest, ldt, sT, xk_tri_dbg);                                \
     XK_LAUNCH_CHECK();                                                                                       \
