@@ -322,3 +322,43 @@ def test_panel_orthogonalisation_vs_reference_tallqr(dev, withM):
     t3[..., 2] = 0.0
     with pytest.raises(RuntimeError):
         tallqr_extend(V.to(dev), t3.to(dev), M=Mop)
+
+
+@pytest.mark.parametrize("mode", ["lowest", "uppest"])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_thick_restart_bounded_basis(dev, mode, overlap):
+    """(extension, opt-in) restart=k_max: the basis never exceeds k_max vectors, the Rayleigh-Ritz matrix stays inside
+    the LDS-resident eigensolver, and the converged pairs are those of the unrestarted (= reference) iteration:
+    eigenvalues against the closed-form spectrum, residual below min_eps, orthonormal vectors."""
+    from xitorch_amd import synthetic
+    B, N, p = 4, 768, 4
+    mat = synthetic.dense_symmetric(B, N, "S2")                       # sqrt(i+1): slow, 50+ reference iterations
+    exact = synthetic.spectrum("S2", N)
+    exact = exact[:p] if mode == "lowest" else exact[-p:]
+    A = xa.LinearOperator.m(mat.to(dev), is_hermitian=True)
+    t0, t1 = {}, {}
+    ev0, _ = davidson(A, p, mode, min_eps=1e-8, trace=t0, overlap=False)
+    ev1, X1 = davidson(A, p, mode, min_eps=1e-8, restart=6 * p, trace=t1, overlap=overlap, max_niter=2000)
+    assert t1["stop_reason"] == "converged" and t1["restarts"] > 0 and t1["basis_size"] <= 6 * p
+    assert t0["restarts"] == 0 and t0["basis_size"] > 6 * p            # the default never restarts
+    assert (ev1.cpu() - exact).abs().max().item() < 1e-9 and (ev0.cpu() - exact).abs().max().item() < 1e-9
+    Xc = X1.cpu()
+    assert (torch.matmul(mat, Xc) - Xc * ev1.cpu().unsqueeze(-2)).abs().max().item() < 1e-8
+    G = torch.matmul(Xc.transpose(-2, -1), Xc)
+    assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < 1e-9
+    with pytest.raises(ValueError):
+        davidson(A, p, mode, restart=2 * p)
+
+
+def test_thick_restart_generalised_problem(dev):
+    case = [c for c in cases.DAVIDSON_CASES if c["name"] == "genM_120_b2_lowest3"][0]
+    mat, Mmat = cases.davidson_matrix(case), cases.davidson_M(case)
+    gold = np.load(os.path.join(GOLD, "davidson_%s.npz" % case["name"]))
+    A = xa.LinearOperator.m(mat.to(dev), True)
+    Mop = xa.LinearOperator.m(Mmat.to(dev), True)
+    tr = {}
+    ev, X = davidson(A, 3, "lowest", M=Mop, min_eps=1e-8, restart=15, trace=tr, max_niter=2000)
+    assert tr["restarts"] > 0 and tr["stop_reason"] == "converged"
+    assert np.abs(ev.cpu().numpy() - gold["evals_exact"]).max() < 1e-9
+    Xc = X.cpu()
+    assert (torch.matmul(mat, Xc) - torch.matmul(Mmat, Xc) * ev.cpu().unsqueeze(-2)).abs().max().item() < 1e-7

@@ -51,7 +51,13 @@ namespace xk {
 
 constexpr int SYMM_TRH = 1024;   // rows per tile
 
-constexpr int SYMM_NU = 2;      // 16 B vectors per lane per row: a wave spans 2 x 64 x VN columns
+#ifndef XK_SYMM_NU
+#define XK_SYMM_NU 2
+#endif
+#ifndef XK_SYMM_WPE
+#define XK_SYMM_WPE 2
+#endif
+constexpr int SYMM_NU = XK_SYMM_NU;      // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
 
 // The operator tile is read through a buffer descriptor (base = first row of the tile, wave-uniform):
 // every load is  descriptor + per-lane column offset (one VGPR, loop-invariant) + scalar row offset,
@@ -248,7 +254,7 @@ __device__ __forceinline__ void symm_tile_rows(
 }
 
 template <typename T, int P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE))) void dense_symm_tiles(
     const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int ntiles,
     int N, long lda, long sA, long ldx, long sX, int NS, int NT) {
   typedef typename Vec16<T>::type VT;

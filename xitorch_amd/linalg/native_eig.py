@@ -86,9 +86,15 @@ class _Group:
     """State of the Davidson iteration for one contiguous block of the batch, bound to one HIP stream."""
 
     def __init__(self, opA, opM, B, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
-                 precond=None):
+                 precond=None, restart=None):
         self.opA, self.opM = opA, opM
         self.precond = precond                    # None | ("diag", dA, dM) | ("op", PanelOperator)
+        # (extension) thick restart: None = never (the reference's ever-growing basis); an int = largest basis
+        # width; `keep` Ritz vectors survive a restart
+        self.restart = restart
+        self.keep = min(2 * p, K.SMALL_EIGH_MAX_P)
+        self._compress = None                     # (Yt (B, pk, k), lam_all (B, pk)) of a pending restart
+        self.nrestart = 0
         self.k1_stream = None                     # two-group pipeline: the (CU-masked) stream of the panel products
         self.timeline, self.tag = None, 0         # debugging: (tag, label, start event, end event) per phase
         self.B, self.N, self.Npad, self.p = B, N, Npad, p
@@ -196,20 +202,33 @@ class _Group:
         the driver repeats it with force_jacobi=True when the tridiagonalisation kernel flagged its own result."""
         k, p, N = self.k, self.p, self.N
         tri_flag = None
-        if self.small_eigh in ("native", "jacobi", "tri") and k <= K.SMALL_EIGH_MAX_K and p <= K.SMALL_EIGH_MAX_P:
+        # thick restart due after this Rayleigh-Ritz?  then the small eigensolver also returns the extra Ritz pairs
+        # that will survive (pk >= p of them; the wanted p are the first / last p of the ascending list)
+        due = self.restart is not None and k + p > self.restart and k > self.keep and k < N
+        pk = min(self.keep, k) if due else p
+        self._compress = None
+        if self.small_eigh in ("native", "jacobi", "tri") and k <= K.SMALL_EIGH_MAX_K and pk <= K.SMALL_EIGH_MAX_P:
             end = self._mark("k3")
             # K3t (tridiagonalisation + bisection + inverse iteration) from order 16 on: the O(k^3) work is done
             # once instead of ~8 Jacobi sweeps; small orders and anything K3t cannot hold in LDS go to Jacobi
             use_tri = (not force_jacobi) and self.small_eigh != "jacobi" and \
                 (k >= K.SMALL_EIGH_TRI_MIN_K or self.small_eigh == "tri") and K.small_eigh_tri_ok(k, p, self.dtype)
+            use_tri = use_tri and K.small_eigh_tri_ok(k, pk, self.dtype)
             if use_tri:
-                lam, Yt, tri_flag = K.small_eigh(self.T, k, p, uppest=(self.mode != "lowest"), method="tri")
+                lam, Yt, tri_flag = K.small_eigh(self.T, k, pk, uppest=(self.mode != "lowest"), method="tri")
             else:
-                lam, Yt, _ = K.small_eigh(self.T, k, p, uppest=(self.mode != "lowest"))  # K3: LDS Jacobi kernel
+                lam, Yt, _ = K.small_eigh(self.T, k, pk, uppest=(self.mode != "lowest"))  # K3: LDS Jacobi kernel
             end()
+            if due:
+                self._compress = (Yt, lam)
+                sl = slice(0, p) if self.mode == "lowest" else slice(pk - p, pk)
+                lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
         else:
             lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # large bases: library eigh
+            if due:
+                lk, Yk = take_eigpairs(lam_all, Y_all, pk, self.mode)
+                self._compress = (Yk.transpose(1, 2).contiguous(), lk.contiguous())
             lam, Y = take_eigpairs(lam_all, Y_all, p, self.mode)
             lam = lam.contiguous()
         end_ritz = self._mark("ritz")
@@ -218,7 +237,7 @@ class _Group:
         self.slot = 1 - self.best_slot if self.best_slot >= 0 else 0
         X = self.Xbuf[self.slot]
         self.rmax.zero_()
-        if self.nadd == p:
+        if self.nadd == p and not due:
             self.newpanel = self.Vs[:, k:k + p]                 # the next panel is produced in place
         else:
             self.newpanel = torch.empty((self.B, p, self.Npad), dtype=self.dtype, device=self.device)
@@ -242,10 +261,33 @@ class _Group:
         self.status[2] = tri_flag.max() if tri_flag is not None else 0.0
         end_ritz()
 
+    def compress(self):
+        """Thick restart (extension; off by default): replace the basis by the `pk` Ritz vectors V Y of the
+        Rayleigh-Ritz step just done — A V Y and M V Y come from the stored products, no operator apply — after
+        which T is the diagonal matrix of their Ritz values.  The span keeps the wanted approximations and the
+        nearest unwanted ones, which is what carries the convergence of the unrestarted iteration."""
+        Yt, lam_all = self._compress
+        self._compress = None
+        k, pk = self.k, Yt.shape[1]
+        for name in ("Vs", "AVs", "MVs"):
+            buf = getattr(self, name)
+            if buf is None:
+                continue
+            tmp = torch.zeros((self.B, pk, self.Npad), dtype=self.dtype, device=self.device)
+            K.lincomb(buf, Yt, tmp, k, pk, coef_layout="ca", alpha=1.0, beta=0.0)
+            buf[:, :pk].copy_(tmp)
+        self.T.zero_()
+        self.T[:, :pk, :pk] = torch.diag_embed(lam_all)
+        self.k = pk
+        self.nrestart += 1
+
     def expand(self):
         """Orthonormalise the residual panel against the basis, apply the operator to it, extend T."""
+        restarted = self._compress is not None
+        if restarted:
+            self.compress()
         k, nadd = self.k, self.nadd
-        if nadd != self.p:
+        if nadd != self.p or restarted:
             self.Vs[:, k:k + nadd].copy_(self.newpanel[:, :nadd])
         end = self._mark("orth")
         for _ in range(max(1, self.orth_passes)):
@@ -299,7 +341,8 @@ def _sub_operator(A, B, N, b0, b1):
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
-             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, **unused):
+             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
+             **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -345,6 +388,13 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         are the negated residuals, exactly like the reference.  ``"diag"``: Davidson's diagonal correction
         ``t = -r / (diag(A) - lam diag(M))`` with the operator's own diagonal (native dense / banded
         operators); a tensor ``(*batch, na)``: the same with that diagonal; a ``LinearOperator``: ``t = K (-r)``
+    restart: int or None
+        (extension) ``None`` (default): the basis grows until convergence, like the reference, which never restarts
+        (symeig.py:132-135).  An integer: thick restart — whenever the next expansion would exceed this many basis
+        vectors, the basis is replaced by the ``min(2*neig, 16)`` Ritz vectors nearest the wanted end (the wanted
+        ``neig`` among them) before the new residual block is appended.  Bounds the memory (2 x restart x N per
+        batch member) and keeps the Rayleigh–Ritz matrix inside the LDS-resident eigensolver on slowly converging
+        spectra; costs extra iterations.  Must be >= ``3 * neig``.
     V0: tensor or None
         (extension) start block ``(*batch, na, nguess)`` replacing the random draw
     orth_passes: int
@@ -368,6 +418,10 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         B *= d
     N, Npad = na, _pad(na, dtype)
     p = neig
+    if restart is not None:
+        restart = int(restart)
+        if restart < 3 * p or restart < nguess + p:
+            raise ValueError("restart must be at least 3 * neig (and nguess + neig), got %d" % restart)
     if nguess > 32:
         raise NativeLibraryError("nguess > 32 is not supported by the native panel Cholesky")
     if p > 32:
@@ -446,7 +500,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         with torch.cuda.stream(streams[g]):
             opM = _PanelOperator(M, bdims, B, N) if M is not None else None
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
-                         precond=_pc_slice(b0, b1))
+                         precond=_pc_slice(b0, b1), restart=restart)
             grp.k1_stream = k1_stream
             if trace is not None and "timeline" in trace:
                 grp.timeline, grp.tag = trace["timeline"], g
@@ -532,7 +586,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     if trace is not None:
         trace.update(niter=niter, napply=sum(op.napply for op in ops) // G, resid_history=history,
                      basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G,
-                     k3_fallbacks=n_fallback[0])
+                     k3_fallbacks=n_fallback[0], restarts=groups[0].nrestart)
     evals = evals.reshape(*bdims, p)
     evecs = Xall[:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
     return evals, evecs
