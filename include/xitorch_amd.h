@@ -100,6 +100,20 @@ int xk_dense_wide_f32(const float* A, const float* Xrm, float* Y, float* ws, lon
 int xk_dense_wide_f64(const double* A, const double* Xrm, double* Y, double* ws, long ws_elems, int B, int M,
                       int N, int P, long lda, long sA, long ldxr, long sXr, long ldy, long sY, void* stream);
 
+/* ---- K1wr: wide panels in the ROW orientation (no transposed copy, no MFMA) -----------------------
+ * Y[b,c,i] = sum_j A[b,i,j] X[b,c,j], any P (32 columns per pass over A): `torch.matmul(mat, x)` of a
+ * non-Hermitian MatrixLinearOperator with many right-hand sides (xitorch/_core/linop.py:695-696;
+ * benchmarks/benchmarks_solve.py:11-15; the BiCGStab / GMRES applies of a multi-RHS solve,
+ * _impls/linalg/solve.py:278,284).  Coalesced 64-row sub-tiles are turned through LDS so that every lane walks
+ * along its own row with wave-uniform (scalar) panel values: no cross-lane reduction.  X, Y panel-major;
+ * requires N, lda, ldx multiples of the 16 B vector width (else XK_ERR_UNSUPPORTED: use xk_dense_mm).
+ * ws: xk_dense_rows_wide_workspace_elems() elements (0 when the contraction is not split). */
+long xk_dense_rows_wide_workspace_elems(int B, int M, int N, int P, int elem_size);
+int xk_dense_rows_wide_f64(const double* A, const double* X, double* Y, double* ws, long ws_elems, int B, int M,
+                           int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+int xk_dense_rows_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int M, int N,
+                           int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+
 /* ---- basis maintenance of the block eigensolver (K2/K4/K5/K6) ------------------------------
  * Panels must be PADDED: pitch a multiple of 16 B and >= N rounded up to 16 B, pads zero.
  *

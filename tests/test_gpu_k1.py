@@ -256,3 +256,30 @@ def test_small_eigh_tri_flags_garbage(dev):
     T[1, 5, 3] = float("nan")                      # lower triangle: the part that is read
     lam, Y, info = K.small_eigh(T.to(dev), 20, 3, method="tri")
     assert info.cpu().tolist()[1] != 0 and info.cpu().tolist()[0] == 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-13), (torch.float32, 3e-6)])
+@pytest.mark.parametrize("B,M,N,P", [(2, 256, 512, 16), (3, 700, 700, 50), (1, 130, 1026, 12), (2, 64, 32, 32),
+                                     (8, 1024, 2048, 48), (2, 65, 8192, 17), (1, 2048, 96, 33), (4, 300, 4100, 13)])
+def test_dense_rows_wide_vs_torch(dev, dtype, tol, B, M, N, P):
+    """K1wr: A X in the row orientation for wide panels (LDS-transposed tiles, scalar panel loads), incl. ragged row
+    counts, column counts that are not a multiple of the 32/64-column sub-tile, split contractions and the
+    benchmarks_solve.py shape (n = 700, ncols = 50); also through dense_mm's dispatch and with a broadcast operator"""
+    g = torch.Generator().manual_seed(M + N + P)
+    A = torch.randn(B, M, N, dtype=torch.float64, generator=g)
+    X = torch.randn(B, P, N, dtype=torch.float64, generator=g)
+    ref = torch.matmul(X, A.transpose(-2, -1))                        # (B, P, M)
+    Ad, Xd = A.to(dev, dtype), X.to(dev, dtype)
+    vn = 2 if dtype == torch.float64 else 4
+    if N % vn:
+        pytest.skip("needs N multiple of the vector width")
+    Y = K.dense_rows_wide(Ad, Xd)
+    scale = float(N) ** 0.5 * 4
+    assert (Y.double().cpu() - ref).abs().max().item() <= tol * scale
+    Y2 = K.dense_mm(Ad, Xd, trans=False)                               # the dispatcher picks K1wr for P >= 12
+    assert torch.equal(Y2, Y)
+    Y3 = K.dense_rows_wide(Ad[:1], Xd)                                 # one operator for the whole panel batch
+    ref3 = torch.matmul(X, A[:1].transpose(-2, -1))
+    assert (Y3.double().cpu() - ref3).abs().max().item() <= tol * scale
+    # deterministic (fixed-order fold of the split contraction)
+    assert torch.equal(K.dense_rows_wide(Ad, Xd), Y)

@@ -72,6 +72,9 @@ def _declare(L):
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
     sigs["xk_dense_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
     sigs["xk_dense_wide_padded_width"] = (I, [I, I])
+    sigs["xk_dense_rows_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
+    for sfx in ("f64", "f32"):
+        sigs["xk_dense_rows_wide_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):
         sigs["xk_dense_wide_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):

@@ -63,6 +63,9 @@ def dense_mm(A, X, out=None, trans=False, rows_hint=0, stagger=1, wide=True):
     if out is None:
         out = torch.empty((B, P, nout), dtype=X.dtype, device=X.device)
     ldy, sY = _panel_strides(out)
+    if not trans and wide and P >= WIDE_MIN_P and _rows_wide_ok(A, X, N, lda, sA, ldx, sX):
+        # many columns in the ROW orientation: 64-row sub-tiles turned through LDS, 32 columns per pass (K1wr)
+        return dense_rows_wide(A, X, out=out)
     if trans and wide and P >= WIDE_MIN_P and _wide_ok(A, N, lda, sA):
         # many columns: one MFMA pass per 32 columns instead of one VALU pass per 8/16
         for c0 in range(0, P, 32):
@@ -491,6 +494,40 @@ def dense_symm_split(A, X, out, tiles_stream):
 
 # --------------------------------------------------------------------------- K1w wide panels (MFMA)
 WIDE_MIN_P = 12
+
+
+def _rows_wide_ok(A, X, N, lda, sA, ldx, sX):
+    vn = 2 if A.dtype == torch.float64 else 4
+    return N % vn == 0 and lda % vn == 0 and sA % vn == 0 and ldx % vn == 0 and sX % vn == 0 and \
+        A.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
+
+
+def dense_rows_wide(A, X, out=None):
+    """Y[b,c,:] = A_b X[b,c,:] (row orientation) for any number of panel columns, 32 per pass over A (K1wr: LDS
+    tile transpose, lane <-> row, scalar panel loads; no transposed copy of the operator).
+    A (B or 1, M, N); X panel-major (B, P, N); returns panel-major (B, P, M)."""
+    require_device(A, "operator matrix")
+    require_device(X, "panel")
+    B, P, N = X.shape
+    if A.dim() == 2:
+        M = A.shape[0]
+        lda, sA = A.stride(0), 0
+    else:
+        M = A.shape[1]
+        lda, sA = A.stride(1), (A.stride(0) if A.shape[0] != 1 else 0)
+    if A.shape[-1] != N:
+        raise _capi.NativeLibraryError("panel length %d != operator columns %d" % (N, A.shape[-1]))
+    ldx, sX = _panel_strides(X)
+    if out is None:
+        out = torch.empty((B, P, M), dtype=X.dtype, device=X.device)
+    ldy, sY = _panel_strides(out)
+    esize = 8 if X.dtype == torch.float64 else 4
+    nws = fn("xk_dense_rows_wide_workspace_elems")(B, M, N, P, esize)
+    ws = _workspace(nws, X.dtype, X.device) if nws > 0 else None
+    rc = fn("xk_dense_rows_wide_" + suffix(X.dtype))(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, M, N, P, lda, sA,
+                                                      ldx, sX, ldy, sY, stream_ptr())
+    check(rc, "xk_dense_rows_wide")
+    return out
 
 
 def _wide_ok(A, N, lda, sA):

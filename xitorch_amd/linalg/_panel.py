@@ -82,18 +82,6 @@ class PanelOperator:
         raise K._capi.NativeLibraryError("the diagonal of a generic LinearOperator is not available: pass it "
                                          "explicitly (precond=<tensor (*batch, N)>) or use a LinearOperator")
 
-    def _transposed(self):
-        """contiguous transpose of the dense operator, made once per PanelOperator (= per solver call); None when
-        the device cannot hold a second copy"""
-        if getattr(self, "_matT", None) is None and not getattr(self, "_matT_refused", False):
-            need = self.mat.numel() * self.mat.element_size()
-            free, _ = torch.cuda.mem_get_info(self.mat.device)
-            if free < need + (1 << 30):
-                self._matT_refused = True
-                return None
-            self._matT = self.mat.transpose(-2, -1).contiguous()
-        return getattr(self, "_matT", None)
-
     def apply(self, X, out, trans=False):
         """out[:, :, :N] = A X  (trans: A^H X).  X, out: (Bt, p, ld)."""
         self.napply += 1
@@ -154,15 +142,8 @@ class PanelOperator:
             # reference's mat @ x)
             if self.hermitian and not self.flip and self.herm_verified:
                 t = True
-            if not t and X.shape[1] >= K.WIDE_MIN_P:
-                # many columns in the ROW orientation (A X, non-Hermitian A): the VALU rows kernel would stream
-                # the operator once per 8 columns.  Keep a transposed copy for the lifetime of this solve (one
-                # pass over A, when the memory is there) and run the MFMA kernel K1w on it: one pass per 32
-                # columns.  (A dedicated row-orientation MFMA kernel is DESIGN.md section 7, item 4.)
-                matT = self._transposed()
-                if matT is not None:
-                    K.dense_mm(matT, X[:, :, :N], out=out[:, :, :N], trans=True)
-                    return out
+            # (many columns in the ROW orientation — A X, non-Hermitian A — go to K1wr inside dense_mm: one pass over
+            # the operator per 32 columns, no transposed copy)
             K.dense_mm(self.mat, X[:, :, :N], out=out[:, :, :N], trans=t)
         else:
             K.banded_mm(self.band, X[:, :, :N], out=out[:, :, :N], trans=trans)
