@@ -158,8 +158,8 @@ def test_preconditioned_cg_and_bicgstab(dev):
 
 
 def test_many_rhs_nonhermitian_goes_through_the_mfma_kernel(dev):
-    # 20 right-hand sides, general dense A: the panel product A X runs on K1w over a transposed copy made once
-    # per solve (the VALU rows kernel would need 3 passes over A per apply); results vs the dense solution
+    # 20 right-hand sides, general dense A: the panel product A X runs on K1wr (row orientation on the matrix cores,
+    # LDS tile turn) — one pass over A, and NO transposed copy of the operator; results vs the dense solution
     from xitorch_amd.linalg._panel import PanelOperator
     g = torch.Generator().manual_seed(13)
     B, n, nc = 2, 256, 20
@@ -169,8 +169,12 @@ def test_many_rhs_nonhermitian_goes_through_the_mfma_kernel(dev):
     op = PanelOperator(xa.LinearOperator.m(A, is_hermitian=False), [B], B, n)
     X = Bm.transpose(-2, -1).contiguous()                       # (B, nc, n) panel
     out = torch.empty_like(X)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
     op.apply(X, out)
-    assert getattr(op, "_matT", None) is not None               # the transposed copy exists -> K1w path
+    torch.cuda.synchronize()
+    assert getattr(op, "_matT", None) is None                   # no transposed copy any more
+    assert torch.cuda.memory_allocated() - before < A.numel() * A.element_size()   # nothing operator-sized appeared
     ref = torch.matmul(A, Bm).transpose(-2, -1)
     assert (out - ref).abs().max().item() <= 1e-12 * ref.abs().max().item() * n ** 0.5
     op.apply(X, out, trans=True)                                # A^T X: K1w directly
