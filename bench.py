@@ -179,7 +179,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group, backend, rccl_world = None, None, 1
-    if world > 1:
+    # XITORCH_BENCH_FORCE_PG=1: create the RCCL process group even for one rank (smoke test of the N > 1 plumbing —
+    # init, barrier, all-reduce of the timing — on a single-GPU box; the solver's own all-reduces need >= 2 ranks)
+    if world > 1 or os.environ.get("XITORCH_BENCH_FORCE_PG") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)         # "nccl" == RCCL on ROCm
@@ -195,7 +197,7 @@ def main():
     exact = synthetic.spectrum(args.spectrum, N, torch.float64, dev)[:p]
 
     def fence():
-        if world > 1:
+        if group is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +236,7 @@ def main():
             marks.append(time.perf_counter())     # host clock only (davidson returns after its last status read)
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if group is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             elapsed = tt.item()
@@ -334,7 +336,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         torch.distributed.destroy_process_group()
 
 
