@@ -263,6 +263,28 @@ def main():
     ok = eval_err <= tol * 100.0 and resid < args.min_eps
     roofline, durs = _k1_roofline(k1_events, N, p, esize, symm, b_local)
 
+    # ---------------- extra: the timed kernel alone on the GPU (no other batch group beside it) ----------------
+    # inside the two-group pipeline the panel product shares HBM with the other group's small kernels (that is the
+    # point of the pipeline); the same kernel on the whole batch with nothing else running shows what the sharing costs
+    if symm:
+        Xs = torch.randn((b_local, p, N), dtype=dtype, device=dev)
+        Ys = torch.empty_like(Xs)
+        XK.dense_symm(mat, Xs, out=Ys)
+        se = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            XK.dense_symm(mat, Xs, out=Ys)
+            e1.record()
+            se.append((e0, e1))
+        torch.cuda.synchronize()
+        s_avg = sum(a.elapsed_time(b) for a, b in se) / len(se) * 1e-3
+        sb = _panel_bytes(b_local, N, p, esize, True)
+        roofline["standalone_whole_batch_launch"] = {
+            "avg_launch_ms": s_avg * 1e3, "achieved": sb / s_avg / 1e9, "frac": sb / s_avg / 1e9 / 8000.0,
+            "bytes": sb, "note": "tile kernel + fold, %d operators, idle GPU, outside the timed region" % b_local}
+        del Xs, Ys
+
     # ---------------- extra: the full-matrix panel kernel on the same resident operator ----------------
     general = None
     if symm and not args.no_general_extra:

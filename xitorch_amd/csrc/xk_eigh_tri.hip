@@ -122,8 +122,8 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
     if (!(sigma == T(0))) {                           // (a NaN column must poison the result, not be skipped)
       const T nrm = sqrt(alpha * alpha + sigma);
       beta = alpha >= T(0) ? -nrm : nrm;
-      tj = (beta - alpha) / beta;
-      scale = T(1) / (alpha - beta);
+      tj = (beta - alpha) * fast_rcp(beta);           // (every wave repeats this: keep it off the divider)
+      scale = fast_rcp(alpha - beta);
     }
     const T v0 = lane == 0 ? T(1) : x0 * scale;       // v over rows j+1.. (v[j+1] = 1)
     const T v1 = x1 * scale;
@@ -158,7 +158,18 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
       w0 *= tj; w1 *= tj;
       const T K = T(0.5) * tj * wave_sum_dpp(w0 * v0 + w1 * v1);
       const T q0 = w0 - K * v0, q1 = w1 - K * v1;
-      for (int i = j + 1 + wave; i < n; i += nw) {
+      int i = j + 1 + wave;
+      for (; i + nw < n; i += 2 * nw) {               // two rows per trip: their LDS round trips overlap
+        const int r0 = i - j - 1, r1 = r0 + nw;
+        const T via = readlane_t(r0 < 64 ? v0 : v1, r0 & 63), qia = readlane_t(r0 < 64 ? q0 : q1, r0 & 63);
+        const T vib = readlane_t(r1 < 64 ? v0 : v1, r1 & 63), qib = readlane_t(r1 < 64 ? q0 : q1, r1 & 63);
+        T sa0 = T(0), sa1 = T(0), sb0 = T(0), sb1 = T(0);
+        if (c0 < n) { sa0 = S[i * ld + c0]; sb0 = S[(i + nw) * ld + c0]; }
+        if (c1 < n) { sa1 = S[i * ld + c1]; sb1 = S[(i + nw) * ld + c1]; }
+        if (c0 < n) { S[i * ld + c0] = sa0 - (via * q0 + qia * v0); S[(i + nw) * ld + c0] = sb0 - (vib * q0 + qib * v0); }
+        if (c1 < n) { S[i * ld + c1] = sa1 - (via * q1 + qia * v1); S[(i + nw) * ld + c1] = sb1 - (vib * q1 + qib * v1); }
+      }
+      if (i < n) {
         const int r0 = i - j - 1;
         const T vi = readlane_t(r0 < 64 ? v0 : v1, r0 & 63);
         const T qi = readlane_t(r0 < 64 ? q0 : q1, r0 & 63);
