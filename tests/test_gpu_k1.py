@@ -106,13 +106,28 @@ def test_small_eigh_vs_oracle(dev, B, k, p, uppest, dtype):
     assert int(sweeps.max()) < 16
 
 
+@pytest.fixture
+def symm_variant():
+    from xitorch_amd._capi import fn
+    prev = []
+
+    def select(v):
+        prev.append(fn("xk_dense_symm_set_variant")(v))
+    yield select
+    if prev:
+        fn("xk_dense_symm_set_variant")(prev[0])
+
+
 @pytest.mark.parametrize("B,N,P,dtype", [(2, 2048, 6, torch.float64), (3, 1536, 4, torch.float64),
                                          (2, 1000, 6, torch.float64), (1, 512, 1, torch.float64),
                                          (2, 130, 3, torch.float64), (1, 3072, 7, torch.float64),
                                          (2, 2, 2, torch.float64), (2, 4096, 6, torch.float32),
-                                         (1, 1100, 5, torch.float32)])
-def test_dense_symm_vs_oracle(dev, B, N, P, dtype):
-    # symmetric-storage K1s (upper triangle only) against the oracle's full dense product
+                                         (1, 1100, 5, torch.float32), (1, 5000, 6, torch.float64)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_dense_symm_vs_oracle(dev, B, N, P, dtype, variant, symm_variant):
+    # symmetric-storage K1s (upper triangle only) against the oracle's full dense product; variant 1 = per-lane rows +
+    # wave reductions (xk_symm.hip, the default), 2 = LDS turn + MFMA row part (xk_symm2.hip)
+    symm_variant(variant)
     g = torch.Generator().manual_seed(N + P)
     R = torch.randn(B, N, N, dtype=dtype, generator=g)
     A = R + R.transpose(-2, -1)                                   # exactly symmetric

@@ -39,13 +39,6 @@ __device__ __forceinline__ V ld_stream(const V* p) {
 __device__ __forceinline__ double shfl_xor_t(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_xor_t(float v, int mask) { return __shfl_xor(v, mask, 64); }
 
-// plain butterfly all-reduce (sum) over the 64 lanes of a wave
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_t(v, m);
-  return v;
-}
 // ---------------------------------------------------------------------------
 // Low-latency wave reduction on the DPP path (no LDS crossbar).
 //
@@ -64,6 +57,36 @@ __device__ __forceinline__ double dpp_shift_or_zero(double v) {
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_shift_or_zero(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+// Partner exchange for reduction stages over lane bits 3..0 on the DPP path (no LDS crossbar): the value of a lane
+// whose bit MASK differs from this lane's.  For MASK = 8, 2, 1 the partner is exactly lane ^ MASK (row_ror:8,
+// quad_perm); for MASK = 4 it is lane ^ 7 (row_half_mirror) — also a bijection between the bit-2 halves, which is
+// all a sum reduction needs as long as the stages over bits 1 and 0 follow (they always do here).
+template <int MASK> struct PartnerCtrl;
+template <> struct PartnerCtrl<8> { static constexpr int ctrl = 0x128; };     // row_ror:8
+template <> struct PartnerCtrl<4> { static constexpr int ctrl = 0x141; };     // row_half_mirror
+template <> struct PartnerCtrl<2> { static constexpr int ctrl = 0x4e; };      // quad_perm [2,3,0,1]
+template <> struct PartnerCtrl<1> { static constexpr int ctrl = 0xb1; };      // quad_perm [1,0,3,2]
+template <int MASK>
+__device__ __forceinline__ double lane_partner(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), PartnerCtrl<MASK>::ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), PartnerCtrl<MASK>::ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int MASK>
+__device__ __forceinline__ float lane_partner(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), PartnerCtrl<MASK>::ctrl, 0xf, 0xf, false));
+}
+// run-time stage mask -> the matching compile-time exchange (the callers' loops are fully unrolled)
+template <typename T>
+__device__ __forceinline__ T lane_partner_rt(T v, int mask) {
+  switch (mask) {
+    case 8: return lane_partner<8>(v);
+    case 4: return lane_partner<4>(v);
+    case 2: return lane_partner<2>(v);
+    case 1: return lane_partner<1>(v);
+    default: return shfl_xor_t(v, mask);
+  }
 }
 __device__ __forceinline__ double readlane63(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
@@ -140,6 +163,19 @@ __device__ __forceinline__ float swap_add16(float a, float b) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// butterfly all-reduce (sum) over the 64 lanes of a wave, every lane gets the bit-identical total; all stages on
+// the vector ALU (half-exchange swaps for lane bits 5 and 4, DPP partners below)
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+  v = swap_add32(v, v);
+  v = swap_add16(v, v);
+  v += lane_partner<8>(v);
+  v += lane_partner<4>(v);
+  v += lane_partner<2>(v);
+  v += lane_partner<1>(v);
+  return v;
+}
+
 template <typename T, int NV>
 __device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane) {
   constexpr int H0 = HalvingStages<NV>::value;
@@ -166,7 +202,7 @@ __device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane) {
       if (i < half) {
         T keep = hi ? v[2 * i + 1] : v[2 * i];
         T send = hi ? v[2 * i] : v[2 * i + 1];
-        v[i] = keep + shfl_xor_t(send, mask);
+        v[i] = keep + lane_partner_rt(send, mask);
       }
     }
     cnt = half;
@@ -176,7 +212,7 @@ __device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane) {
     const int mask = 32 >> s;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      if (i < (NV >> H)) v[i] += shfl_xor_t(v[i], mask);
+      if (i < (NV >> H)) v[i] += lane_partner_rt(v[i], mask);
     }
   }
 }

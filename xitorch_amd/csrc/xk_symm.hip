@@ -187,7 +187,7 @@ __device__ __forceinline__ void symm_chunk8(
     for (int c = 0; c < P; ++c) {
       const T keep = hi ? L2[1][c] : L2[0][c];
       const T send = hi ? L2[0][c] : L2[1][c];
-      L3[c] = keep + shfl_xor_t(send, 8);
+      L3[c] = keep + lane_partner<8>(send);
     }
   }
   const int r = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
@@ -201,12 +201,12 @@ __device__ __forceinline__ void symm_chunk8(
     for (int w = 0; w < P / 2; ++w) {
       const T keep = hi ? L3[2 * w + 1] : L3[2 * w];
       const T send = hi ? L3[2 * w] : L3[2 * w + 1];
-      L4[w] = keep + shfl_xor_t(send, 4);
+      L4[w] = keep + lane_partner<4>(send);
     }
 #pragma unroll
     for (int w = 0; w < P / 2; ++w) {
-      L4[w] += shfl_xor_t(L4[w], 2);
-      L4[w] += shfl_xor_t(L4[w], 1);
+      L4[w] += lane_partner<2>(L4[w]);
+      L4[w] += lane_partner<1>(L4[w]);
     }
     if ((lane & 3) == 0 && rowok) {
 #pragma unroll
@@ -217,9 +217,9 @@ __device__ __forceinline__ void symm_chunk8(
   } else {
 #pragma unroll
     for (int c = 0; c < P; ++c) {
-      L3[c] += shfl_xor_t(L3[c], 4);
-      L3[c] += shfl_xor_t(L3[c], 2);
-      L3[c] += shfl_xor_t(L3[c], 1);
+      L3[c] += lane_partner<4>(L3[c]);
+      L3[c] += lane_partner<2>(L3[c]);
+      L3[c] += lane_partner<1>(L3[c]);
     }
     if ((lane & 7) == 0 && rowok) {
 #pragma unroll
@@ -236,17 +236,24 @@ __device__ __forceinline__ void symm_tile_rows(
     typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
     T* rowacc, int lane) {
   typedef typename Vec16<T>::type VT;
-  if (i_begin >= i_end) return;
+  const bool any = i_begin < i_end;          // (wave-uniform) a wave right of a crossing tile's diagonal has no rows
   const int full_end = i_begin + ((i_end - i_begin) / SYMM_R) * SYMM_R;
   const int i_last = i_end - 1;
   VT a[SYMM_R][SYMM_NU];                     // ring of 8 rows, refilled pair by pair inside the chunks
+  if (any) {
 #pragma unroll
-  for (int r = 0; r < SYMM_R; ++r) {
-    int row = i_begin + r;
-    row = row < i_last ? row : i_last;
+    for (int r = 0; r < SYMM_R; ++r) {
+      int row = i_begin + r;
+      row = row < i_last ? row : i_last;
 #pragma unroll
-    for (int u = 0; u < SYMM_NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
+      for (int u = 0; u < SYMM_NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
+    }
   }
+  // the block's LDS set-up runs UNDER the first 16 KB of loads (they do not depend on it): every wave passes
+  // here exactly once, whichever of the two instantiations it took
+  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
+  __syncthreads();
+  if (!any) return;
   for (int i0 = i_begin; i0 < full_end; i0 += SYMM_R)
     symm_chunk8<T, P, CROSSING, false>(a, Ab, Xb, lda, ldx, N, i0, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
   if (full_end < i_end)
@@ -298,9 +305,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE
   }
   const T* Ab = A + (long)b * sA;
   const T* Xb = X + (long)b * sX;
-  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
-  __syncthreads();
-
   // rows of this tile that can hold an element on/above the diagonal: i <= last column of the slab
   int i_end = row0 + SYMM_TRH;
   const int col_last = col0 + SLAB - 1;
@@ -369,17 +373,35 @@ __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, con
   Y[b * sY + (long)c * ldy + n] = s;
 }
 
+// K1s2 (xk_symm2.hip): the same contract with the row part on the matrix cores
+template <typename T>
+int symm2_launch(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P, long lda, long sA,
+                 long ldx, long sX, long ldy, long sY, void* stream, int phase);
+long symm2_workspace_elems(int B, int N, int P, int elem_size);
+
+static int g_symm_variant = 1;     // 1: per-lane rows + wave reductions (this file), 2: LDS turn + MFMA row part
+
 }  // namespace xk
 
 extern "C" {
 
-// workspace (elements): row partials (B, NS, P, N) + column partials (B, NT, P, N)
+// which implementation serves xk_dense_symm_* (both read only the upper triangle and share the workspace
+// contract); returns the previous setting.  Kept for A/B measurements (bench.py --k1s-variant).
+int xk_dense_symm_set_variant(int v) {
+  const int old = xk::g_symm_variant;
+  if (v == 1 || v == 2) xk::g_symm_variant = v;
+  return old;
+}
+
+// workspace (elements): row partials (B, NS, P, N) + column partials (B, NT, P, N), the larger of the variants
 long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
   const int vn = 16 / elem_size;
   const long slab = 256L * vn * xk::SYMM_NU;
   const long NS = (N + slab - 1) / slab, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;
   const long pc = P > 6 ? 6 : P;
-  return (long)B * (NS + NT) * pc * N;
+  const long v1 = (long)B * (NS + NT) * pc * N;
+  const long v2 = xk::symm2_workspace_elems(B, N, P, elem_size);
+  return v1 > v2 ? v1 : v2;
 }
 
 #define XK_DEFINE_SYMM(SUF, T)                                                                              \
@@ -389,6 +411,8 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
     if (B < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                                         \
     if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
     if (phase != 0 && P > 6) return XK_ERR_UNSUPPORTED;   /* split phases: one column chunk only */         \
+    if (xk::g_symm_variant == 2)                                                                            \
+      return xk::symm2_launch<T>(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, stream, phase); \
     constexpr int VN = xk::Vec16<T>::n;                                                                     \
     constexpr int SLAB = 256 * VN * xk::SYMM_NU;                                                            \
     if ((N % VN) || (lda % VN) || (sA % VN) || (ldx % VN) || (sX % VN) || ((uintptr_t)A & 15) ||             \
