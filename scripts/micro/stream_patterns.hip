@@ -82,13 +82,16 @@ __global__ __launch_bounds__(64 * W) void stream(const double* __restrict__ A, d
     const int lrow = lane >> 3, lcol = lane & 7;
     unsigned rowpart[8];
     for (int k = 0; k < 8; ++k) rowpart[k] = (unsigned)(k * 8 + lrow) * ldab + lcol * 16;
+    if (MODE == 3)   // MFMA A-operand layout straight from memory: lane -> row (lane & 15) of a 16-row block, 16 B chunk
+      for (int k = 0; k < 8; ++k)   // (lane >> 4) + 4 * (k & 1): an instruction covers 16 rows x 64 B, a pair the full 128 B lines
+        rowpart[k] = (unsigned)((k >> 1) * 16 + (lane & 15)) * ldab + (unsigned)((lane >> 4) + 4 * (k & 1)) * 16;
     const int nstrip = TCB / 128, nsub = TR / 64;
     const int per_wave = nstrip / W;
     const int steps = per_wave * nsub;
     d2 buf[DEPTH][8];
     auto stepoff = [&](int n) -> unsigned {
       int k, sub;
-      if (MODE == 1) { k = n / nsub; sub = n - k * nsub; return (unsigned)(wave + k * W) * 128u + (unsigned)sub * 64u * ldab; }
+      if (MODE == 1 || MODE == 3) { k = n / nsub; sub = n - k * nsub; return (unsigned)(wave + k * W) * 128u + (unsigned)sub * 64u * ldab; }
       // MODE 2: rows fixed per (wave, sub-block), walk along the row
       sub = n / per_wave; k = n - sub * per_wave;
       return (unsigned)(wave * per_wave + k) * 128u + (unsigned)sub * 64u * ldab;
@@ -170,6 +173,11 @@ int main(int argc, char** argv) {
   if (argc > 3 && argv[3][0] == 's') {   // what the symmetric kernels add to the bare stream, one ingredient at a time
     const int L = 120 * 1024;
     run<1, 8, 2, 0>("colsweep 8 waves, 1 block/CU", A, out, B, N, 512, 8192, L);
+    run<3, 8, 2, 0>("colsweep, loads in the MFMA operand layout (16 rows x 64 B per instruction), 8 waves 1 block/CU", A, out, B, N, 512, 8192, L);
+    run<3, 4, 2, 0>("same, 4 waves x 2 blocks/CU", A, out, B, N, 512, 8192, 80 * 1024);
+    run<3, 4, 2, 3>("same, 4 waves x 2 blocks/CU + triangle + prologue/epilogue", A, out, B, N, 512, 8192, 80 * 1024);
+    run<3, 4, 2, 3>("same, 4 waves x 3 blocks/CU + triangle + prologue/epilogue", A, out, B, N, 512, 8192, 53 * 1024);
+    run<3, 4, 2, 3>("same, 4 waves x 3 blocks/CU, 1024-row tiles", A, out, B, N, 1024, 8192, 53 * 1024);
     run<1, 8, 2, 1>("+ triangle tile list", A, out, B, N, 512, 8192, L);
     run<1, 8, 2, 3>("+ triangle + prologue/epilogue", A, out, B, N, 512, 8192, L);
     run<1, 8, 2, 7>("+ triangle + prologue/epilogue + LDS park", A, out, B, N, 512, 8192, L);
