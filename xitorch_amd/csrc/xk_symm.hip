@@ -57,6 +57,9 @@ constexpr int SYMM_TRH = 1024;   // rows per tile
 #ifndef XK_SYMM_WPE
 #define XK_SYMM_WPE 2
 #endif
+#ifndef XK_SYMM_EARLY
+#define XK_SYMM_EARLY 1
+#endif
 constexpr int SYMM_NU = XK_SYMM_NU;      // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
 
 // The operator tile is read through a buffer descriptor (base = first row of the tile, wave-uniform):
@@ -240,19 +243,22 @@ __device__ __forceinline__ void symm_tile_rows(
   const int full_end = i_begin + ((i_end - i_begin) / SYMM_R) * SYMM_R;
   const int i_last = i_end - 1;
   VT a[SYMM_R][SYMM_NU];                     // ring of 8 rows, refilled pair by pair inside the chunks
-  if (any) {
+  // (unconditional: a branch around the fill would leave the compiler without the order of the outstanding loads at
+  // the loop head and turn every wait of the ring into vmcnt(0); a wave without rows re-reads the tile's first row)
 #pragma unroll
-    for (int r = 0; r < SYMM_R; ++r) {
-      int row = i_begin + r;
-      row = row < i_last ? row : i_last;
+  for (int r = 0; r < SYMM_R; ++r) {
+    int row = i_begin + r;
+    row = row < i_last ? row : i_last;
+    row = row > row_tile0 ? row : row_tile0;
 #pragma unroll
-      for (int u = 0; u < SYMM_NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
-    }
+    for (int u = 0; u < SYMM_NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
   }
   // the block's LDS set-up runs UNDER the first 16 KB of loads (they do not depend on it): every wave passes
   // here exactly once, whichever of the two instantiations it took
+#if XK_SYMM_EARLY
   for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
   __syncthreads();
+#endif
   if (!any) return;
   for (int i0 = i_begin; i0 < full_end; i0 += SYMM_R)
     symm_chunk8<T, P, CROSSING, false>(a, Ab, Xb, lda, ldx, N, i0, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
@@ -305,6 +311,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE
   }
   const T* Ab = A + (long)b * sA;
   const T* Xb = X + (long)b * sX;
+#if !XK_SYMM_EARLY      /* A/B only: LDS set-up and barrier before the first load is issued */
+  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
+  __syncthreads();
+#endif
   // rows of this tile that can hold an element on/above the diagonal: i <= last column of the slab
   int i_end = row0 + SYMM_TRH;
   const int col_last = col0 + SLAB - 1;

@@ -26,12 +26,20 @@
 // boundaries.  The SEG x SEG diagonal blocks (0.2 % of the data) are done afterwards, one synchronous masked step
 // per diagonal strip.  Partials and the fold are as in xk_symm.hip (rowP[J][c][i], colP[I][c][j]).
 //
-// Status (r02, fp64, P = 6, 32 x 16384^2, same box): 6.2-6.4 ms alone vs 5.8-6.0 ms for xk_symm.hip, 7.5-7.7 vs 6.05-6.1 ms
-// inside the eigensolver's two-group pipeline — NOT the default (xk_dense_symm_set_variant(2) / XITORCH_AMD_K1S_VARIANT=2
-// selects it).  What the experiments behind it established (scripts/micro/stream_patterns.hip, scripts/symm_pmc.sh,
-// DESIGN.md 7.1): every walk of the tile streams at 6.9-7.1 TB/s when nothing is computed; the LDS turn costs
-// nothing; the per-block set-up/flush costs 4-6 %; the rest of the gap is arithmetic that two waves per SIMD do not
-// hide although no unit is more than 40 % busy (VALU work is 40 % below xk_symm.hip's, LDS 37 % busy, MFMA ~30 %).
+// Status (r02, fp64, P = 6, 32 x 16384^2, same box): 6.2 ms alone vs 6.0 ms for xk_symm.hip (5.5 vs 5.7 TB/s), 7.2 vs
+// 6.15 ms on the 192 CUs the eigensolver's two-group pipeline gives the panel product — NOT the default
+// (xk_dense_symm_set_variant(2) / XITORCH_AMD_K1S_VARIANT=2 selects it; tests run both).  What the experiments behind
+// it established (scripts/micro/stream_patterns.hip, scripts/symm_pmc.sh):
+//   * every walk of the tile (rows of 1-2 KB, 64 x 128 B sub-tiles down or along the rows) streams at 6.9-7.1 TB/s
+//     with 8 waves x 16 KB in flight per CU when nothing is computed; the LDS turn costs nothing; loading straight
+//     in the MFMA operand layout (16 rows x 64 B per instruction) costs 16 % (5.8 TB/s);
+//   * a vector-memory instruction under a branch inside the streaming loop makes the compiler wait with vmcnt(0)
+//     on every step (a full drain of the prefetch): the loop below issues exactly 8 loads per step, poisoned
+//     offsets instead of branches — this alone was worth 7 %;
+//   * the kernel is bound per CU, not by HBM: v_mfma_f64_16x16x4_f64 occupies the matrix pipe for ~120 cycles
+//     (K1wr's plateau at 32 of them per 8 KB says the same), so the 16 per sub-tile — of whose 16 output columns
+//     only P = 6 are used — cost 5x the 96 vector FMAs they replace: MFMA ~60 % busy at 5.5 TB/s with two
+//     dependent chains and two waves per SIMD.  The matrix cores only pay from P >= 12 (K1w / K1wr).
 #include "xk_common.h"
 
 namespace xk {
@@ -215,17 +223,22 @@ __device__ __forceinline__ void s2_issue(typename Vec16<T>::type (&an)[8], const
                                          unsigned ldab, int lrow) {
   typedef typename Vec16<T>::type VT;
   const unsigned cb = colpart + (unsigned)(sub * S2_ROWS) * ldab;
-  if ((sub + 1) * S2_ROWS <= main_rows) {
+  const int left = main_rows - sub * S2_ROWS;          // rows of this sub-tile above the diagonal block (scalar)
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-      an[t] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(rowpart[t] + cb), 0, 2));
-  } else {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const unsigned off = (sub * S2_ROWS + t * 8 + lrow) < main_rows ? rowpart[t] + cb : S2_POISON;
-      an[t] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 2));
-    }
+  for (int t = 0; t < 8; ++t) {
+    const unsigned off = (lrow < left - t * 8) ? rowpart[t] + cb : S2_POISON;
+    an[t] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 2));
   }
+}
+
+// one element through a buffer descriptor (an out-of-range offset reads as zero)
+template <typename T> __device__ __forceinline__ T s2_ld_elem(const S2Rsrc r, unsigned off);
+template <> __device__ __forceinline__ double s2_ld_elem<double>(const S2Rsrc r, unsigned off) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+template <> __device__ __forceinline__ float s2_ld_elem<float>(const S2Rsrc r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
 
 template <typename T, int P>
@@ -286,36 +299,58 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
   for (int t = 0; t < NLD; ++t) rowpart[t] = (unsigned)(t * 8 + lrow) * ldab;
 
-  // ---- main sweep: flattened sequence of (strip, sub-tile) steps, loads two steps ahead of the compute -----------
-  S2Strip pr, co;                       // producer (loads) and consumer (compute) positions
+  // ---- main sweep ----------------------------------------------------------------------------------------------
+  // The loads run two sub-tile steps ahead of the compute, across strip boundaries.  The steady loop must not
+  // contain a vector-memory instruction under a branch: the compiler's s_waitcnt insertion falls back to vmcnt(0)
+  // — a full drain of the prefetch on every step — as soon as the order of the outstanding loads differs between
+  // paths.  Hence: every step issues exactly its 8 loads (offsets poisoned when there is nothing to fetch), every
+  // strip runs an EVEN number of steps (an odd one gets a step of zeros), the panel values of the next strip are
+  // requested at the start of the current one, and the stores of a strip's column sums sit between the loops.
+  S2Strip pr, co, nx;                   // producer (loads), consumer (compute), the consumer's next strip
   pr.s = wave - S2_WAVES;
   bool pvalid = s2_next_strip<T>(pr, col0, row0, tile_rows, N);
   co = pr;
   bool cvalid = pvalid;
-  unsigned pcol = 0;
-  int bjn_strip = -1;                   // strip whose panel values sit in bJn (a 1-step strip can be overtaken)
+  unsigned pcol = S2_POISON;
+  int prows = 0, pnst = 0;              // rows above the diagonal block / steps (even) of the producer's strip
   VT an0[NLD], an1[NLD];
   T bJ[NT4], bJn[NT4], acc_col[NT4][P];
-  // entering a strip on the producer side: column offset of its loads, and the panel values at the lane's columns
-  // (the row part's MFMA B operand) — requested two steps before the consumer needs them
-#define XK_S2_PCOL()                                                                                      \
+  S2Rsrc rx;                            // the panel through a descriptor: absent values are poisoned offsets, not branches
+  {
+    const uint64_t v = reinterpret_cast<uint64_t>(Xb);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    void* base = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    const long bytes = ((long)(P - 1) * ldx + N) * (long)sizeof(T);
+    const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0x7fffffe0L ? 0x7fffffe0L : bytes));
+    rx = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)nrec, 0x00020000);
+  }
+  const unsigned xrow = mi < P ? (unsigned)mi * (unsigned)(ldx * (long)sizeof(T)) : S2_POISON;
+  // panel values X[mi][j0 + lane's columns] of strip j0 (valid == false: zeros)
+#define XK_S2_LOAD_BJ(DST, J0, VALID)                                                                       \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int e = 0; e < VN; ++e) {            \
+    const int col = (J0) + (q + 4 * h) * VN + e;                                                            \
+    const unsigned off = ((VALID) && mi < P && col < N) ? xrow + (unsigned)col * (unsigned)sizeof(T)        \
+                                                        : S2_POISON;                                        \
+    DST[h * VN + e] = s2_ld_elem<T>(rx, off);                                                               \
+  }
+#define XK_S2_PENTER()                                                                                    \
   {                                                                                                       \
-    pcol = (pr.j0 + lcol * VN) < N ? (unsigned)(pr.j0 + lcol * VN) * (unsigned)sizeof(T) : S2_POISON;     \
-    bjn_strip = pr.s;                                                                                     \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int e = 0; e < VN; ++e) {        \
-      const int col = pr.j0 + (q + 4 * h) * VN + e;                                                       \
-      bJn[h * VN + e] = (mi < P && col < N) ? Xb[(long)mi * ldx + col] : T(0);                            \
-    }                                                                                                     \
+    pcol = (pvalid && (pr.j0 + lcol * VN) < N) ? (unsigned)(pr.j0 + lcol * VN) * (unsigned)sizeof(T)      \
+                                               : S2_POISON;                                               \
+    prows = pvalid ? pr.main_rows : 0;                                                                    \
+    pnst = pvalid ? ((pr.nsub + 1) & ~1) : 0x40000000;                                                    \
   }
 #define XK_S2_PRODUCE(BUF)                                                                \
-  if (pvalid) {                                                                           \
-    s2_issue<T>(BUF, rs, rowpart, pcol, pr.sub, pr.main_rows, ldab, lrow);                \
-    if (++pr.sub == pr.nsub) {                                                            \
+  {                                                                                       \
+    s2_issue<T>(BUF, rs, rowpart, pcol, pr.sub, prows, ldab, lrow);                       \
+    if (++pr.sub == pnst) {                                                               \
       pvalid = s2_next_strip<T>(pr, col0, row0, tile_rows, N);                            \
-      if (pvalid) XK_S2_PCOL()                                                            \
+      XK_S2_PENTER()                                                                      \
     }                                                                                     \
   }
-  if (pvalid) XK_S2_PCOL()
+  XK_S2_LOAD_BJ(bJn, co.j0, cvalid)
+  XK_S2_PENTER()
   XK_S2_PRODUCE(an0)
   XK_S2_PRODUCE(an1)
   // the block's LDS set-up runs UNDER the first 16 KB of loads per wave (they do not depend on it): zero row
@@ -327,20 +362,8 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     *reinterpret_cast<T*>(xI + (unsigned)r * XP + (unsigned)c * sizeof(T)) = v;
   }
   __syncthreads();
-#define XK_S2_STEP(BUF)                                                                                        \
+#define XK_S2_STEP(BUF, SUB)                                                                                   \
   {                                                                                                            \
-    if (co.sub == 0) { /* strip start: take the prefetched panel values (or fetch them: see below), zero sums */ \
-      if (bjn_strip == co.s) {                                                                                 \
-        _Pragma("unroll") for (int t = 0; t < NT4; ++t) bJ[t] = bJn[t];                                        \
-      } else {                                                                                                 \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int e = 0; e < VN; ++e) {         \
-          const int col = co.j0 + (q + 4 * h) * VN + e;                                                        \
-          bJ[h * VN + e] = (mi < P && col < N) ? Xb[(long)mi * ldx + col] : T(0);                              \
-        }                                                                                                      \
-      }                                                                                                        \
-      _Pragma("unroll") for (int t = 0; t < NT4; ++t) _Pragma("unroll") for (int c = 0; c < P; ++c)            \
-          acc_col[t][c] = T(0);                                                                                \
-    }                                                                                                          \
     /* the previous sub-tile's LDS reads are consumed (MFMA / FMA operands) before these writes are issued */  \
     _Pragma("unroll") for (int t = 0; t < NLD; ++t)                                                            \
         *reinterpret_cast<VT*>(tile + st_off + (unsigned)(t * 8) * S2_PITCH) = BUF[t];                         \
@@ -348,30 +371,45 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                     \
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the tile is in LDS (same wave: program order) */        \
     {                                                                                                          \
-      const int lr0 = co.sub * S2_ROWS;                                                                        \
+      int lr0 = (SUB) * S2_ROWS; /* (the step of zeros of an odd strip lands on the tile's last rows) */       \
+      lr0 = lr0 < S2_TRH - S2_ROWS ? lr0 : S2_TRH - S2_ROWS;                                                   \
       s2_group<T, P, 2, false>(tile, xI, rowacc, 0, lr0, row0 + lr0, co.j0, bJ, acc_col, lane);                \
       s2_group<T, P, 2, false>(tile, xI, rowacc, 2, lr0, row0 + lr0, co.j0, bJ, acc_col, lane);                \
     }                                                                                                          \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                     \
-    if (++co.sub == co.nsub) { /* strip end: column sums over the 16 row-lanes, lane mi == c stores column c */ \
-      _Pragma("unroll") for (int t = 0; t < NT4; ++t) {                                                        \
-        const int col = co.j0 + (q + 4 * (t / VN)) * VN + (t % VN);                                            \
-        _Pragma("unroll") for (int c = 0; c < P; ++c) {                                                        \
-          const T sum = s2_row16_sum(acc_col[t][c]);                                                           \
-          if (mi == c && col < N) cp[(long)c * N + col] = sum;                                                 \
-        }                                                                                                      \
-      }                                                                                                        \
-      cvalid = s2_next_strip<T>(co, col0, row0, tile_rows, N);                                                 \
-    }                                                                                                          \
   }
   while (cvalid) {
-    XK_S2_STEP(an0)
-    if (!cvalid) break;
-    XK_S2_STEP(an1)
+    // strip start: the prefetched panel values become the MFMA B operand, those of the next strip are requested
+#pragma unroll
+    for (int t = 0; t < NT4; ++t) bJ[t] = bJn[t];
+    nx = co;
+    const bool nvalid = s2_next_strip<T>(nx, col0, row0, tile_rows, N);
+    XK_S2_LOAD_BJ(bJn, nx.j0, nvalid)
+#pragma unroll
+    for (int t = 0; t < NT4; ++t)
+#pragma unroll
+      for (int c = 0; c < P; ++c) acc_col[t][c] = T(0);
+    const int nst = (co.nsub + 1) & ~1;
+    for (int sub = 0; sub < nst; sub += 2) {
+      XK_S2_STEP(an0, sub)
+      XK_S2_STEP(an1, sub + 1)
+    }
+    // strip end: column sums over the 16 row-lanes, lane mi == c stores panel column c
+#pragma unroll
+    for (int t = 0; t < NT4; ++t) {
+      const int col = co.j0 + (q + 4 * (t / VN)) * VN + (t % VN);
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const T sum = s2_row16_sum(acc_col[t][c]);
+        if (mi == c && col < N) cp[(long)c * N + col] = sum;
+      }
+    }
+    co = nx;
+    cvalid = nvalid;
   }
 #undef XK_S2_STEP
 #undef XK_S2_PRODUCE
-#undef XK_S2_PCOL
+#undef XK_S2_PENTER
 
   // ---- diagonal blocks of this wave's strips (rows j0 .. j0+SEG-1): one synchronous masked step each ---------------
   for (int s = wave; s < NSTRIP; s += S2_WAVES) {
@@ -386,13 +424,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     for (int t = 0; t < SEG / 8; ++t)
       ad[t] = __builtin_bit_cast(
           VT, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(colok ? rowpart[t] + dcol : S2_POISON), 0, 2));
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int e = 0; e < VN; ++e) {
-        const int col = j0 + (q + 4 * h) * VN + e;
-        bJ[h * VN + e] = (mi < P && col < N) ? Xb[(long)mi * ldx + col] : T(0);
-      }
+    XK_S2_LOAD_BJ(bJ, j0, true)
 #pragma unroll
     for (int t = 0; t < NT4; ++t)
 #pragma unroll
@@ -417,6 +449,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
       }
     }
   }
+#undef XK_S2_LOAD_BJ
   __syncthreads();
   T* rp = rowP + (((long)b * NS + J) * P) * (long)N;
   for (int idx = threadIdx.x; idx < tile_rows * P; idx += S2_THREADS) {
