@@ -342,7 +342,7 @@ def _sub_operator(A, B, N, b0, b1):
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
-             **unused):
+             groups="auto", **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -379,6 +379,12 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         units free, and the small Rayleigh–Ritz / orthogonalisation kernels of one group run on those CUs (own
         hardware queue) underneath the panel product of the other.  Iteration counts and the stopping rule are
         unchanged.  ``"auto"`` (default): on from 8 GiB of operator storage; ``True`` / ``False`` force it
+    groups: str or int
+        (extension) number of batch groups of the overlapped form.  ``"auto"`` (default): two.  More groups
+        would hide a longer small-kernel chain under the other groups' panel products, but every group costs one
+        host read of its status and ~20 kernel launches per iteration, and at the batch sizes where the chain is
+        exposed the host is the limit: 8 operators of order 16384: 32.7 ms with 2 groups, 40.1 with 3, 52 with 4;
+        16 operators: 56.6 vs 69.8 ms with 4 (r02).  An integer forces it (clamped to the batch size)
     reserve_cus: int
         (extension) compute units the panel-product stream leaves to the small kernels (default 64 of 256: the
         HBM-bound panel product is as fast on 192 CUs as on all of them; whole 32-CU mask words measured best:
@@ -439,17 +445,23 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         and not (precond is not None and not isinstance(precond, (str, torch.Tensor)))
     big = B * N * N * (8 if dtype == torch.float64 else 4) >= 2 ** 33
     two = can_two and (overlap is True or (overlap == "auto" and big))
+    ngrp = 2
+    if two:
+        if groups == "auto":
+            ngrp = 2
+        else:
+            ngrp = max(2, min(int(groups), B))
     if two:
         try:
-            grp_streams = [K.masked_stream(device, 0, slot=1), K.masked_stream(device, 0, slot=2)]
+            grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
             k1_stream = K.masked_stream(device, reserve_cus)
         except NativeLibraryError as err:            # no CU-mask support: same kernels, one group, one stream
             import warnings
             warnings.warn("xitorch_amd davidson: CU-masked streams unavailable (%s); running one batch group" % err)
             two = False
     if two:
-        h = B // 2
-        spans = [(0, h), (h, B)]
+        cuts = [(B * g) // ngrp for g in range(ngrp + 1)]
+        spans = [(cuts[g], cuts[g + 1]) for g in range(ngrp)]
         ops = [_PanelOperator(_sub_operator(A, B, N, b0, b1), [b1 - b0], b1 - b0, N) for (b0, b1) in spans]
         cur = torch.cuda.current_stream()
         # each group gets a stream with its own hardware queue (see kernels.masked_stream).  The caller's
