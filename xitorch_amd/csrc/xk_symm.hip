@@ -346,6 +346,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE
   }
   else
     symm_tile_rows<T, P, false>(tile, Xb, ldab, ldx, N, row0, i_end, jj, joff, row0, acc_col, xJ, rowacc, lane);
+#if defined(XK_SYMM_EXP) && XK_SYMM_EXP >= 1      /* experiment (wrong results): no end barrier, no row flush */
+  if (rowacc[threadIdx.x] == T(12345.678)) rowP[threadIdx.x] = T(1);
+#else
   __syncthreads();
   // flush: row partial slot J (rows of this tile), column partial slot I (columns of this slab)
   T* rp = rowP + (((long)b * NS + J) * P) * (long)N;
@@ -354,10 +357,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE
     const int c = idx / nrows, lr = idx - c * nrows;
     rp[(long)c * N + row0 + lr] = rowacc[lr * P + c];
   }
+#endif
   T* cp = colP + (((long)b * NT + I) * P) * (long)N;
+#if defined(XK_SYMM_EXP) && XK_SYMM_EXP >= 2      /* experiment: no column flush either (all sums kept alive) */
+  T chk = T(0);
 #pragma unroll
   for (int u = 0; u < NU; ++u)
-    if (colok[u]) {
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+      for (int v = 0; v < VN; ++v) chk += acc_col[u][c][v];
+  const bool doflush = (chk == T(12345.678));
+#else
+  const bool doflush = true;
+#endif
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    if (colok[u] && doflush) {
 #pragma unroll
       for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(cp + (long)c * N + jj[u]) = acc_col[u][c];
     }

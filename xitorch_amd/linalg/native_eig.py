@@ -530,9 +530,15 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         niter = it + 1
         local_max, bad = 0.0, 0.0
         deferred = []
+        with torch.cuda.stream(streams[0]):
+            groups[0].small()
         for g in range(G):
+            if g + 1 < G:
+                # the next group's Rayleigh-Ritz chain is enqueued BEFORE the host blocks on this group's status:
+                # it starts the moment its own panel product is done instead of one host round trip later
+                with torch.cuda.stream(streams[g + 1]):
+                    groups[g + 1].small()
             with torch.cuda.stream(streams[g]):
-                groups[g].small()
                 st_g, bad_g, tri_g = groups[g].status.tolist()        # host waits for THIS group's stream only
                 if tri_g != 0:
                     # the tridiagonalisation kernel's self-check failed for some member: same step on Jacobi
