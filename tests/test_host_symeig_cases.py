@@ -75,13 +75,23 @@ def test_lsymeig_AM(dtype, method, ashape, mshape):
         gradgradcheck(fcn, (mata, matm))
 
 
-def _degenerate_setup(dtype, eivaloffset=0):
+def _levels(dtype, shift=0.0):
+    """three distinct levels; the operators below repeat the middle and the top one (spectrum 1, 2, 2, 3, 3 + shift)"""
     torch.manual_seed(SEED)
-    n = 5
-    a = torch.tensor([1.0, 2.0, 3.0], dtype=dtype) + eivaloffset
-    if torch.is_complex(a):
-        a = a.real
-    return n, a.requires_grad_()
+    lv = torch.tensor([1.0, 2.0, 3.0], dtype=dtype) + shift
+    return (lv.real if torch.is_complex(lv) else lv).requires_grad_()
+
+
+def _operator_with_repeated_levels(levels, frame_src, dtype):
+    """Q^H diag(l0, l1, l1, l2, l2) Q with Q from the QR factorisation of `frame_src`"""
+    Q, _ = torch.linalg.qr(frame_src)
+    spectrum = torch.cat((levels[:2], levels[1:2], levels[2:], levels[2:])).to(dtype)
+    return Q.transpose(-2, -1).conj() @ torch.diag_embed(spectrum) @ Q
+
+
+def _subspace_functional(W, U):
+    """depends on span(U) only through U U^H: invariant under rotations inside a degenerate pair"""
+    return torch.einsum("rc,rc->", W @ U, U.conj())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -89,62 +99,56 @@ def _degenerate_setup(dtype, eivaloffset=0):
 @pytest.mark.parametrize("eivaloffset", [0, -4])
 def test_symeig_A_degenerate(dtype, method, eivaloffset):
     """the gradient propagates stably when the loss does not depend on which degenerate eigenvectors were picked"""
-    n, a = _degenerate_setup(dtype, eivaloffset)
-    mat = torch.randn((n, n), dtype=dtype).requires_grad_()
-    P2 = torch.randn((n, n), dtype=dtype).requires_grad_()
+    n = 5
+    levels = _levels(dtype, eivaloffset)
+    frame = torch.randn((n, n), dtype=dtype).requires_grad_()
+    W = torch.randn((n, n), dtype=dtype).requires_grad_()
 
-    def get_loss(a, mat, P2):
-        P, _ = torch.linalg.qr(mat)
-        b = torch.cat((a[:2], a[1:2], a[2:], a[2:])).to(dtype)
-        A = torch.matmul(torch.matmul(P.transpose(-2, -1).conj(), torch.diag_embed(b)), P)
-        _, eivecs = symeig(LinearOperator.m(A, is_hermitian=True), neig=3, method=method,
-                           bck_options={"method": "exactsolve"})
-        U = eivecs[:, 1:3]
-        return torch.einsum("rc,rc->", torch.matmul(P2, U), U.conj())
-    gradcheck(get_loss, (a, mat, P2))
-    gradgradcheck(get_loss, (a, mat, P2))
+    def loss(levels, frame, W):
+        A = _operator_with_repeated_levels(levels, frame, dtype)
+        _, vecs = symeig(LinearOperator.m(A, is_hermitian=True), neig=3, method=method,
+                         bck_options={"method": "exactsolve"})
+        return _subspace_functional(W, vecs[:, 1:3])          # the degenerate pair
+    gradcheck(loss, (levels, frame, W))
+    gradgradcheck(loss, (levels, frame, W))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("method", METHODS)
 def test_symeig_AM_degenerate(dtype, method):
-    n, a = _degenerate_setup(dtype)
-    matA = torch.randn((n, n), dtype=dtype)
-    matM = torch.rand((n, n), dtype=dtype)
-    P2 = torch.randn((n, n), dtype=dtype).requires_grad_()
+    n = 5
+    levels = _levels(dtype)
+    frame = torch.randn((n, n), dtype=dtype)
+    overlap_src = torch.rand((n, n), dtype=dtype)
+    W = torch.randn((n, n), dtype=dtype).requires_grad_()
 
-    def get_loss(a, matA, matM, P2):
-        P, _ = torch.linalg.qr(matA)
-        PM, _ = torch.linalg.qr(matM)
-        b = torch.cat((a[:2], a[1:2], a[2:], a[2:])).to(dtype)
-        A = torch.matmul(torch.matmul(P.transpose(-2, -1).conj(), torch.diag_embed(b)), P)
-        M = torch.matmul(PM.transpose(-2, -1).conj(), PM)
-        _, eivecs = symeig(LinearOperator.m(A, is_hermitian=True), M=LinearOperator.m(M, is_hermitian=True), neig=3,
-                           method=method, bck_options={"method": "exactsolve"})
-        U = eivecs[:, 1:3]
-        return torch.einsum("rc,rc->", torch.matmul(P2, U), U.conj())
-    gradcheck(get_loss, (a, matA, matM, P2))
-    gradgradcheck(get_loss, (a, matA, matM, P2))
+    def loss(levels, frame, overlap_src, W):
+        A = _operator_with_repeated_levels(levels, frame, dtype)
+        R, _ = torch.linalg.qr(overlap_src)
+        M = R.transpose(-2, -1).conj() @ R
+        _, vecs = symeig(LinearOperator.m(A, is_hermitian=True), M=LinearOperator.m(M, is_hermitian=True), neig=3,
+                         method=method, bck_options={"method": "exactsolve"})
+        return _subspace_functional(W, vecs[:, 1:3])
+    gradcheck(loss, (levels, frame, overlap_src, W))
+    gradgradcheck(loss, (levels, frame, overlap_src, W))
 
 
 def test_symeig_A_degenerate_requirement_not_satisfied_warns():
     """a loss that DOES depend on the choice inside the degenerate subspace: one MathWarning in debug mode"""
-    n, a = _degenerate_setup(torch.float64)
-    mat = torch.randn((n, n), dtype=torch.float64).requires_grad_()
+    n = 5
+    levels = _levels(torch.float64)
+    frame = torch.randn((n, n), dtype=torch.float64).requires_grad_()
 
-    def get_loss(a, mat):
-        P, _ = torch.linalg.qr(mat)
-        b = torch.cat((a[:2], a[1:2], a[2:], a[2:]))
-        A = torch.matmul(torch.matmul(P.T, torch.diag_embed(b)), P)
-        _, eivecs = symeig(LinearOperator.m(A), neig=3, method="custom_exacteig",
-                           bck_options={"method": "exactsolve"})
-        return torch.sum(eivecs[:, :3] ** 4)
-    with warnings.catch_warnings(record=True) as w, enable_debug():
+    def loss(levels, frame):
+        A = _operator_with_repeated_levels(levels, frame, torch.float64)
+        _, vecs = symeig(LinearOperator.m(A), neig=3, method="custom_exacteig", bck_options={"method": "exactsolve"})
+        return torch.sum(vecs[:, :3] ** 4)                     # columns 1, 2 span the degenerate pair
+    with warnings.catch_warnings(record=True) as caught, enable_debug():
         warnings.simplefilter("always")
-        get_loss(a, mat).backward()
-    w = [x for x in w if x.category is MathWarning]
-    assert len(w) == 1
-    msg = str(w[0].message).lower()
+        loss(levels, frame).backward()
+    caught = [x for x in caught if x.category is MathWarning]
+    assert len(caught) == 1
+    msg = str(caught[0].message).lower()
     assert "degener" in msg and "loss function" in msg and "incorrect" in msg
 
 
