@@ -266,6 +266,25 @@ def main():
     # ---------------- extra: the timed kernel alone on the GPU (no other batch group beside it) ----------------
     # inside the two-group pipeline the panel product shares HBM with the other group's small kernels (that is the
     # point of the pipeline); the same kernel on the whole batch with nothing else running shows what the sharing costs
+    # what the operator batch streams at with no arithmetic at all (3 read-only passes, idle GPU): the practical
+    # ceiling of any panel kernel on this box and this placement of the batch
+    try:
+        XK.stream_read(mat)
+        re_ = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            nread = XK.stream_read(mat)
+            e1.record()
+            re_.append((e0, e1))
+        torch.cuda.synchronize()
+        r_avg = sum(a.elapsed_time(b) for a, b in re_) / len(re_) * 1e-3
+        roofline["stream_read"] = {"GBps": nread / r_avg / 1e9, "frac_of_peak": nread / r_avg / 1e9 / 8000.0,
+                                   "bytes": nread, "avg_ms": r_avg * 1e3,
+                                   "note": "xk_stream_read over the whole operator batch: 16 B/lane nt loads, no arithmetic"}
+        roofline["frac_of_stream_read"] = roofline["achieved"] / roofline["stream_read"]["GBps"]
+    except Exception as err:        # a measurement extra never costs the headline line
+        roofline["stream_read"] = {"error": repr(err)}
     if symm:
         Xs = torch.randn((b_local, p, N), dtype=dtype, device=dev)
         Ys = torch.empty_like(Xs)
@@ -283,6 +302,10 @@ def main():
         roofline["standalone_whole_batch_launch"] = {
             "avg_launch_ms": s_avg * 1e3, "achieved": sb / s_avg / 1e9, "frac": sb / s_avg / 1e9 / 8000.0,
             "bytes": sb, "note": "tile kernel + fold, %d operators, idle GPU, outside the timed region" % b_local}
+        if "GBps" in roofline.get("stream_read", {}):
+            # the triangle kernel against the bare stream: the same bytes per second scale, no data-sheet number
+            roofline["standalone_whole_batch_launch"]["frac_of_stream_read"] = \
+                (sb / s_avg / 1e9) / roofline["stream_read"]["GBps"]
         del Xs, Ys
 
     # ---------------- extra: the full-matrix panel kernel on the same resident operator ----------------

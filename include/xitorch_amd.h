@@ -40,6 +40,10 @@ int xk_abi_version(void);
  * (hipExtStreamCreateWithCUMask).  The eigensolver launches the HBM-bound panel product on it so that the
  * latency-bound small kernels of the other half of the batch find free CUs (linalg.symeig davidson,
  * option overlap).  The caller owns the stream (xk_stream_destroy). */
+/* measurement utility: read bytes/pitch_bytes rows of pitch_bytes (16 B multiples, 16 B aligned) of device memory once
+ * in the panel kernels' tile walk, no arithmetic; `scratch`: >= 4 KiB of device memory or NULL.  Timed by the caller
+ * (bench.py: the practical streaming ceiling of the operator batch) */
+int xk_stream_read(const void* src, long bytes, long pitch_bytes, void* scratch, void* stream);
 int xk_stream_create_cu_masked(int device, int reserve_cus, void** stream_out);
 int xk_stream_destroy(void* stream);
 

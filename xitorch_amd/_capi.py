@@ -54,6 +54,7 @@ def _declare(L):
         "xk_abi_version": (I, []),
         "xk_stream_create_cu_masked": (I, [I, I, P]),
         "xk_stream_destroy": (I, [P]),
+        "xk_stream_read": (I, [P, Lg, Lg, P, P]),
         "xk_dense_mm_workspace_elems": (Lg, [I, I, I, I, I]),
         "xk_dense_mm_f64": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),
         "xk_dense_mm_f32": (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, I, I, P]),

@@ -39,3 +39,59 @@ extern "C" int xk_stream_destroy(void* stream) {
   if (!stream) return XK_OK;
   return (int)hipStreamDestroy((hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Measurement utility: read `bytes` of device memory once with 16 B/lane non-temporal loads and NO arithmetic
+// beyond a checksum that keeps the loads alive.  The buffer is walked the way the panel kernels walk an operator
+// batch: rows of `pitch_bytes`, tiles of 1024 rows x 8 KB, one 256-thread block per tile, every wave 2 KB of a row
+// per step with a ring of 8 rows (16 KB) in flight.  bench.py times it on the operator batch to report what the
+// SAME buffer streams at when nothing is computed — the practical ceiling the panel kernels are measured against
+// (`roofline.stream_read`; scripts/micro/stream_patterns.hip has the other walks).
+// ---------------------------------------------------------------------------------------------
+namespace xk {
+typedef unsigned int api_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_read_kernel(const char* __restrict__ src, long rows, long pitch,
+                                                           int tiles_c, unsigned* __restrict__ scratch) {
+  constexpr int DEPTH = 8, TR = 1024, TCB = 8192;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long tr = blockIdx.x / tiles_c;
+  const int tc = (int)(blockIdx.x - tr * tiles_c);
+  const long row0 = tr * TR;
+  long nrows = rows - row0;
+  nrows = nrows < TR ? nrows : TR;
+  const long colb = (long)tc * TCB + wave * 2048 + lane * 16;       // byte column of this lane's first vector
+  const bool ok0 = colb + 16 <= pitch, ok1 = colb + 1024 + 16 <= pitch;
+  const char* base = src + row0 * pitch + colb;
+  api_u4 acc = {0u, 0u, 0u, 0u};
+  api_u4 ring[DEPTH][2];
+#pragma unroll
+  for (int r = 0; r < DEPTH; ++r) {
+    const long rr = r < nrows ? r : nrows - 1;
+    ring[r][0] = ok0 ? __builtin_nontemporal_load((const api_u4*)(base + rr * pitch)) : acc;
+    ring[r][1] = ok1 ? __builtin_nontemporal_load((const api_u4*)(base + rr * pitch + 1024)) : acc;
+  }
+  for (long i0 = 0; i0 < nrows; i0 += DEPTH) {
+#pragma unroll
+    for (int r = 0; r < DEPTH; ++r) {
+      acc ^= ring[r][0] ^ ring[r][1];
+      long rr = i0 + DEPTH + r;
+      rr = rr < nrows ? rr : nrows - 1;
+      ring[r][0] = ok0 ? __builtin_nontemporal_load((const api_u4*)(base + rr * pitch)) : acc;
+      ring[r][1] = ok1 ? __builtin_nontemporal_load((const api_u4*)(base + rr * pitch + 1024)) : acc;
+    }
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && scratch) scratch[blockIdx.x & 1023] = acc[0];
+}
+}  // namespace xk
+
+extern "C" int xk_stream_read(const void* src, long bytes, long pitch_bytes, void* scratch, void* stream) {
+  if (bytes < 0 || pitch_bytes <= 0 || (pitch_bytes & 15) || ((uintptr_t)src & 15)) return XK_ERR_ARG;
+  const long rows = bytes / pitch_bytes;
+  if (rows == 0) return XK_OK;
+  const long tiles_r = (rows + 1023) / 1024, tiles_c = (pitch_bytes + 8191) / 8192;
+  if (tiles_r * tiles_c > 0x7fffffffL || tiles_c > 0x7fffffffL) return XK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(xk::stream_read_kernel, dim3((unsigned)(tiles_r * tiles_c)), dim3(256), 0, (hipStream_t)stream,
+                     (const char*)src, rows, pitch_bytes, (int)tiles_c, (unsigned*)scratch);
+  XK_LAUNCH_CHECK();
+  return XK_OK;
+}

@@ -392,6 +392,22 @@ def dense_outer_complex(U, W):
     return torch.view_as_complex(G.view(B, M, N, 2))
 
 
+# --------------------------------------------------------------------------- measurement utility
+def stream_read(t):
+    """Enqueue one read-only pass over the storage of the contiguous HIP tensor `t` (rows = its last dimension; the
+    panel kernels' tile walk, 16 B/lane non-temporal loads, no arithmetic) on the current stream.  Timed by the
+    caller: what this very buffer streams at when nothing is computed (bench.py ``roofline.stream_read``)."""
+    if not t.is_cuda or not t.is_contiguous() or t.dim() < 1:
+        raise _capi.NativeLibraryError("stream_read needs a contiguous HIP tensor")
+    pitch = t.shape[-1] * t.element_size()
+    if pitch % 16:
+        raise _capi.NativeLibraryError("stream_read: the row length must be a multiple of 16 bytes")
+    nbytes = t.numel() * t.element_size()
+    rc = fn("xk_stream_read")(ptr(t), nbytes, pitch, None, stream_ptr())
+    check(rc, "xk_stream_read")
+    return nbytes
+
+
 # --------------------------------------------------------------------------- CU-masked stream
 _MASKED_STREAMS = {}
 
