@@ -298,3 +298,23 @@ def test_dense_rows_wide_vs_torch(dev, dtype, tol, B, M, N, P):
     assert (Y3.double().cpu() - ref3).abs().max().item() <= tol * scale
     # deterministic (fixed-order fold of the split contraction)
     assert torch.equal(K.dense_rows_wide(Ad, Xd), Y)
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 1000, 1000), torch.float64), ((1, 5, 16388), torch.float32),
+                                         ((2, 2048, 2048), torch.float64), ((7, 12), torch.float32)])
+def test_stream_read_utility_runs_on_ragged_shapes(dev, shape, dtype):
+    # the measurement utility behind bench.py's roofline.stream_read: every byte once, nothing written; rows and row
+    # lengths that are not multiples of its 1024 x 8 KB tiles must stay inside the buffer (a guard region is checked)
+    n = 1
+    for d in shape:
+        n *= d
+    guard = 4096
+    buf = torch.full((n + 2 * guard,), 7.0, dtype=dtype, device=dev)
+    t = buf[guard:guard + n].view(shape)
+    if (t.data_ptr() % 16) or (shape[-1] * t.element_size()) % 16:
+        pytest.skip("alignment")
+    before = buf.clone()
+    nbytes = K.stream_read(t)
+    torch.cuda.synchronize()
+    assert nbytes == n * t.element_size()
+    assert torch.equal(buf, before)
