@@ -184,7 +184,27 @@ def main():
     if world > 1 or os.environ.get("XITORCH_BENCH_FORCE_PG") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)         # "nccl" == RCCL on ROCm
+        if world == 1:                      # the forced single-rank group: no launcher has set the rendezvous up
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("LOCAL_RANK", "0")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        # RCCL prints a version banner on the C-level stdout when its first communicator comes up; rank 0's
+        # stdout carries exactly one JSON line, so the banner is sent to stderr (fd 1 -> fd 2 while the group and its
+        # first collective are set up, C stdio flushed before fd 1 is restored)
+        import ctypes
+        libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=dev)         # "nccl" == RCCL on ROCm
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+        finally:
+            libc.fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         group = dist.group.WORLD
         backend, rccl_world = dist.get_backend(group), dist.get_world_size(group)
 
@@ -380,6 +400,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # nothing buffered by native libraries may follow the line
         print(json.dumps(out), flush=True)
     if group is not None:
         torch.distributed.destroy_process_group()
