@@ -76,6 +76,9 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size);
 /* implementation behind xk_dense_symm_*: 1 = per-lane rows + wave reductions (xk_symm.hip), 2 = LDS turn + MFMA row
  * part (xk_symm2.hip, default); returns the previous value (A/B measurements) */
 int xk_dense_symm_set_variant(int variant);
+/* bit 0: non-temporal stores of the row / column partials, bit 1: non-temporal loads in the fold (default 3);
+ * returns the previous value (A/B measurements) */
+int xk_dense_symm_set_flags(int flags);
 int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, long ws_elems, int B,
                       int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
 int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,

@@ -75,6 +75,7 @@ def _declare(L):
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
     sigs["xk_dense_symm_set_variant"] = (I, [I])
+    sigs["xk_dense_symm_set_flags"] = (I, [I])
     sigs["xk_dense_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
     sigs["xk_dense_wide_padded_width"] = (I, [I, I])
     sigs["xk_dense_rows_wide_workspace_elems"] = (Lg, [I, I, I, I, I])

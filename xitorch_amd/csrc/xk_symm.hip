@@ -269,7 +269,7 @@ __device__ __forceinline__ void symm_tile_rows(
 template <typename T, int P>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE))) void dense_symm_tiles(
     const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int ntiles,
-    int N, long lda, long sA, long ldx, long sX, int NS, int NT) {
+    int N, long lda, long sA, long ldx, long sX, int NS, int NT, int flags) {
   typedef typename Vec16<T>::type VT;
   constexpr int VN = Vec16<T>::n;
   constexpr int NU = SYMM_NU;
@@ -353,9 +353,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE
   // flush: row partial slot J (rows of this tile), column partial slot I (columns of this slab)
   T* rp = rowP + (((long)b * NS + J) * P) * (long)N;
   const int nrows = (row0 + SYMM_TRH <= N ? SYMM_TRH : N - row0);
-  for (int idx = threadIdx.x; idx < nrows * P; idx += 256) {
-    const int c = idx / nrows, lr = idx - c * nrows;
-    rp[(long)c * N + row0 + lr] = rowacc[lr * P + c];
+  if (flags & 1) {
+    for (int idx = threadIdx.x; idx < nrows * P; idx += 256) {
+      const int c = idx / nrows, lr = idx - c * nrows;
+      __builtin_nontemporal_store(rowacc[lr * P + c], &rp[(long)c * N + row0 + lr]);
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < nrows * P; idx += 256) {
+      const int c = idx / nrows, lr = idx - c * nrows;
+      rp[(long)c * N + row0 + lr] = rowacc[lr * P + c];
+    }
   }
 #endif
   T* cp = colP + (((long)b * NT + I) * P) * (long)N;
@@ -374,15 +381,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE
 #pragma unroll
   for (int u = 0; u < NU; ++u)
     if (colok[u] && doflush) {
+      if (flags & 1) {
 #pragma unroll
-      for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(cp + (long)c * N + jj[u]) = acc_col[u][c];
+        for (int c = 0; c < P; ++c) __builtin_nontemporal_store(acc_col[u][c], reinterpret_cast<VT*>(cp + (long)c * N + jj[u]));
+      } else {
+#pragma unroll
+        for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(cp + (long)c * N + jj[u]) = acc_col[u][c];
+      }
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, const T* __restrict__ colP,
                                                   T* __restrict__ Y, int N, int P, int NS, int NT, int slab,
-                                                  long ldy, long sY, long total) {
+                                                  long ldy, long sY, long total, int flags) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*P*N
   if (idx >= total) return;
   const long per_b = (long)P * N;
@@ -393,9 +405,15 @@ __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, con
   const int It = n / SYMM_TRH;                 // row tile of n
   const int Jfirst = (It * SYMM_TRH) / slab;   // first column slab that owns a tile with row tile It
   T s = T(0);
-  for (int J = Jfirst; J < NS; ++J) s += rowP[(((long)b * NS + J) * P + c) * (long)N + n];
   const int Imax = ((n / slab) * slab + slab - 1) / SYMM_TRH;   // row tiles I with I*TRH <= last column of n's slab
-  for (int I = 0; I <= Imax && I < NT; ++I) s += colP[(((long)b * NT + I) * P + c) * (long)N + n];
+  if (flags & 2) {                                              // the partials are read exactly once
+    for (int J = Jfirst; J < NS; ++J) s += __builtin_nontemporal_load(&rowP[(((long)b * NS + J) * P + c) * (long)N + n]);
+    for (int I = 0; I <= Imax && I < NT; ++I)
+      s += __builtin_nontemporal_load(&colP[(((long)b * NT + I) * P + c) * (long)N + n]);
+  } else {
+    for (int J = Jfirst; J < NS; ++J) s += rowP[(((long)b * NS + J) * P + c) * (long)N + n];
+    for (int I = 0; I <= Imax && I < NT; ++I) s += colP[(((long)b * NT + I) * P + c) * (long)N + n];
+  }
   Y[b * sY + (long)c * ldy + n] = s;
 }
 
@@ -405,6 +423,10 @@ int symm2_launch(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int 
                  long ldx, long sX, long ldy, long sY, void* stream, int phase);
 long symm2_workspace_elems(int B, int N, int P, int elem_size);
 
+// bit 0: the row / column partials leave with non-temporal stores, bit 1: the fold reads them with non-temporal
+// loads (they are written once and read once, 6 ms apart: keeping them out of L2's way is worth 1.2 % of the call,
+// same-process A/B scripts/symm_flags_ab.py); 0 restores plain stores / loads for that A/B
+static int g_symm_flags = 3;
 static int g_symm_variant = 1;     // 1: per-lane rows + wave reductions (this file), 2: LDS turn + MFMA row part
 
 }  // namespace xk
@@ -413,6 +435,13 @@ extern "C" {
 
 // which implementation serves xk_dense_symm_* (both read only the upper triangle and share the workspace
 // contract); returns the previous setting.  Kept for A/B measurements (bench.py --k1s-variant).
+// A/B switch for the non-temporal handling of the partials (see g_symm_flags); returns the previous value
+int xk_dense_symm_set_flags(int f) {
+  const int old = xk::g_symm_flags;
+  xk::g_symm_flags = f;
+  return old;
+}
+
 int xk_dense_symm_set_variant(int v) {
   const int old = xk::g_symm_variant;
   if (v == 1 || v == 2) xk::g_symm_variant = v;
@@ -467,7 +496,8 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
       if (phase != 1) {                                                                                     \
         const long total = (long)B * pc * N;                                                                \
         hipLaunchKernelGGL((xk::symm_fold<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,     \
-                           rowP, colP, Y + (long)c0 * ldy, N, pc, NS, NT, SLAB, ldy, sY, total);            \
+                           rowP, colP, Y + (long)c0 * ldy, N, pc, NS, NT, SLAB, ldy, sY, total,             \
+                           xk::g_symm_flags);                                                               \
         XK_LAUNCH_CHECK();                                                                                  \
       }                                                                                                     \
       c0 += pc;                                                                                             \
@@ -492,7 +522,7 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
 #define XK_SYMM_CASE(PP)                                                                                  \
   case PP:                                                                                                \
     hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP>), grid, dim3(256), lds, st, A, Xc, rowP, colP, nt,   \
-                       N, lda, sA, ldx, sX, NS, NT);                                                      \
+                       N, lda, sA, ldx, sX, NS, NT, xk::g_symm_flags);                                    \
     break;
 
 #define TT double

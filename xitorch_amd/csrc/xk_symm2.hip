@@ -454,7 +454,7 @@ __global__ __launch_bounds__(S2_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
   T* rp = rowP + (((long)b * NS + J) * P) * (long)N;
   for (int idx = threadIdx.x; idx < tile_rows * P; idx += S2_THREADS) {
     const int c = idx / tile_rows, lr = idx - c * tile_rows;
-    rp[(long)c * N + row0 + lr] = rowacc[lr * P + c];
+    __builtin_nontemporal_store(rowacc[lr * P + c], &rp[(long)c * N + row0 + lr]);   // written once, read once
   }
 }
 
@@ -476,9 +476,10 @@ __global__ __launch_bounds__(256) void symm2_fold(const T* __restrict__ rowP, co
   const int It = n / S2_TRH;
   const int Jfirst = (It * S2_TRH) / SLAB;
   T s = T(0);
-  for (int J = Jfirst; J < NS; ++J) s += rowP[(((long)b * NS + J) * P + c) * (long)N + n];
+  for (int J = Jfirst; J < NS; ++J) s += __builtin_nontemporal_load(&rowP[(((long)b * NS + J) * P + c) * (long)N + n]);
   const int Imax = ((n / SEG) * SEG) / S2_TRH;
-  for (int I = 0; I <= Imax && I < NT; ++I) s += colP[(((long)b * NT + I) * P + c) * (long)N + n];
+  for (int I = 0; I <= Imax && I < NT; ++I)
+    s += __builtin_nontemporal_load(&colP[(((long)b * NT + I) * P + c) * (long)N + n]);
   Y[b * sY + (long)c * ldy + n] = s;
 }
 
