@@ -165,6 +165,12 @@ int xk_diag_precond_f64(double* t, const double* d, const double* m, const doubl
 int xk_diag_precond_f32(float* t, const float* d, const float* m, const float* lam, int B, int N, int P,
                         long ldt, long sT, long sD, long sM, long sLam, double floor_, void* stream);
 
+/* ---- group status of a Davidson step in one launch (native_eig._Group.small; the reference reads
+ * `resid.abs().max()` on the host, symeig.py:190-197): status[0] = max_b rmax[b] (NaN if any is NaN),
+ * status[1] = max_b info[b] (panel Cholesky flags), status[2] = max_b flag[b] (K3t self-check; flag may be NULL) */
+int xk_group_status_f64(const double* rmax, const int* info, const int* flag, double* status, int B, void* stream);
+int xk_group_status_f32(const float* rmax, const int* info, const int* flag, double* status, int B, void* stream);
+
 /* ---- K3: batched small symmetric eigensolver (LDS-resident parallel Jacobi) -----------------
  * Lowest (uppest=0) / uppermost (uppest=1) p eigenpairs of B symmetric k x k matrices (lower
  * triangle read, pitch ldt, batch pitch sT), eigenvalues ascending: lam (B,p), Y (B,p,k) with

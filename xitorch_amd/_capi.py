@@ -84,6 +84,7 @@ def _declare(L):
     for sfx in ("f64", "f32"):
         sigs["xk_dense_wide_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):
+        sigs["xk_group_status_" + sfx] = (I, [P, P, P, P, I, P])
         sigs["xk_dense_symm_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
         sigs["xk_dense_symm_tiles_" + sfx] = (I, [P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, P])
         sigs["xk_dense_symm_fold_" + sfx] = (I, [P, P, Lg, I, I, I, Lg, Lg, P])

@@ -318,6 +318,50 @@ __global__ __launch_bounds__(256) void diag_precond_kernel(T* __restrict__ Tn, c
   *t = *t / den;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Group status in one launch: status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b]} as doubles.
+// Replaces three torch reductions + three converting element copies per Rayleigh-Ritz step (eight tiny launches on
+// the critical chain of a small batch group).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void group_status_kernel(const T* __restrict__ rmax, const int* __restrict__ info,
+                                                          const int* __restrict__ flag, double* __restrict__ status,
+                                                          int B) {
+  const int lane = threadIdx.x;
+  double m = 0.0;
+  int nan = 0, i1 = 0, i2 = 0;
+  bool first = true;
+  for (int b = lane; b < B; b += 64) {
+    const double v = (double)rmax[b];
+    nan |= (v != v);
+    m = first ? v : (v > m ? v : m);
+    const int a = info[b];
+    i1 = first ? a : (a > i1 ? a : i1);
+    if (flag) {
+      const int f = flag[b];
+      i2 = first ? f : (f > i2 ? f : i2);
+    }
+    first = false;
+  }
+  // lanes without an element must not contribute: fold with explicit validity
+  double mm = first ? -__builtin_inf() : m;
+  int a1 = first ? -2147483647 - 1 : i1, a2 = first ? -2147483647 - 1 : i2;
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const double om = __shfl_xor(mm, sft, 64);
+    const int o1 = __shfl_xor(a1, sft, 64), o2 = __shfl_xor(a2, sft, 64), on = __shfl_xor(nan, sft, 64);
+    mm = om > mm ? om : mm;
+    a1 = o1 > a1 ? o1 : a1;
+    a2 = o2 > a2 ? o2 : a2;
+    nan |= on;
+  }
+  if (lane == 0) {
+    status[0] = nan ? __builtin_nan("") : mm;
+    status[1] = (double)a1;
+    status[2] = flag ? (double)a2 : 0.0;
+  }
+}
+
 }  // namespace xk
 
 extern "C" {
@@ -363,6 +407,18 @@ extern "C" {
 
 XK_DEFINE_BASIS(f64, double)
 XK_DEFINE_BASIS(f32, float)
+
+#define XK_DEFINE_STATUS(SUF, T)                                                                            \
+  int xk_group_status_##SUF(const T* rmax, const int* info, const int* flag, double* status, int B,         \
+                            void* stream) {                                                                 \
+    if (B <= 0 || !rmax || !info || !status) return XK_ERR_ARG;                                             \
+    hipLaunchKernelGGL((xk::group_status_kernel<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, rmax, info, \
+                       flag, status, B);                                                                    \
+    XK_LAUNCH_CHECK();                                                                                      \
+    return XK_OK;                                                                                           \
+  }
+XK_DEFINE_STATUS(f64, double)
+XK_DEFINE_STATUS(f32, float)
 
 #define XK_DEFINE_PRECOND(SUF, T)                                                                          \
   int xk_diag_precond_##SUF(T* Tn, const T* d, const T* m, const T* lam, int B, int N, int P, long ldt,    \

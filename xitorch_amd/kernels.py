@@ -111,6 +111,14 @@ def lincomb(V, C, out, k, P, coef_layout="ac", alpha=1.0, beta=0.0):
     return out
 
 
+def group_status(rmax, info, flag, status):
+    """status (3 doubles on the device) = {max rmax (NaN-propagating), max info, max flag or 0}: one launch instead of
+    three reductions and three converting copies (the host reads it once per Davidson step, symeig.py:190-197)."""
+    rc = fn("xk_group_status_" + suffix(rmax.dtype))(ptr(rmax), ptr(info), ptr(flag) if flag is not None else None,
+                                                     ptr(status), rmax.shape[0], stream_ptr())
+    check(rc, "xk_group_status")
+
+
 def ritz_residual(V, AV, Y, lam, X, Tn, rmax, k, P):
     """Fused K4/K5 (symeig.py:178-188): X = Y^T V, AX = Y^T AV, Tn = -(AX - lam X), rmax[b] = max|AX - lam X|.
 

@@ -256,9 +256,7 @@ class _Group:
                 self.precond[1].apply(self.newpanel, tmp)
                 self.newpanel.copy_(tmp)
         self.lam = lam
-        self.status[0] = self.rmax.max()
-        self.status[1] = self.info.max()
-        self.status[2] = tri_flag.max() if tri_flag is not None else 0.0
+        K.group_status(self.rmax, self.info, tri_flag, self.status)
         end_ritz()
 
     def compress(self):
