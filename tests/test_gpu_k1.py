@@ -318,3 +318,22 @@ def test_stream_read_utility_runs_on_ragged_shapes(dev, shape, dtype):
     torch.cuda.synchronize()
     assert nbytes == n * t.element_size()
     assert torch.equal(buf, before)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("B", [1, 5, 64, 200])
+def test_group_status_kernel(dev, dtype, B):
+    # {max|resid| (NaN-propagating), max Cholesky flag, max K3t flag} of a batch group in one launch
+    g = torch.Generator().manual_seed(B)
+    rmax = torch.rand(B, dtype=dtype, generator=g).to(dev)
+    info = torch.randint(0, 3, (B,), dtype=torch.int32, generator=g).to(dev)
+    flag = torch.randint(0, 5, (B,), dtype=torch.int32, generator=g).to(dev)
+    st = torch.full((3,), -1.0, dtype=torch.float64, device=dev)
+    K.group_status(rmax, info, flag, st)
+    assert st.tolist() == [float(rmax.max().double()), float(info.max()), float(flag.max())]
+    K.group_status(rmax, info, None, st)
+    assert st.tolist()[2] == 0.0
+    rmax[B // 2] = float("nan")
+    K.group_status(rmax, info, flag, st)
+    out = st.tolist()
+    assert out[0] != out[0] and out[1] == float(info.max())
