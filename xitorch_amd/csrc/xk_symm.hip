@@ -174,7 +174,10 @@ __device__ __forceinline__ void symm_chunk8(
           row = row < i_last ? row : i_last;
 #pragma unroll
           for (int u = 0; u < NU; ++u)
-            a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
+            // (crossing tiles: a lane whose columns all lie strictly below the row fetches nothing — its values
+            //  would be masked to zero anyway; the out-of-range offset returns the zeros without the traffic)
+            a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, (!CROSSING || jj[u] + VN - 1 >= row) ? joff[u] : 0x7ffffff0u,
+                                                  (unsigned)(row - row_tile0) * lda);
         }
       }
       __builtin_amdgcn_sched_barrier(0);      // keep the row pairs in program order (bounded live ranges)
@@ -251,7 +254,9 @@ __device__ __forceinline__ void symm_tile_rows(
     row = row < i_last ? row : i_last;
     row = row > row_tile0 ? row : row_tile0;
 #pragma unroll
-    for (int u = 0; u < SYMM_NU; ++u) a[r][u] = ld_tile<VT>(Ab, joff[u], (unsigned)(row - row_tile0) * lda);
+    for (int u = 0; u < SYMM_NU; ++u)
+      a[r][u] = ld_tile<VT>(Ab, (!CROSSING || jj[u] + Vec16<T>::n - 1 >= row) ? joff[u] : 0x7ffffff0u,
+                            (unsigned)(row - row_tile0) * lda);
   }
   // the block's LDS set-up runs UNDER the first 16 KB of loads (they do not depend on it): every wave passes
   // here exactly once, whichever of the two instantiations it took
