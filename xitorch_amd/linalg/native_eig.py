@@ -416,7 +416,9 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         raise NativeLibraryError("xitorch_amd davidson runs on a HIP device only (operator is on %s); "
                                  "there is no CPU fallback" % device)
     if dtype not in (torch.float64, torch.float32):
-        raise NativeLibraryError("xitorch_amd davidson supports float64/float32 operators, got %s" % dtype)
+        raise NativeLibraryError("xitorch_amd davidson supports float64/float32 operators, got %s (the reference's "
+                                 "davidson is real-only as well: unconjugated transposes, symeig.py:163; complex "
+                                 "Hermitian operators go through method='exacteig')" % dtype)
     B = 1
     for d in bdims:
         B *= d
