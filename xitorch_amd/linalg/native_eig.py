@@ -34,6 +34,9 @@ from xitorch_amd.dist import allreduce_max_
 
 __all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend"]
 
+import os as _os
+_PRELAUNCH = _os.environ.get("XITORCH_AMD_PRELAUNCH", "1") != "0"     # A/B: enqueue the next group's chain early
+
 
 def take_eigpairs(evals, evecs, neig, mode):
     """First (``lowest``) or last (``uppest``) ``neig`` pairs of an ascending ``eigh`` result; the
@@ -533,7 +536,10 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         with torch.cuda.stream(streams[0]):
             groups[0].small()
         for g in range(G):
-            if g + 1 < G:
+            if not _PRELAUNCH and g > 0:
+                with torch.cuda.stream(streams[g]):
+                    groups[g].small()
+            if _PRELAUNCH and g + 1 < G:
                 # the next group's Rayleigh-Ritz chain is enqueued BEFORE the host blocks on this group's status:
                 # it starts the moment its own panel product is done instead of one host round trip later
                 with torch.cuda.stream(streams[g + 1]):
