@@ -236,13 +236,14 @@ def main():
         """`warmup` untimed + exactly `steps` timed symeig calls between two barrier+synchronize fences; MAX over ranks."""
         traces = []
 
-        scratch_events = [] if events is not None else None
+        if events is not None:
+            # the timing events of the panel launches are created (and instantiated by one record each) BEFORE the
+            # timed region: creating them costs host time — visibly so under rocprofv3, where the GPU then idles
+            # between an event and its kernel — and now and then a ~30 ms stall when the runtime grows its pool
+            XK.prefill_timing_events(2 * 48 * (steps + 1))
 
         def step(timed):
-            # warm-up calls record their launches into a throw-away list: the first call that creates ~70 timing
-            # events pays for them on the host (visibly so under rocprofv3, where the GPU then idles between an
-            # event and its kernel), and that call must not be a timed one
-            tr = {"k1_events": events if timed else scratch_events}
+            tr = {"k1_events": events if timed else None}
             with torch.no_grad():
                 evals, evecs = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=args.min_eps,
                                       v_init="randn", rng_device="device", max_niter=args.max_niter,

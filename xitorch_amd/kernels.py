@@ -480,11 +480,45 @@ def dense_symm(A, X, out=None):
     return out
 
 
-def dense_symm_split(A, X, out, tiles_stream):
+# --------------------------------------------------------------------------- events without per-launch creation
+# Creating a HIP event costs host time (and every few hundred of them the runtime grows a pool: a ~30 ms stall seen
+# once per process in the benchmark's timed region).  Cross-stream ordering therefore re-records two cached events per
+# issuing stream, and timing events come from a pool that measurement code can pre-fill.
+_SYNC_EVENTS = {}
+_TIMING_POOL = []
+
+
+def sync_events(stream):
+    """(ready, done): two cached non-timing events owned by `stream` (the stream that issues the work).  A wait
+    captures the record that precedes it, so re-recording them launch after launch is safe."""
+    key = (stream.device.index, stream.cuda_stream)
+    ev = _SYNC_EVENTS.get(key)
+    if ev is None:
+        ev = _SYNC_EVENTS[key] = (torch.cuda.Event(), torch.cuda.Event())
+    return ev
+
+
+def timing_event_pair():
+    if len(_TIMING_POOL) >= 2:
+        return _TIMING_POOL.pop(), _TIMING_POOL.pop()
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def prefill_timing_events(n):
+    """Create (and record once, which is what instantiates them) `n` timing events ahead of a timed region."""
+    st = torch.cuda.current_stream()
+    fresh = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    for e in fresh:
+        e.record(st)
+    st.synchronize()
+    _TIMING_POOL.extend(fresh)
+
+
+def dense_symm_split(A, X, out, tiles_stream, timed=False):
     """K1s with its two launches on two streams (P <= 6): the tile kernel on `tiles_stream` (after everything
     queued so far on the current stream), the fold back on the current stream once the tiles are done.  The
     partial-sum workspace belongs to the current stream, so callers on different streams never share one.
-    Returns the (start, end) timing events recorded around the tile kernel."""
+    Returns the (start, end) timing events recorded around the tile kernel when `timed`, else (None, None)."""
     require_device(A, "operator matrix")
     require_device(X, "panel")
     B, P, N = X.shape
@@ -500,17 +534,21 @@ def dense_symm_split(A, X, out, tiles_stream):
     nws = fn("xk_dense_symm_workspace_elems")(B, N, P, esize)
     cur = torch.cuda.current_stream()
     ws = _workspace(nws, X.dtype, X.device)                 # keyed by the CURRENT (group) stream
-    ready = torch.cuda.Event()
+    ready, done = sync_events(cur)                          # re-recorded on every launch: no event is created here
     ready.record(cur)
     sfx = suffix(X.dtype)
+    e0 = e1 = None
     with torch.cuda.stream(tiles_stream):
         tiles_stream.wait_event(ready)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(tiles_stream)
+        if timed:
+            e0, e1 = timing_event_pair()
+            e0.record(tiles_stream)
         rc = fn("xk_dense_symm_tiles_" + sfx)(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, stream_ptr())
         check(rc, "xk_dense_symm_tiles")
-        e1.record(tiles_stream)
-    cur.wait_event(e1)
+        if timed:
+            e1.record(tiles_stream)
+        done.record(tiles_stream)
+    cur.wait_event(done)
     rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, stream_ptr())
     check(rc, "xk_dense_symm_fold")
     return e0, e1

@@ -89,7 +89,7 @@ class PanelOperator:
         if self.hermitian:
             trans = False
         if self.events is not None and self.kind != "generic":
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = K.timing_event_pair()
             e0.record()
             self._native(X, out, trans)
             e1.record()
@@ -110,17 +110,17 @@ class PanelOperator:
         N = self.N
         if self.kind == "dense" and self.symm and X.shape[1] <= 6 and not self.flip:
             self.napply += 1
-            e0, e1 = K.dense_symm_split(self.mat, X[:, :, :N], out[:, :, :N], k1_stream)
+            e0, e1 = K.dense_symm_split(self.mat, X[:, :, :N], out[:, :, :N], k1_stream,
+                                        timed=self.events is not None)
             if self.events is not None:
                 self.events.append((e0, e1, X.shape[1], X.shape[0]))
             return out
         cur = torch.cuda.current_stream()
-        ready = torch.cuda.Event()
+        ready, done = K.sync_events(cur)            # cached per issuing stream, re-recorded on every launch
         ready.record(cur)
         with torch.cuda.stream(k1_stream):
             k1_stream.wait_event(ready)
             self.apply(X, out)
-            done = torch.cuda.Event()
             done.record(k1_stream)
         cur.wait_event(done)
         return out
