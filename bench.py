@@ -61,6 +61,8 @@ def parse():
                     help="compute units the panel-product stream leaves to the small kernels of the other batch half")
     ap.add_argument("--k1", default="auto", choices=["auto", "general"],
                     help="auto: upper-triangle kernel when the storage is exactly symmetric; general: full matrix")
+    ap.add_argument("--k1s-run", type=int, default=0,
+                    help="measurement: column slabs per workgroup run of the upper-triangle kernel (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="4x4096", help="BxN of the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -178,6 +180,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.k1s_run > 0:
+        from xitorch_amd._capi import fn as _fn
+        _fn("xk_dense_symm_tune")(1, args.k1s_run)
     group, backend, rccl_world = None, None, 1
     # XITORCH_BENCH_FORCE_PG=1: create the RCCL process group even for one rank (smoke test of the N > 1 plumbing —
     # init, barrier, all-reduce of the timing — on a single-GPU box; the solver's own all-reduces need >= 2 ranks)

@@ -73,12 +73,12 @@ int xk_dense_mm_f32(const float* A, const float* X, float* Y, float* ws, long ws
  * (xitorch/_impls/linalg/symeig.py:163,221; symeig requires a Hermitian operator, linalg/symeig.py:103).
  * N must be a multiple of the 16 B vector width; ws: xk_dense_symm_workspace_elems(B,N,P,sizeof(T)). */
 long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size);
-/* implementation behind xk_dense_symm_*: 1 = per-lane rows + wave reductions (xk_symm.hip), 2 = LDS turn + MFMA row
- * part (xk_symm2.hip, default); returns the previous value (A/B measurements) */
-int xk_dense_symm_set_variant(int variant);
-/* bit 0: non-temporal stores of the row / column partials, bit 1: non-temporal loads in the fold (default 3);
- * returns the previous value (A/B measurements) */
-int xk_dense_symm_set_flags(int flags);
+/* Results are run-to-run bit-identical: the four waves of a workgroup add into the LDS row accumulator in a fixed
+ * order (phase rotation with barriers), partial slots are folded in a fixed order.
+ * xk_dense_symm_tune — measurement hook, returns the previous value: what = 0: bit 0 non-temporal stores of the row /
+ * column partials, bit 1 non-temporal loads in the fold (default 3); what = 1: column slabs per workgroup run
+ * (row partials per row tile = ceil(slabs / run), default 1).  Process-wide; not for use while other threads launch. */
+int xk_dense_symm_tune(int what, int value);
 int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, long ws_elems, int B,
                       int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
 int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,

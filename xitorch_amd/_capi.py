@@ -35,9 +35,6 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback." % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
-        v = os.environ.get("XITORCH_AMD_K1S_VARIANT")        # A/B measurements only (1 | 2)
-        if v:
-            _lib.xk_dense_symm_set_variant(int(v))
     return _lib
 
 
@@ -74,8 +71,7 @@ def _declare(L):
         sigs["xk_small_eigh_tri_" + sfx] = (I, [P, P, P, P, I, I, I, I, Lg, Lg, P])
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
-    sigs["xk_dense_symm_set_variant"] = (I, [I])
-    sigs["xk_dense_symm_set_flags"] = (I, [I])
+    sigs["xk_dense_symm_tune"] = (I, [I, I])
     sigs["xk_dense_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
     sigs["xk_dense_wide_padded_width"] = (I, [I, I])
     sigs["xk_dense_rows_wide_workspace_elems"] = (Lg, [I, I, I, I, I])

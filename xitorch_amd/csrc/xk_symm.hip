@@ -6,71 +6,60 @@
 // and used for both of its contributions
 //        y_I += A_IJ x_J      (row part)          y_J += A_IJ^T x_I     (column part)
 // which halves the HBM traffic of the eigensolver's panel product (symeig operators are always
-// Hermitian: xitorch/linalg/symeig.py:103).  Opt-in: the caller asserts exact symmetry of the
-// storage (MatrixLinearOperator(..., symmetric_storage=True)); for merely "allclose" symmetric
-// input (LinearOperator.m's check, linop.py:97-105) the general kernel keeps the reference's
-// full-matrix semantics.
+// Hermitian: xitorch/linalg/symeig.py:103; the product itself: _impls/linalg/symeig.py:163,221).
+// Opt-in: the caller asserts exact symmetry of the storage (LinearOperator.m verifies it bit for
+// bit, linop.py:97-105 in the reference only checks allclose); anything else takes the general kernel.
 //
-// Mapping.  Tiles of TRH=1024 rows x 1024 columns (fp64; 2048 columns fp32).  One 256-thread block
-// per tile; the 4 waves own 4 x 256 columns (lane: two 16 B vectors, so each load instruction is a
-// contiguous 1 KB and the cross-lane reduction is amortised over twice the data), and walk down the
-// tile's rows in chunks of 8 (16 buffer loads = 16 KB in flight per wave; descriptor + one loop-invariant
-// lane offset + scalar row offset, no 64-bit vector address arithmetic):
-//   * column part: per-lane register accumulators acc_col[P][VN] over the whole tile (panel
-//     values x_I are wave-uniform scalar loads);
-//   * row part: per-lane products a[r]*x_J (x_J held in registers for the tile), folded across
-//     the 64 lanes by an eager transposing tree (half-exchange swaps first), then added into an LDS
-//     accumulator rowacc[1024][P] (ds_add_f64; 48 KB for P=6);
-//   * tile results go to partial buffers  rowP[J][c][i]  /  colP[I][c][j]  (one slot per column slab /
-//     row tile) and a fold kernel adds, for every output element, exactly the slots that exist:
-//        y[c][n] = sum_{J >= 2*(n>>10)} rowP[J][c][n] + sum_{I <= n>>10} colP[I][c][n].
-//   Tiles crossing the diagonal mask the strictly-lower elements (and count the diagonal once); each of
-//   their waves stops at its own last column.  Lanes past the last column of a ragged matrix read through
-//   an out-of-range offset (hardware returns zeros).
+// Mapping (round 3).  Tiles of TRH = 1024 rows x SLAB columns (1024 fp64 / 2048 fp32) on/above the
+// diagonal.  One 256-thread block owns a RUN of up to L consecutive tiles of one row tile (same rows,
+// adjacent column slabs); its 4 waves own 4 x WCOLS columns of the current slab (lane: two 16 B vectors,
+// so every load instruction is a contiguous 1 KB) and walk down rows in chunks of 8 through a ring of
+// 8 rows per wave (16 buffer loads = 16 KB always in flight: descriptor + loop-invariant lane offset +
+// scalar row/column offset, no 64-bit vector address arithmetic).  The ring never drains inside a run:
+// the last chunk of a row range refills it with the first rows of the wave's next range, which may
+// belong to the next tile.
+//   * column part: per-lane register accumulators acc_col[NU][P] over the tile (panel values x_I are
+//     wave-uniform scalar loads), flushed once per tile to the column partials colP[I][c][j];
+//   * row part: per-lane products a[r]*x_J, folded across the 64 lanes by an eager transposing tree
+//     (half-exchange swaps, then DPP partner exchanges), then added into an LDS accumulator
+//     rowacc[1024][P] that lives for the whole run: one row partial rowP[slot][c][i] per RUN.
+//   * DETERMINISTIC accumulation (round 3): the four waves never add into the same accumulator rows at
+//     the same time.  A tile is processed in four phases separated by block barriers; in phase q wave w
+//     works on row quarter (w + q) mod 4, so every accumulator entry receives its four waves'
+//     contributions in a fixed order (phase order) and every wave's own contributions in program
+//     order.  Two runs of the same launch give bit-identical results (round 2 let the LDS float atomics
+//     of the four waves race).  `s_barrier` does not drain vector memory (the ring stays in flight).
+//   * a fold kernel adds, for every output element, exactly the partial slots that exist, in fixed order:
+//        y[c][n] = sum_{slot < runs(n>>10)} rowP[slot][c][n] + sum_{I <= Imax(n)} colP[I][c][n].
+//   Quarters that reach the diagonal mask the strictly-lower elements (and count the diagonal once);
+//   a wave skips quarters that lie entirely below its columns.  Lanes past the last column of a ragged
+//   matrix read through an out-of-range offset (the hardware bounds check returns zeros).
 //
-// Register budget (fp64, P=6): 203 VGPRs -> 2 waves per SIMD; the panel/accumulator registers (96) cannot be
-// shared between waves, so the third wave (<=168 VGPRs) is out of reach and the chunk depth is what keeps
-// enough bytes in flight.
+// Register budget (fp64, P=6): ~200 VGPRs -> 2 waves per SIMD; the panel/accumulator registers (96)
+// cannot be shared between waves, so a third wave (<=168 VGPRs) is out of reach and the ring depth is
+// what keeps enough bytes in flight.
 //
-// What was measured (fp64, P = 6, N = 16384, half batch of 32 per launch):
-//   alone on the GPU — this kernel 5.60-5.76 ms; the same with the chunk's 16 loads issued up front instead of
-//     the rolling ring 5.58-5.74; the first version (4-row chunks, per-lane 64-bit addresses, generic
-//     reduction, 188 VGPRs) 5.53-5.70;
-//   inside the eigensolver's two-group pipeline, i.e. sharing HBM and CUs with the other group's small kernels
-//     — ring 6.03-6.12 ms (222-225 ms per symeig call), loads-up-front 6.32-6.41 (232-235), first version
-//     6.78 (248.5).  The ring keeps 12-16 KB per wave in flight at all times and is what holds the request
-//     stream up under contention, so it is the shipped form although it wins nothing in isolation.
-//   tile orders other than row-tile-major (XCD-contiguous runs, batch-fastest, short-tiles-first, slab-major,
-//     member pairs interleaved): 0-7 % slower; balancing the diagonal tiles across waves: 1 % slower.
-//
-// Traffic per launch: B*N^2*s/2 (+2 % for the crossing tiles) + 2 * B*(NS+NT)*P*N*s of partials
-// (2.5 %) — vs B*N^2*s for the general kernel.
+// Traffic per launch: B*N^2*s/2 (+2 % for the diagonal tiles) + B*(NT + NS/L)*P*N*s of partials written
+// and read once — vs B*N^2*s for the general kernel.
 #include "xk_common.h"
 
 namespace xk {
 
 constexpr int SYMM_TRH = 1024;   // rows per tile
+constexpr int SYMM_QR = 256;     // rows per quarter (phase granularity of the deterministic accumulation)
+constexpr int SYMM_NU = 2;       // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
+constexpr int SYMM_R = 8;        // rows per chunk == ring depth
 
-#ifndef XK_SYMM_NU
-#define XK_SYMM_NU 2
-#endif
-#ifndef XK_SYMM_WPE
-#define XK_SYMM_WPE 2
-#endif
-#ifndef XK_SYMM_EARLY
-#define XK_SYMM_EARLY 1
-#endif
-constexpr int SYMM_NU = XK_SYMM_NU;      // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
-
-// The operator tile is read through a buffer descriptor (base = first row of the tile, wave-uniform):
-// every load is  descriptor + per-lane column offset (one VGPR, loop-invariant) + scalar row offset,
-// so the streaming loop carries no 64-bit VGPR address arithmetic.  aux = 2: non-temporal.
+// The operator rows of a run are read through ONE buffer descriptor (base = first row of the row tile,
+// wave-uniform): every load is  descriptor + per-lane column offset (one VGPR, loop-invariant) + scalar
+// (row, slab) offset.  aux = 2: non-temporal (the operator is touched once per product).
 typedef __amdgpu_buffer_rsrc_t TileRsrc;
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+constexpr unsigned SYMM_OOR = 0x7ffffff0u;     // beyond any descriptor range: returns zeros, moves no data
 
 template <typename VT>
-__device__ __forceinline__ VT ld_tile(const TileRsrc rsrc, unsigned lane_off, unsigned row_off) {
-  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)row_off, 2);
+__device__ __forceinline__ VT ld_tile(const TileRsrc rsrc, unsigned lane_off, unsigned s_off) {
+  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)s_off, 2);
   return __builtin_bit_cast(VT, raw);
 }
 
@@ -80,34 +69,49 @@ __device__ __forceinline__ TileRsrc make_tile_rsrc(const T* tile_base, long byte
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   void* base = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
-  const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xffffffffL ? 0xffffffffL : bytes));
+  const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0x7fffffe0L ? 0x7fffffe0L : bytes));
   return __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)nrec, 0x00020000);
 }
 
+// Where the ring is refilled from while a chunk is consumed (everything wave-uniform but `loff`):
+// the chunk one ring depth ahead in the wave's sequence — usually the next 8 rows of the same range,
+// at the end of a range the first rows of the wave's next range (next phase, or next tile of the run).
+struct SymmNext {
+  int row;          // first row of that chunk (absolute)
+  int last;         // last row of its range: rows past it re-read this one (masked when consumed)
+  int col0;         // first column of its tile
+  int diag;         // its range reaches the diagonal: lanes strictly below the row fetch nothing
+};
+
 // ---------------------------------------------------------------------------------------------
-// 8-row chunk (16 loads = 16 KB in flight per wave).  At 188+ VGPRs the kernel runs 2 waves per
-// SIMD whatever the chunk size, so the only way to keep more bytes in flight is a deeper chunk; the
-// row sums are folded EAGERLY so that the 48 partial sums never coexist:
+// 8-row chunk.  The row sums are folded EAGERLY so that the 48 partial sums never coexist:
 //   rows (2h, 2h+1)  -> half-exchange over lane bit 5      (6 values per row pair)
 //   row pairs        -> half-exchange over lane bit 4      (6 values per 4 rows)
-//   the two 4-groups -> select + xor-8 shuffle             (6 values per 8 rows)
-//   panel columns    -> (even P) select + xor-4 shuffle, then xor-2 / xor-1 butterflies
+//   the two 4-groups -> select + xor-8 exchange            (6 values per 8 rows)
+//   panel columns    -> (even P) select + xor-4 exchange, then xor-2 / xor-1 butterflies
 // afterwards lane l holds, for row r = 4*bit3 + 2*bit4 + bit5 of the chunk, the complete sums of
-// columns c = 2w + bit2 (w < P/2); lanes with bits 1,0 clear add them into the LDS accumulator.
+// columns c = 2w + bit2 (w < P/2); lanes with bits 1,0 clear add them into the LDS accumulator
+// (ds_add_f64/f32: a single wave owns these accumulator rows during the phase, see above).
+// DIAG: the chunk's rows reach the wave's columns (mask strictly-lower elements, diagonal once).
+// TAIL: the chunk is the ragged end of its range (rows >= i_end are masked).
 // ---------------------------------------------------------------------------------------------
-constexpr int SYMM_R = 8;       // rows per chunk
-
-template <typename T, int P, bool CROSSING, bool TAIL>
+template <typename T, int P, bool DIAG, bool TAIL>
 __device__ __forceinline__ void symm_chunk8(
-    typename Vec16<T>::type (&a)[SYMM_R][SYMM_NU], const TileRsrc Ab, const T* __restrict__ Xb, unsigned lda,
-    long ldx, int N, int i0, int i_end,
-    const int (&jj)[SYMM_NU], const unsigned (&joff)[SYMM_NU], int row_tile0,
+    typename Vec16<T>::type (&a)[SYMM_R][SYMM_NU], const TileRsrc Ab, const T* __restrict__ Xb, unsigned ldab,
+    long ldx, int i0, int i_end, int row_tile0, int col0, int N, const int (&jj)[SYMM_NU], const SymmNext nx,
     typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
     T* rowacc, int lane) {
   typedef typename Vec16<T>::type VT;
   constexpr int VN = Vec16<T>::n;
   constexpr int R = SYMM_R, NU = SYMM_NU;
   const int i_last = i_end - 1;
+  const unsigned ncoloff = (unsigned)nx.col0 * (unsigned)sizeof(T);
+  // per-lane byte offset inside a row of the successor's tile; lanes past the last column of a ragged matrix get
+  // an offset beyond the descriptor's range (the hardware bounds check returns zeros: no branch, no select later)
+  unsigned nloff[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    nloff[u] = (jj[u] - col0 + nx.col0 < N) ? (unsigned)(jj[u] - col0) * (unsigned)sizeof(T) : SYMM_OOR;
   T L2[2][P];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -135,7 +139,7 @@ __device__ __forceinline__ void symm_chunk8(
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
           VT ar = a[r][u], ac = a[r][u];
-          if (CROSSING) {
+          if (DIAG) {
 #pragma unroll
             for (int v = 0; v < VN; ++v) {
               if (jj[u] + v < row) { ar[v] = T(0); ac[v] = T(0); }
@@ -165,20 +169,21 @@ __device__ __forceinline__ void symm_chunk8(
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int c = 0; c < P; ++c) asm volatile("" : "+v"(acc_col[u][c]));
-      // rolling prefetch: the two rows just consumed are refilled with the rows 8 further down, so the wave
-      // always has ~6 row pairs of loads in flight while it computes (rows past the end re-read the last one)
-      if (!TAIL) {
+      // rolling prefetch: the two rows just consumed are refilled with the rows one ring depth ahead in the
+      // wave's sequence, so the wave always has ~6 row pairs of loads in flight while it computes.  Issued on
+      // every path (a range without successor refills through the out-of-range offset: no data moves), so the
+      // compiler's vmcnt bookkeeping stays exact.
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          int row = i0 + R + 4 * g + 2 * h + q;
-          row = row < i_last ? row : i_last;
+      for (int q = 0; q < 2; ++q) {
+        int row = nx.row + 4 * g + 2 * h + q;
+        row = row < nx.last ? row : nx.last;
+        const unsigned soff = (unsigned)(row - row_tile0) * ldab + ncoloff;
+        // (diagonal ranges: a lane whose columns all lie strictly below the row fetches nothing — its values
+        //  would be masked to zero anyway; the out-of-range offset returns the zeros without the traffic)
+        const int thr = nx.diag ? row - nx.col0 - (VN - 1) + col0 : -0x40000000;
 #pragma unroll
-          for (int u = 0; u < NU; ++u)
-            // (crossing tiles: a lane whose columns all lie strictly below the row fetches nothing — its values
-            //  would be masked to zero anyway; the out-of-range offset returns the zeros without the traffic)
-            a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, (!CROSSING || jj[u] + VN - 1 >= row) ? joff[u] : 0x7ffffff0u,
-                                                  (unsigned)(row - row_tile0) * lda);
-        }
+        for (int u = 0; u < NU; ++u)
+          a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
       }
       __builtin_amdgcn_sched_barrier(0);      // keep the row pairs in program order (bounded live ranges)
     }
@@ -235,171 +240,262 @@ __device__ __forceinline__ void symm_chunk8(
   }
 }
 
-template <typename T, int P, bool CROSSING>
-__device__ __forceinline__ void symm_tile_rows(
-    const TileRsrc Ab, const T* __restrict__ Xb, unsigned lda, long ldx, int N, int i_begin, int i_end,
-    const int (&jj)[SYMM_NU], const unsigned (&joff)[SYMM_NU], int row_tile0,
-    typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
-    T* rowacc, int lane) {
-  typedef typename Vec16<T>::type VT;
-  const bool any = i_begin < i_end;          // (wave-uniform) a wave right of a crossing tile's diagonal has no rows
-  const int full_end = i_begin + ((i_end - i_begin) / SYMM_R) * SYMM_R;
-  const int i_last = i_end - 1;
-  VT a[SYMM_R][SYMM_NU];                     // ring of 8 rows, refilled pair by pair inside the chunks
-  // (unconditional: a branch around the fill would leave the compiler without the order of the outstanding loads at
-  // the loop head and turn every wait of the ring into vmcnt(0); a wave without rows re-reads the tile's first row)
-#pragma unroll
-  for (int r = 0; r < SYMM_R; ++r) {
-    int row = i_begin + r;
-    row = row < i_last ? row : i_last;
-    row = row > row_tile0 ? row : row_tile0;
-#pragma unroll
-    for (int u = 0; u < SYMM_NU; ++u)
-      a[r][u] = ld_tile<VT>(Ab, (!CROSSING || jj[u] + Vec16<T>::n - 1 >= row) ? joff[u] : 0x7ffffff0u,
-                            (unsigned)(row - row_tile0) * lda);
-  }
-  // the block's LDS set-up runs UNDER the first 16 KB of loads (they do not depend on it): every wave passes
-  // here exactly once, whichever of the two instantiations it took
-#if XK_SYMM_EARLY
-  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
-  __syncthreads();
-#endif
-  if (!any) return;
-  for (int i0 = i_begin; i0 < full_end; i0 += SYMM_R)
-    symm_chunk8<T, P, CROSSING, false>(a, Ab, Xb, lda, ldx, N, i0, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
-  if (full_end < i_end)
-    symm_chunk8<T, P, CROSSING, true>(a, Ab, Xb, lda, ldx, N, full_end, i_end, jj, joff, row_tile0, acc_col, xJ, rowacc, lane);
+// The geometry of one run as seen by one wave (all wave-uniform).
+struct SymmRun {
+  int row0;         // first row of the row tile
+  int tile_end;     // one past its last row (ragged last tile: N)
+  int J0;           // first column slab of the run
+  int ntile;        // slabs in the run
+  int N;
+  int wave;
+  int sig;          // the wave's quarter in phase q is q ^ sig (a bijection wave -> quarter in every phase)
+};
+
+// Rows [rb, re) wave `wave` handles in phase q of tile j of the run, and whether they reach the diagonal.
+template <typename T>
+__device__ __forceinline__ bool symm_range(const SymmRun& run, int j, int q, int& rb, int& re, int& col0, int& diag) {
+  constexpr int VN = Vec16<T>::n;
+  constexpr int WCOLS = SYMM_NU * 64 * VN, SLAB = 4 * WCOLS;
+  col0 = (run.J0 + j) * SLAB;
+  const int wc0 = col0 + run.wave * WCOLS, wc1 = wc0 + WCOLS;
+  // rows that can hold an element on/above the diagonal for this wave: row <= its last column
+  int wend = run.tile_end < wc1 ? run.tile_end : wc1;
+  if (wc0 >= run.N) wend = run.row0;                       // ragged last slab: the wave has no columns
+  const int k = q ^ run.sig;
+  rb = run.row0 + k * SYMM_QR;
+  re = rb + SYMM_QR;
+  re = re < wend ? re : wend;
+  diag = (re - 1 >= wc0) ? 1 : 0;
+  return rb < re;
 }
 
-template <typename T, int P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XK_SYMM_WPE))) void dense_symm_tiles(
-    const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int ntiles,
-    int N, long lda, long sA, long ldx, long sX, int NS, int NT, int flags) {
-  typedef typename Vec16<T>::type VT;
-  constexpr int VN = Vec16<T>::n;
-  constexpr int NU = SYMM_NU;
-  constexpr int WCOLS = NU * 64 * VN;          // columns per wave
-  constexpr int SLAB = 4 * WCOLS;              // columns per block
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
-  // tile list in row-tile-major order: row tile I owns the column slabs J >= (I*TRH)/SLAB
-  int b = blockIdx.x / ntiles;
-  int I = 0, J = 0;
-  {
-    int rem = blockIdx.x - b * ntiles;
-    for (;; ++I) {
-      const int jmin = (I * SYMM_TRH) / SLAB;
-      const int cnt = NS - jmin;
-      if (rem < cnt) { J = jmin + rem; break; }
-      rem -= cnt;
+// first non-empty range after (j, q) in the wave's sequence; nx.row < 0 when there is none
+template <typename T>
+__device__ __forceinline__ SymmNext symm_next_range(const SymmRun& run, int j, int q) {
+  SymmNext nx;
+  nx.row = -1; nx.last = 0; nx.col0 = 0; nx.diag = 0;
+#pragma unroll 1
+  for (int s = 0; s < 8; ++s) {
+    if (++q == 4) { q = 0; ++j; }
+    if (j >= run.ntile) break;
+    int rb, re, c0, dg;
+    if (symm_range<T>(run, j, q, rb, re, c0, dg)) {
+      nx.row = rb; nx.last = re - 1; nx.col0 = c0; nx.diag = dg;
+      break;
     }
   }
-  // the integer divisions above run on the vector ALU: pin their (wave-uniform) results in SGPRs so that
-  // everything derived from them (row pointers, loop bounds, panel addresses) is scalar arithmetic
-  b = __builtin_amdgcn_readfirstlane(b);
-  I = __builtin_amdgcn_readfirstlane(I);
-  J = __builtin_amdgcn_readfirstlane(J);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar row pointers
-  const int row0 = I * SYMM_TRH;
-  const int col0 = J * SLAB;
-  int jj[NU];
-  unsigned joff[NU];
-  bool colok[NU];
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    jj[u] = col0 + wave * WCOLS + u * 64 * VN + lane * VN;      // each load instruction: 1 KB contiguous
-    colok[u] = jj[u] < N;
-    // lanes past the last column get a byte offset beyond the descriptor's range: the hardware bounds
-    // check returns zeros for them (no branch, no select), so they add nothing to either sum
-    joff[u] = colok[u] ? (unsigned)jj[u] * (unsigned)sizeof(T) : 0x7ffffff0u;
+  return nx;
+}
+
+template <typename T, int P, bool DIAG>
+__device__ __forceinline__ void symm_rows(
+    typename Vec16<T>::type (&a)[SYMM_R][SYMM_NU], const TileRsrc Ab, const T* __restrict__ Xb, unsigned ldab,
+    long ldx, int rb, int re, int row_tile0, int col0, int N, const int (&jj)[SYMM_NU], const SymmNext after,
+    typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
+    T* rowacc, int lane) {
+  const int nfull = (re - rb) / SYMM_R;
+  const bool tail = ((re - rb) % SYMM_R) != 0;
+  int i0 = rb;
+  for (int c = 0; c < nfull; ++c, i0 += SYMM_R) {
+    // the successor of a chunk lies in this same range, except for the last chunk of the range: there the ring
+    // moves on to the wave's next range (scalar selects; the chunk's loads are the same on both paths)
+    const bool last = !tail && c == nfull - 1;
+    SymmNext nx;
+    nx.row = last ? after.row : i0 + SYMM_R;
+    nx.last = last ? after.last : re - 1;
+    nx.col0 = last ? after.col0 : col0;
+    nx.diag = last ? after.diag : (DIAG ? 1 : 0);
+    symm_chunk8<T, P, DIAG, false>(a, Ab, Xb, ldab, ldx, i0, re, row_tile0, col0, N, jj, nx, acc_col, xJ, rowacc,
+                                   lane);
   }
-  const T* Ab = A + (long)b * sA;
-  const T* Xb = X + (long)b * sX;
-#if !XK_SYMM_EARLY      /* A/B only: LDS set-up and barrier before the first load is issued */
-  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
-  __syncthreads();
-#endif
-  // rows of this tile that can hold an element on/above the diagonal: i <= last column of the slab
-  int i_end = row0 + SYMM_TRH;
-  const int col_last = col0 + SLAB - 1;
-  if (i_end > col_last + 1) i_end = col_last + 1;
-  if (i_end > N) i_end = N;
-  const bool crossing = (i_end - 1 >= col0);   // some row index reaches the first column: mask needed
-  const int tile_rows = (row0 + SYMM_TRH <= N ? SYMM_TRH : N - row0);
-  const unsigned ldab = (unsigned)(lda * (long)sizeof(T));
-  const TileRsrc tile = make_tile_rsrc(Ab + (long)row0 * lda, (long)tile_rows * lda * (long)sizeof(T));
-  VT acc_col[NU][P], xJ[NU][P];
+  if (tail)
+    symm_chunk8<T, P, DIAG, true>(a, Ab, Xb, ldab, ldx, i0, re, row_tile0, col0, N, jj, after, acc_col, xJ, rowacc,
+                                  lane);
+}
+
+// per-tile set-up of one wave: absolute columns of its lanes, zeroed column sums, the panel values x_J of its columns
+template <typename T, int P>
+__device__ __forceinline__ void symm_tile_setup(const T* __restrict__ Xb, int ldx, int col0, int N,
+                                                const int (&lanecol)[SYMM_NU], int (&jj)[SYMM_NU],
+                                                typename Vec16<T>::type (&acc_col)[SYMM_NU][P],
+                                                typename Vec16<T>::type (&xJ)[SYMM_NU][P]) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
 #pragma unroll
-  for (int u = 0; u < NU; ++u)
+  for (int u = 0; u < SYMM_NU; ++u) {
+    jj[u] = col0 + lanecol[u];
 #pragma unroll
     for (int c = 0; c < P; ++c) {
 #pragma unroll
       for (int v = 0; v < VN; ++v) acc_col[u][c][v] = T(0);
-      if (colok[u]) {
+      if (jj[u] < N) {
         xJ[u][c] = *reinterpret_cast<const VT*>(Xb + (long)c * ldx + jj[u]);
       } else {
 #pragma unroll
         for (int v = 0; v < VN; ++v) xJ[u][c][v] = T(0);
       }
     }
-  if (crossing) {
-    // rows below this WAVE's last column hold only strictly-lower elements for it: stop there
-    int w_end = col0 + (wave + 1) * WCOLS;
-    w_end = w_end < i_end ? w_end : i_end;
-    symm_tile_rows<T, P, true>(tile, Xb, ldab, ldx, N, row0, w_end, jj, joff, row0, acc_col, xJ, rowacc, lane);
   }
-  else
-    symm_tile_rows<T, P, false>(tile, Xb, ldab, ldx, N, row0, i_end, jj, joff, row0, acc_col, xJ, rowacc, lane);
-#if defined(XK_SYMM_EXP) && XK_SYMM_EXP >= 1      /* experiment (wrong results): no end barrier, no row flush */
-  if (rowacc[threadIdx.x] == T(12345.678)) rowP[threadIdx.x] = T(1);
-#else
+  // Drain here, once per tile: the x_J loads above (and the previous tile's column-partial stores) are YOUNGER than
+  // the ring loads already in flight for this tile's first rows.  Left pending, the wait for x_J at the head of the
+  // chunk loop would be vmcnt(0) on every iteration (the compiler's counts are per program point, it cannot peel
+  // the first one) and drain the whole ring once per chunk.  vmcnt(0), expcnt/lgkmcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+template <typename T, int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
+    const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int nruns,
+    int N, long lda, long sA, long ldx, long sX, int NS, int NT, int NSL, int L, int flags) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int NU = SYMM_NU;
+  constexpr int WCOLS = NU * 64 * VN;          // columns per wave
+  constexpr int SLAB = 4 * WCOLS;              // columns per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
+  // run list in row-tile-major order: row tile I owns the slabs J >= (I*TRH)/SLAB, cut into runs of L
+  int b = blockIdx.x / nruns;
+  int I = 0, slot = 0, jmin = 0, cnt = 0;
+  {
+    int rem = blockIdx.x - b * nruns;
+    for (;; ++I) {
+      jmin = (I * SYMM_TRH) / SLAB;
+      cnt = NS - jmin;
+      const int nr = (cnt + L - 1) / L;
+      if (rem < nr) { slot = rem; break; }
+      rem -= nr;
+    }
+  }
+  // the integer divisions above run on the vector ALU: pin their (wave-uniform) results in SGPRs so that
+  // everything derived from them (row offsets, loop bounds, panel addresses) is scalar arithmetic
+  b = __builtin_amdgcn_readfirstlane(b);
+  I = __builtin_amdgcn_readfirstlane(I);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  jmin = __builtin_amdgcn_readfirstlane(jmin);
+  cnt = __builtin_amdgcn_readfirstlane(cnt);
+  const int lane = threadIdx.x & 63;
+  SymmRun run;
+  run.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+  run.row0 = I * SYMM_TRH;
+  run.tile_end = run.row0 + SYMM_TRH <= N ? run.row0 + SYMM_TRH : N;
+  run.J0 = jmin + slot * L;
+  run.ntile = (cnt - slot * L) < L ? (cnt - slot * L) : L;
+  run.N = N;
+  // phase -> quarter map q ^ sig: sig = wave when a wave's columns span one quarter of rows (fp64); with two quarters
+  // per wave (fp32) waves 1 and 2 swap, so that both quarters of a wave's diagonal block come in phases 0 and 1
+  run.sig = (WCOLS == SYMM_QR) ? run.wave : ((run.wave & 1) << 1 | (run.wave >> 1));
+  const int wave = run.wave;
+  int lanecol[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) lanecol[u] = wave * WCOLS + u * 64 * VN + lane * VN;   // 1 KB contiguous per load
+  const T* Ab = A + (long)b * sA;
+  const T* Xb = X + (long)b * sX;
+  const unsigned ldab = (unsigned)(lda * (long)sizeof(T));
+  const TileRsrc tile = make_tile_rsrc(Ab + (long)run.row0 * lda,
+                                       (long)(run.tile_end - run.row0) * lda * (long)sizeof(T));
+  // ---- ring fill: the first rows of the wave's first range (unconditional: a wave without any range fills
+  // through the out-of-range offset) — issued BEFORE the LDS set-up so that the set-up runs under the loads
+  VT a[SYMM_R][NU];
+  {
+    SymmNext first = symm_next_range<T>(run, 0, -1);
+    const int ncols = first.row >= 0 ? N : 0;          // no range at all: every lane fills through the OOR offset
+    if (first.row < 0) { first.row = run.row0; first.last = run.row0; }
+    unsigned floff[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      floff[u] = (first.col0 + lanecol[u] < ncols) ? (unsigned)lanecol[u] * (unsigned)sizeof(T) : SYMM_OOR;
+#pragma unroll
+    for (int r = 0; r < SYMM_R; ++r) {
+      int row = first.row + r;
+      row = row < first.last ? row : first.last;
+      const unsigned soff = (unsigned)(row - run.row0) * ldab + (unsigned)first.col0 * (unsigned)sizeof(T);
+      const int thr = first.diag ? row - first.col0 - (VN - 1) : -0x40000000;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) a[r][u] = ld_tile<VT>(tile, lanecol[u] >= thr ? floff[u] : SYMM_OOR, soff);
+    }
+  }
+  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
   __syncthreads();
-  // flush: row partial slot J (rows of this tile), column partial slot I (columns of this slab)
-  T* rp = rowP + (((long)b * NS + J) * P) * (long)N;
-  const int nrows = (row0 + SYMM_TRH <= N ? SYMM_TRH : N - row0);
-  if (flags & 1) {
-    for (int idx = threadIdx.x; idx < nrows * P; idx += 256) {
-      const int c = idx / nrows, lr = idx - c * nrows;
-      __builtin_nontemporal_store(rowacc[lr * P + c], &rp[(long)c * N + row0 + lr]);
-    }
-  } else {
-    for (int idx = threadIdx.x; idx < nrows * P; idx += 256) {
-      const int c = idx / nrows, lr = idx - c * nrows;
-      rp[(long)c * N + row0 + lr] = rowacc[lr * P + c];
+
+  VT acc_col[NU][P], xJ[NU][P];
+  int jj[NU];
+  int col0 = run.J0 * SLAB;
+  symm_tile_setup<T, P>(Xb, (int)ldx, col0, N, lanecol, jj, acc_col, xJ);
+  int q = 0;
+  if (slot == 0) {
+    // The first tile of a row tile's first run reaches the diagonal.  With the phase -> quarter map above every
+    // range that needs the diagonal masks lies in the first WCOLS/QR phases of that tile: they run here, on the
+    // masked instantiation (all four waves, whatever their own range needs), so the loop below is mask-free.
+#pragma unroll 1
+    for (; q < WCOLS / SYMM_QR; ++q) {
+      int rb, re, c0, dg;
+      if (symm_range<T>(run, 0, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T>(run, 0, q);
+        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = 0x20000000; }
+        symm_rows<T, P, true>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
+                              rowacc, lane);
+      }
+      __syncthreads();
     }
   }
-#endif
-  T* cp = colP + (((long)b * NT + I) * P) * (long)N;
-#if defined(XK_SYMM_EXP) && XK_SYMM_EXP >= 2      /* experiment: no column flush either (all sums kept alive) */
-  T chk = T(0);
-#pragma unroll
-  for (int u = 0; u < NU; ++u)
-#pragma unroll
-    for (int c = 0; c < P; ++c)
-#pragma unroll
-      for (int v = 0; v < VN; ++v) chk += acc_col[u][c][v];
-  const bool doflush = (chk == T(12345.678));
-#else
-  const bool doflush = true;
-#endif
-#pragma unroll
-  for (int u = 0; u < NU; ++u)
-    if (colok[u] && doflush) {
-      if (flags & 1) {
-#pragma unroll
-        for (int c = 0; c < P; ++c) __builtin_nontemporal_store(acc_col[u][c], reinterpret_cast<VT*>(cp + (long)c * N + jj[u]));
-      } else {
-#pragma unroll
-        for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(cp + (long)c * N + jj[u]) = acc_col[u][c];
+  int j = 0;
+#pragma unroll 1
+  for (;;) {
+#pragma unroll 1
+    for (; q < 4; ++q) {
+      int rb, re, c0, dg;
+      if (symm_range<T>(run, j, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T>(run, j, q);
+        // no successor (end of the run for this wave): refill through the out-of-range offset (col0 = "past N":
+        // every lane is beyond the last column), so that every chunk issues the same loads
+        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = 0x20000000; }
+        symm_rows<T, P, false>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
+                               rowacc, lane);
       }
+      __syncthreads();        // s_waitcnt lgkmcnt(0) + s_barrier: the ring's loads stay in flight
     }
+    // column partial slot I (columns of this slab)
+    T* cp = colP + (((long)b * NT + I) * P) * (long)N;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (jj[u] < N) {
+        if (flags & 1) {
+#pragma unroll
+          for (int c = 0; c < P; ++c) __builtin_nontemporal_store(acc_col[u][c], reinterpret_cast<VT*>(cp + (long)c * N + jj[u]));
+        } else {
+#pragma unroll
+          for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(cp + (long)c * N + jj[u]) = acc_col[u][c];
+        }
+      }
+    if (++j >= run.ntile) break;
+    q = 0;
+    col0 = (run.J0 + j) * SLAB;
+    symm_tile_setup<T, P>(Xb, (int)ldx, col0, N, lanecol, jj, acc_col, xJ);
+  }
+  {
+    // the run's row sums of quarter 3 ^ sig are complete: the other three waves added theirs in the earlier
+    // phases (barriers), this wave just added the last ones (LDS operations of one wave execute in order).
+    // Row partial slot `slot` of this row tile.
+    const int k3 = 3 ^ run.sig;
+    const int fb = run.row0 + k3 * SYMM_QR;
+    int fe = fb + SYMM_QR;
+    fe = fe < run.tile_end ? fe : run.tile_end;
+    const int nr = fe - fb;
+    T* rp = rowP + (((long)b * NSL + slot) * P) * (long)N;
+    for (int idx = lane; idx < nr * P; idx += 64) {
+      const int c = idx / nr, lr = idx - c * nr;
+      const T v = rowacc[(fb - run.row0 + lr) * P + c];
+      if (flags & 1) __builtin_nontemporal_store(v, &rp[(long)c * N + fb + lr]);
+      else rp[(long)c * N + fb + lr] = v;
+    }
+  }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, const T* __restrict__ colP,
-                                                  T* __restrict__ Y, int N, int P, int NS, int NT, int slab,
-                                                  long ldy, long sY, long total, int flags) {
+                                                  T* __restrict__ Y, int N, int P, int NS, int NT, int NSL, int L,
+                                                  int slab, long ldy, long sY, long total, int flags) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*P*N
   if (idx >= total) return;
   const long per_b = (long)P * N;
@@ -408,60 +504,50 @@ __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, con
   const int c = (int)(rem / N);
   const int n = (int)(rem - (long)c * N);
   const int It = n / SYMM_TRH;                 // row tile of n
-  const int Jfirst = (It * SYMM_TRH) / slab;   // first column slab that owns a tile with row tile It
+  const int jmin = (It * SYMM_TRH) / slab;     // first column slab that owns a tile with row tile It
+  const int nslot = (NS - jmin + L - 1) / L;   // runs (= row partial slots) of that row tile
   T s = T(0);
   const int Imax = ((n / slab) * slab + slab - 1) / SYMM_TRH;   // row tiles I with I*TRH <= last column of n's slab
   if (flags & 2) {                                              // the partials are read exactly once
-    for (int J = Jfirst; J < NS; ++J) s += __builtin_nontemporal_load(&rowP[(((long)b * NS + J) * P + c) * (long)N + n]);
+    for (int r = 0; r < nslot; ++r) s += __builtin_nontemporal_load(&rowP[(((long)b * NSL + r) * P + c) * (long)N + n]);
     for (int I = 0; I <= Imax && I < NT; ++I)
       s += __builtin_nontemporal_load(&colP[(((long)b * NT + I) * P + c) * (long)N + n]);
   } else {
-    for (int J = Jfirst; J < NS; ++J) s += rowP[(((long)b * NS + J) * P + c) * (long)N + n];
+    for (int r = 0; r < nslot; ++r) s += rowP[(((long)b * NSL + r) * P + c) * (long)N + n];
     for (int I = 0; I <= Imax && I < NT; ++I) s += colP[(((long)b * NT + I) * P + c) * (long)N + n];
   }
   Y[b * sY + (long)c * ldy + n] = s;
 }
 
-// K1s2 (xk_symm2.hip): the same contract with the row part on the matrix cores
-template <typename T>
-int symm2_launch(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P, long lda, long sA,
-                 long ldx, long sX, long ldy, long sY, void* stream, int phase);
-long symm2_workspace_elems(int B, int N, int P, int elem_size);
-
-// bit 0: the row / column partials leave with non-temporal stores, bit 1: the fold reads them with non-temporal
-// loads (they are written once and read once, 6 ms apart: keeping them out of L2's way is worth 1.2 % of the call,
-// same-process A/B scripts/symm_flags_ab.py); 0 restores plain stores / loads for that A/B
-static int g_symm_flags = 3;
-static int g_symm_variant = 1;     // 1: per-lane rows + wave reductions (this file), 2: LDS turn + MFMA row part
+// Tuning state (process-wide; written only through xk_dense_symm_tune, a measurement hook):
+//   [0] bit 0: the row / column partials leave with non-temporal stores, bit 1: the fold reads them with
+//       non-temporal loads (written once, read once, milliseconds apart: keeping them out of L2's way was worth
+//       1.2 % of the eigensolver call in round 2);
+//   [1] L: column slabs per run (row partials per row tile = ceil(slabs / L)).
+static int g_symm_tune[2] = {3, 1};
 
 }  // namespace xk
 
 extern "C" {
 
-// which implementation serves xk_dense_symm_* (both read only the upper triangle and share the workspace
-// contract); returns the previous setting.  Kept for A/B measurements (bench.py --k1s-variant).
-// A/B switch for the non-temporal handling of the partials (see g_symm_flags); returns the previous value
-int xk_dense_symm_set_flags(int f) {
-  const int old = xk::g_symm_flags;
-  xk::g_symm_flags = f;
+// measurement hook: set tuning value `what` (0: non-temporal flags, 1: slabs per run), return the previous one.
+// Results do not depend on either (the run length changes the summation order of the row partials — still a
+// fixed order).  Not meant to be flipped while launches are being issued from other threads.
+int xk_dense_symm_tune(int what, int value) {
+  if (what < 0 || what > 1) return XK_ERR_ARG;
+  const int old = xk::g_symm_tune[what];
+  if (what == 0 && value >= 0 && value <= 3) xk::g_symm_tune[0] = value;
+  if (what == 1 && value >= 1 && value <= 64) xk::g_symm_tune[1] = value;
   return old;
 }
 
-int xk_dense_symm_set_variant(int v) {
-  const int old = xk::g_symm_variant;
-  if (v == 1 || v == 2) xk::g_symm_variant = v;
-  return old;
-}
-
-// workspace (elements): row partials (B, NS, P, N) + column partials (B, NT, P, N), the larger of the variants
+// workspace (elements): row partials (B, NS, P, N) + column partials (B, NT, P, N) — sized for runs of one slab
 long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
   const int vn = 16 / elem_size;
   const long slab = 256L * vn * xk::SYMM_NU;
   const long NS = (N + slab - 1) / slab, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;
   const long pc = P > 6 ? 6 : P;
-  const long v1 = (long)B * (NS + NT) * pc * N;
-  const long v2 = xk::symm2_workspace_elems(B, N, P, elem_size);
-  return v1 > v2 ? v1 : v2;
+  return (long)B * (NS + NT) * pc * N;
 }
 
 #define XK_DEFINE_SYMM(SUF, T)                                                                              \
@@ -471,26 +557,27 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
     if (B < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                                         \
     if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
     if (phase != 0 && P > 6) return XK_ERR_UNSUPPORTED;   /* split phases: one column chunk only */         \
-    if (xk::g_symm_variant == 2)                                                                            \
-      return xk::symm2_launch<T>(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, stream, phase); \
     constexpr int VN = xk::Vec16<T>::n;                                                                     \
     constexpr int SLAB = 256 * VN * xk::SYMM_NU;                                                            \
     if ((N % VN) || (lda % VN) || (sA % VN) || (ldx % VN) || (sX % VN) || ((uintptr_t)A & 15) ||             \
         ((uintptr_t)X & 15) || ((uintptr_t)ws & 15))                                                        \
       return XK_ERR_UNSUPPORTED;                                                                            \
+    if ((long)xk::SYMM_TRH * lda * (long)sizeof(T) > 0x7fffffe0L) return XK_ERR_UNSUPPORTED;               \
     hipStream_t st = (hipStream_t)stream;                                                                   \
+    const int L = xk::g_symm_tune[1], fl = xk::g_symm_tune[0];                                              \
     const int NS = (N + SLAB - 1) / SLAB, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;                       \
-    int nt = 0;                                                                                             \
-    for (int I = 0; I < NT; ++I) nt += NS - (I * xk::SYMM_TRH) / SLAB;                                      \
+    const int NSL = (NS + L - 1) / L;                                                                       \
+    int nruns = 0;                                                                                          \
+    for (int I = 0; I < NT; ++I) nruns += (NS - (I * xk::SYMM_TRH) / SLAB + L - 1) / L;                     \
     int c0 = 0;                                                                                             \
     while (c0 < P) {                                                                                        \
       const int pc = (P - c0) >= 6 ? 6 : (P - c0);                                                          \
-      const long nrow = (long)B * NS * pc * N, ncol = (long)B * NT * pc * N;                                \
+      const long nrow = (long)B * NSL * pc * N, ncol = (long)B * NT * pc * N;                               \
       if (ws_elems < nrow + ncol) return XK_ERR_ARG;                                                        \
       T* rowP = ws;                                                                                         \
       T* colP = ws + nrow;                                                                                  \
       const size_t lds = (size_t)xk::SYMM_TRH * pc * sizeof(T);                                             \
-      const dim3 grid((unsigned)((long)B * nt));                                                            \
+      const dim3 grid((unsigned)((long)B * nruns));                                                         \
       const T* Xc = X + (long)c0 * ldx;                                                                     \
       if (phase != 2) {                                                                                     \
         switch (pc) {                                                                                       \
@@ -501,8 +588,8 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
       if (phase != 1) {                                                                                     \
         const long total = (long)B * pc * N;                                                                \
         hipLaunchKernelGGL((xk::symm_fold<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,     \
-                           rowP, colP, Y + (long)c0 * ldy, N, pc, NS, NT, SLAB, ldy, sY, total,             \
-                           xk::g_symm_flags);                                                               \
+                           rowP, colP, Y + (long)c0 * ldy, N, pc, NS, NT, NSL, L, SLAB, ldy, sY, total,     \
+                           fl);                                                                             \
         XK_LAUNCH_CHECK();                                                                                  \
       }                                                                                                     \
       c0 += pc;                                                                                             \
@@ -526,8 +613,8 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
 
 #define XK_SYMM_CASE(PP)                                                                                  \
   case PP:                                                                                                \
-    hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP>), grid, dim3(256), lds, st, A, Xc, rowP, colP, nt,   \
-                       N, lda, sA, ldx, sX, NS, NT, xk::g_symm_flags);                                    \
+    hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP>), grid, dim3(256), lds, st, A, Xc, rowP, colP,       \
+                       nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl);                                   \
     break;
 
 #define TT double
