@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       int rb, re, c0, dg;
       if (symm_range<T>(run, 0, q, rb, re, c0, dg)) {
         SymmNext after = symm_next_range<T>(run, 0, q);
-        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = 0x20000000; }
+        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
         symm_rows<T, P, true>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
                               rowacc, lane);
       }
@@ -447,9 +447,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       int rb, re, c0, dg;
       if (symm_range<T>(run, j, q, rb, re, c0, dg)) {
         SymmNext after = symm_next_range<T>(run, j, q);
-        // no successor (end of the run for this wave): refill through the out-of-range offset (col0 = "past N":
-        // every lane is beyond the last column), so that every chunk issues the same loads
-        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = 0x20000000; }
+        // no successor (end of the run for this wave): refill through the out-of-range offset (a tile starting at
+        // column N: every lane is beyond the last column), so that every chunk issues the same loads
+        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
         symm_rows<T, P, false>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
                                rowacc, lane);
       }
