@@ -281,6 +281,30 @@ int xk_kry_status_f64(const double* Prr, const double* stop, double* rnorm, doub
 int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double* status, int S, int nblk,
                       void* stream);
 
+/* ---- GMRES: per-system Hessenberg / Givens state on the device (xitorch/_impls/linalg/solve.py:326-433) ----------
+ * The reference fills one Hessenberg column per iteration by modified Gram-Schmidt (:390-394) and solves the
+ * (k+1) x k least-squares problem from scratch with torch.linalg.lstsq (:403) on every pass of its Python loop.
+ * Here the S = batch x columns systems keep their state on the device, always in double:
+ *   R  (S, cap+1, cap) row-major per system: the rotated (triangularised) Hessenberg, R[i][j] meaningful for i <= j
+ *   cs, sn (S, cap): Givens rotations;  g (S, cap+1): rotated right-hand side, g[:,0] = |r0| set by the caller.
+ * xk_gmres_step: column k from the two Gram passes of the CGS2 orthogonalisation — c1[s, 0..k] = <q_j, w>,
+ *   c2n[s, 0..k] = <q_j, w1> with w1 = w - Q c1 and c2n[s, k+1] = <w1, w1> (strides sc1 / sc2 between systems) —
+ *   h[j,k] = c1 + c2, h[k+1,k] = sqrt(<w1,w1> - |c2|^2); replays rotations 0..k-1, creates rotation k, updates g;
+ *   inv_hn[s] = 1 / h[k+1,k] (0 on breakdown); est2[s * xk_kry_max_partials()] = g[k+1]^2, i.e. a one-partial |r|^2
+ *   array for xk_kry_status: the least-squares residual norm, equal to :414-415's explicit one in exact arithmetic.
+ * xk_gmres_finish: basis row k+1 (holding w1) <- (w1 - sum_{j<=k} c2n[j] q_j) * inv_hn   (:392,396-398).
+ * xk_gmres_solve: y[s, 0..kd) = R^-1 g (back substitution; zero pivots give 0) — what :403 returns; kd <= 8192. */
+int xk_gmres_step_f64(const double* c1, long sc1, const double* c2n, long sc2, int k, int cap, double* R, double* cs,
+                      double* sn, double* g, double* inv_hn, double* est2, int S, void* stream);
+int xk_gmres_step_f32(const float* c1, long sc1, const float* c2n, long sc2, int k, int cap, double* R, double* cs,
+                      double* sn, double* g, float* inv_hn, float* est2, int S, void* stream);
+int xk_gmres_finish_f64(double* Q, const double* c2n, long sc2, const double* inv_hn, int S, int N, int k, long ldq,
+                        long sQ, void* stream);
+int xk_gmres_finish_f32(float* Q, const float* c2n, long sc2, const float* inv_hn, int S, int N, int k, long ldq,
+                        long sQ, void* stream);
+int xk_gmres_solve_f64(const double* R, const double* g, double* y, long sy, int S, int kd, int cap, void* stream);
+int xk_gmres_solve_f32(const double* R, const double* g, float* y, long sy, int S, int kd, int cap, void* stream);
+
 /* ---- the same fused Krylov kernels for COMPLEX systems (complex64 = _c64, complex128 = _c128) ----------
  * The reference runs cg / bicgstab on complex operators with conjugated inner products
  * (xitorch/_impls/linalg/solve.py:441-445; _tests/test_linop_fcns.py:474-524, 631-676).  Pointers address

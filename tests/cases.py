@@ -93,6 +93,15 @@ SOLVE_CASES = [
          ncols=1, kwargs=dict(rtol=1e-10, atol=1e-12, posdef=True)),
     dict(name="gmres_nonsym60", method="gmres", op="dense", hermitian=False, n=60, batch=(2,), ncols=2,
          kwargs=dict(rtol=1e-8, posdef=True, max_niter=60)),
+    # gmres with a shift: the reference handles one column only (its column-swapped layout breaks for more) and
+    # returns that layout (ncols, *batch, n, 1) without undoing the swap (solve.py:349-432): `gold_swapped`
+    dict(name="gmres_nonsym_AE", method="gmres", op="dense", hermitian=False, n=50, batch=(2,), ncols=1, E=True,
+         gold_swapped=True, kwargs=dict(rtol=1e-8, posdef=True, max_niter=50)),
+    dict(name="gmres_nonsym_AEM", method="gmres", op="dense", hermitian=False, n=50, batch=(2,), ncols=1, E=True,
+         M=True, gold_swapped=True, kwargs=dict(rtol=1e-8, posdef=True, max_niter=50)),
+    # not converging within max_niter: ConvergenceWarning + the best-residual iterate is returned (:417-432)
+    dict(name="gmres_nonconv60", method="gmres", op="dense", hermitian=False, n=60, batch=(2,), ncols=2,
+         nonconv=True, kwargs=dict(rtol=1e-12, posdef=True, max_niter=6)),
     dict(name="cg_sym_AEM", method="cg", op="dense", hermitian=True, n=80, batch=(2,), ncols=3, E=True, M=True,
          kwargs=dict(rtol=1e-8, posdef=True)),
     dict(name="bicgstab_nonsym_AE", method="bicgstab", op="dense", hermitian=False, n=80, batch=(2,), ncols=3,
@@ -158,6 +167,27 @@ def solve_inputs(case):
         R2 = torch.rand((*batch, n, n), dtype=f64, generator=g)
         M = 0.05 * (R2 + R2.transpose(-2, -1)) * 0.5 + torch.eye(n, dtype=f64)
     return A, B, E, M
+
+
+def solve_kappa(case, A, E, M):
+    """2-norm condition number of the operator the Krylov loop works on — A - E_c M per column (worst over batch
+    and columns), its normal-equation form A^H A when the loop needs a Hermitian operator and A is not
+    (solve.py:607-612,637-643) — the factor between a residual tolerance and the solution error."""
+    if case["op"] == "banded":
+        from oracle import ops as oops
+        A = oops.BandedOp(A).fullmatrix()
+    n = A.shape[-1]
+    worst = 0.0
+    ncols = E.shape[-1] if E is not None else 1
+    for c in range(ncols):
+        op = A
+        if E is not None:
+            Mm = M if M is not None else torch.eye(n, dtype=A.dtype)
+            op = A - E[..., c].unsqueeze(-1).unsqueeze(-1) * Mm
+        if case["method"] == "cg" and not case["hermitian"]:
+            op = op.transpose(-2, -1).conj() @ op
+        worst = max(worst, float(torch.linalg.cond(op).max()))
+    return worst
 
 
 def solve_precond(case, A):

@@ -43,6 +43,16 @@ def exact(a, b, what):
         raise SystemExit("oracle != reference for %s (max abs diff %.3e)" % (what, err))
 
 
+def close(a, b, what, rel=1e-13):
+    """gmres only: both sides call torch.linalg.lstsq every iteration (solve.py:403), whose CPU kernel is not
+    bit-reproducible between two calls on identical inputs (the last bit follows the alignment of its work buffers:
+    probed, the SAME function gives different last bits in two calls of one process).  The oracle is therefore pinned
+    to 1e-13 of the reference there instead of bit for bit; every other method stays torch.equal."""
+    err = (a - b).abs().max().item()
+    if not err <= rel * max(1.0, a.abs().max().item()):
+        raise SystemExit("oracle != reference for %s (max abs diff %.3e)" % (what, err))
+
+
 class CountingRefOp(xitorch.LinearOperator):
     """Reference-side wrapper that counts applies (to pin iteration counts)."""
 
@@ -103,8 +113,10 @@ def gen_davidson():
         resid = (torch.matmul(mat, X_r) - MX * ev_r.unsqueeze(-2)).abs().max()
         # store evecs only through a sign-free, small summary: |X|^T at a few probe rows
         probe = cases.probe_rows(mat.shape[-1])
+        # (round 3) the reference's eigenvectors themselves: the GPU tests compare subspaces,
+        # sigma_min(X_ref^T M X) >= 1 - 1e-8; signs are never compared (quirk Q15)
         save("davidson_" + name, evals=ev_r, evals_exact=ev_x, napply=rop.n, niter=tr["niter"],
-             max_resid=resid, absX_probe=X_r.abs()[..., probe, :], probe=probe)
+             max_resid=resid, absX_probe=X_r.abs()[..., probe, :], probe=probe, X=X_r)
 
 
 # --------------------------------------------------------------------------- solve
@@ -135,10 +147,23 @@ def gen_solve():
             X_r = fr(rA, B, E, rM, **kw_r)
             tr = {}
             X_o = fo(oA, B, E, oM, trace=tr, **kw_o)
-        exact(X_r, X_o, name)
+        (close if case["method"] == "gmres" else exact)(X_r, X_o, name)
         assert oA.n_apply == rA.n, (name, oA.n_apply, rA.n)
-        X_x = osolve.exactsolve(oA, B, E, oM) if case["method"] != "gmres" or E is None else X_r
-        save("solve_" + name, X=X_r, X_exact=X_x, napply=rA.n, niter=tr["niter"], converged=tr["converged"])
+        assert bool(tr["converged"]) != bool(case.get("nonconv")), (name, tr)
+        X_x = osolve.exactsolve(oA, B, E, oM)
+        if case.get("gold_swapped"):
+            # the reference's gmres hands back its column-swapped work layout (ncols, *batch, n, 1)
+            assert X_r.shape == (B.shape[-1], *B.shape[:-2], B.shape[-2], 1), X_r.shape
+        # (round 3) kappa: condition number of the iterated operator, the factor between the residual tolerance
+        # and the solution error the GPU tests allow against X
+        X_store = X_r
+        if case["method"] == "gmres":
+            # the reference's own output moves in its last bits from run to run here (lstsq, see close()): the
+            # fixture keeps 12 decimals, so that regenerating it gives the same file (barring a value that sits on
+            # a rounding boundary); the GPU tests compare at 1e-8 * kappa
+            X_store = torch.round(X_r * 1e12) / 1e12
+        save("solve_" + name, X=X_store, X_exact=X_x, napply=rA.n, niter=tr["niter"], converged=tr["converged"],
+             kappa=cases.solve_kappa(case, A, E, M))
 
 
 # --------------------------------------------------------------------------- rootfinder

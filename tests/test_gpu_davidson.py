@@ -42,10 +42,17 @@ def test_davidson_vs_golden_and_oracle(dev, case):
     evals, evecs = evals.cpu().numpy(), evecs.cpu().numpy()
     assert evals.shape == gold["evals"].shape
     _check_pairs(mat, evals, evecs, gold["evals"], case["min_eps"], gold["evals_exact"], Mmat)
-    # same iteration path as the reference: same start block, same algorithm -> same count (+-2 for
-    # rounding-level differences in the stopping test)
-    assert abs(tr["niter"] - int(gold["niter"])) <= 2, (tr["niter"], int(gold["niter"]))
-    # subspace parity: |X| at probe rows matches the reference's eigenvectors up to sign
+    # same iteration path as the reference: same start block, same algorithm -> same count (one more or less only
+    # where max|resid| sits within rounding of min_eps when the reference stops)
+    assert abs(tr["niter"] - int(gold["niter"])) <= 1, (tr["niter"], int(gold["niter"]))
+    # subspace parity with the reference's own eigenvectors: sigma_min(X_ref^T M X) >= 1 - 1e-8, i.e. the
+    # two invariant subspaces coincide to 1e-4 rad; signs / rotations inside the subspace are free (quirk Q15)
+    Xr = torch.from_numpy(gold["X"])
+    Xm = torch.from_numpy(evecs)
+    MX = torch.matmul(Mmat, Xm) if Mmat is not None else Xm
+    sig = torch.linalg.svdvals(torch.matmul(Xr.transpose(-2, -1), MX))
+    assert sig.min().item() >= 1.0 - 1e-8 and sig.max().item() <= 1.0 + 1e-8, (sig.min().item(), sig.max().item())
+    # ... and entrywise up to sign where the wanted eigenvalues are separated
     probe = [int(i) for i in gold["probe"]]
     sep_ok = np.abs(np.diff(gold["evals"], axis=-1)).min() > 1e-6 if gold["evals"].shape[-1] > 1 else True
     if sep_ok:

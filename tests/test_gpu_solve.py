@@ -48,29 +48,46 @@ def test_krylov_vs_golden_and_oracle(dev, case):
     pre = {k: xa.LinearOperator.m(P.to(dev), is_hermitian=True) for k, P in cases.solve_precond(case, A).items()} \
         if case["op"] != "banded" else {}
     tr = {}
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")                   # a ConvergenceWarning would be a failure here
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
         X = fcn(Aop, B.to(dev), E.to(dev) if E is not None else None, Mop, trace=tr, **case["kwargs"], **pre)
+    nconv = [w for w in wlist if issubclass(w.category, xa.ConvergenceWarning)]
+    # a ConvergenceWarning is a failure, except in the case that pins the non-converging path (best iterate returned)
+    assert bool(nconv) == bool(case.get("nonconv")), [str(w.message) for w in wlist]
     X = X.cpu()
-    assert list(X.shape) == list(gold["X"].shape)
+    Xg, Xe = torch.from_numpy(gold["X"]), torch.from_numpy(gold["X_exact"])
+    if case.get("gold_swapped"):
+        # the reference's gmres returns its column-swapped work layout (ncols, *batch, n, 1) when E is given
+        # (solve.py:349-432 never undoes it); the native method returns (*batch, n, ncols) like every other method
+        Xg = Xg.squeeze(-1).movedim(0, -1)
+    assert list(X.shape) == list(Xg.shape) == list(Xe.shape)
+    kw = case["kwargs"]
+    rtol, atol = kw.get("rtol", 1e-6), kw.get("atol", 1e-8)
+    if case.get("nonconv"):
+        # the best-residual iterate of the truncated iteration: same Krylov space, same minimiser as the reference's
+        assert (X - Xg).norm().item() <= 1e-9 * float(gold["kappa"]) * Xg.norm().item()
+        assert not tr["converged"] and tr["niter"] == int(gold["niter"])
+        return
     # (1) the residual identity the reference tests assert (test_linop_fcns.py:467-468, 674-676)
     oM = oops.DenseOp(M, True) if M is not None else None
     AX = oA.mm(X)
     if E is not None:
         AX = AX - (oM.mm(X) if oM is not None else X) * E.unsqueeze(-2)
-    kw = case["kwargs"]
-    rtol, atol = kw.get("rtol", 1e-6), kw.get("atol", 1e-8)
     if case["name"].startswith("cg_nonsym"):
         pass      # normal equations: the stopping test is on A^T(AX - B); checked through X below
     else:
         lim = torch.clamp(rtol * B.norm(dim=-2), min=atol)
         assert torch.all((AX - B).norm(dim=-2) <= lim * 1.001)
-    # (2) against the reference's own output and the dense solution
-    Xg, Xe = torch.from_numpy(gold["X"]), torch.from_numpy(gold["X_exact"])
-    scale = Xe.abs().max().item()
-    assert (X - Xe).abs().max().item() <= max(1e-6, (Xg - Xe).abs().max().item() * 50) * scale
-    # (3) same iteration path as the reference (identical algorithm, rounding-level differences only)
-    assert abs(tr["niter"] - int(gold["niter"])) <= 2, (tr["niter"], int(gold["niter"]))
+    # (2) against the reference's OWN output: both iterates satisfy |r| <= rtol |b|, so they lie within
+    # 2 rtol kappa of each other, kappa = condition number of the iterated operator (from the fixture)
+    kappa = float(gold["kappa"])
+    assert (X - Xg).norm().item() <= 2.0 * rtol * kappa * Xg.norm().item(), \
+        ((X - Xg).norm().item() / Xg.norm().item(), rtol, kappa)
+    #     ... and the dense solution
+    assert (X - Xe).norm().item() <= 2.0 * rtol * kappa * Xe.norm().item()
+    # (3) same iteration path as the reference (identical algorithm, rounding-level differences only): the count
+    # may move by one where a residual norm sits within rounding of the threshold
+    assert abs(tr["niter"] - int(gold["niter"])) <= 1, (tr["niter"], int(gold["niter"]))
     assert tr["converged"]
 
 
@@ -191,3 +208,49 @@ def test_many_rhs_nonhermitian_goes_through_the_mfma_kernel(dev):
     op32.apply(X32, o32)
     r32 = torch.matmul(A32.double(), B32.double()).transpose(-2, -1)
     assert (o32.double() - r32).abs().max().item() <= 3e-5 * r32.abs().max().item()
+
+
+def test_gmres_device_state_semantics(dev):
+    """Native GMRES (reference: solve.py:326-433): iterates checked on TRUE residuals; with resid_calc_every > 1 the
+    same solution at fewer applies; one host read per iteration; many columns with per-column shifts E (which the
+    reference cannot do: its swapped layout breaks for ncols > 1); float32; breakdown of a system whose Krylov space
+    is exhausted early."""
+    g = torch.Generator().manual_seed(5)
+    n, nc = 96, 3
+    R = torch.rand(2, n, n, dtype=torch.float64, generator=g)
+    Amat = 0.1 * R + torch.eye(n, dtype=torch.float64)
+    Bm = torch.rand(2, n, nc, dtype=torch.float64, generator=g)
+    E = torch.rand(2, nc, dtype=torch.float64, generator=g) * 0.3
+    A = xa.LinearOperator.m(Amat.to(dev), is_hermitian=False)
+    ref = torch.linalg.solve(Amat, Bm)
+    tr1, tr5 = {}, {}
+    X1 = nk.gmres(A, Bm.to(dev), rtol=1e-10, atol=1e-12, posdef=True, trace=tr1).cpu()
+    X5 = nk.gmres(A, Bm.to(dev), rtol=1e-10, atol=1e-12, posdef=True, resid_calc_every=5, trace=tr5).cpu()
+    for X in (X1, X5):
+        assert ((Amat @ X - Bm).norm(dim=-2) <= 1e-10 * Bm.norm(dim=-2) * 1.001).all()
+        assert (X - ref).norm().item() <= 1e-8 * ref.norm().item()
+    assert tr1["converged"] and tr5["converged"]
+    assert tr5["arnoldi_steps"] in (tr1["arnoldi_steps"], tr1["arnoldi_steps"] + 1)
+    assert tr5["napply"] < tr1["napply"]
+    # one read of the status per iteration (+1 for the initial residual, +1 when the estimate triggers the check)
+    assert tr1["host_syncs"] == tr1["arnoldi_steps"] + 1
+    assert tr5["host_syncs"] <= tr5["arnoldi_steps"] + 3
+    # per-column shifts with several columns
+    XE = nk.gmres(A, Bm.to(dev), E.to(dev), rtol=1e-10, atol=1e-12, posdef=True).cpu()
+    for c in range(nc):
+        Ac = Amat - E[:, c].reshape(2, 1, 1) * torch.eye(n, dtype=torch.float64)
+        xc = torch.linalg.solve(Ac, Bm[..., c:c + 1])
+        assert (XE[..., c:c + 1] - xc).norm().item() <= 1e-8 * xc.norm().item()
+    # float32
+    A32 = xa.LinearOperator.m(Amat.float().to(dev), is_hermitian=False)
+    X32 = nk.gmres(A32, Bm.float().to(dev), rtol=1e-4, atol=1e-6, posdef=True).cpu().double()
+    assert (X32 - ref).norm().item() <= 1e-3 * ref.norm().item()
+    # a system whose Krylov space is exhausted after one step (b is an eigenvector) next to generic ones: the
+    # reference divides by h[k+1,k] = 0 there (NaN); here that system simply stays converged
+    D = torch.diag(torch.linspace(1.0, 2.0, n, dtype=torch.float64)).unsqueeze(0).repeat(2, 1, 1)
+    Bd = torch.rand(2, n, 1, dtype=torch.float64, generator=g)
+    Bd[0] = 0.0
+    Bd[0, 3, 0] = 1.0
+    Xd = nk.gmres(xa.LinearOperator.m(D.to(dev), is_hermitian=False), Bd.to(dev), rtol=1e-10, posdef=True).cpu()
+    assert torch.isfinite(Xd).all()
+    assert (D @ Xd - Bd).norm().item() <= 1e-9

@@ -42,8 +42,10 @@ def test_oracle_solve(case):
     pre = {k: oops.DenseOp(P, True) for k, P in cases.solve_precond(case, A).items()} if case["op"] != "banded" else {}
     tr = {}
     with warnings.catch_warnings():
-        warnings.simplefilter("error")
+        # a ConvergenceWarning is a failure, except in the case that pins the non-converging path
+        warnings.simplefilter("ignore" if case.get("nonconv") else "error")
         X = getattr(osolve, case["method"])(oA, B, E, oM, trace=tr, **case["kwargs"], **pre)
+    assert bool(tr["converged"]) == bool(gold["converged"]) == (not case.get("nonconv"))
     assert np.abs(X.numpy() - gold["X"]).max() <= 1e-9 * max(1.0, np.abs(gold["X"]).max())
     assert abs(tr["niter"] - int(gold["niter"])) <= 1
 

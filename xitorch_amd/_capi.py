@@ -96,6 +96,10 @@ def _declare(L):
         sigs["xk_kry_status_" + sfx] = (I, [P] * 4 + [I, I, P])
         sigs["xk_banded_grad_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
         sigs["xk_dense_outer_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, P])
+    for sfx in ("f64", "f32"):
+        sigs["xk_gmres_step_" + sfx] = (I, [P, Lg, P, Lg, I, I, P, P, P, P, P, P, I, P])
+        sigs["xk_gmres_finish_" + sfx] = (I, [P, P, Lg, P, I, I, I, Lg, Lg, P])
+        sigs["xk_gmres_solve_" + sfx] = (I, [P, P, P, Lg, I, I, I, P])
     for sfx in ("c64", "c128"):
         sigs["xk_kry_dots_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, I, P])
         sigs["xk_bicg_p_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])

@@ -509,16 +509,47 @@ def cg(A, B, E=None, M=None, posdef=None, precond=None, max_niter=None, rtol=1e-
 
 
 # ------------------------------------------------------------------------------- GMRES
-def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-8, eps=1e-12,
-          process_group=None, trace=None, **unused):
-    r"""
-    Solve the linear equations using the Generalised minimal residual method on HIP kernels.
+class _GmresState:
+    """Per-system Hessenberg / Givens state on the device (float64 whatever the vector dtype), growing with the basis
+    (the reference preallocates max_niter vectors and a (max_niter+1) x max_niter Hessenberg, solve.py:384-386, Q12)."""
 
-    The Krylov basis of every system is kept panel-major on the device and grows by one vector
-    per iteration (the reference preallocates ``max_niter`` vectors, solve.py:384, Q12);
-    orthogonalisation is classical Gram–Schmidt applied twice through the K1 / xk_lincomb
-    kernels; the small Hessenberg least-squares problems are updated with Givens rotations, whose
-    residual estimate drives the same stopping rule; the true residual is verified once at the end.
+    def __init__(self, S, cap, device):
+        self.S, self.cap, self.device = S, cap, device
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=device)
+        self.R, self.cs, self.sn, self.g = z(S, cap + 1, cap), z(S, cap), z(S, cap), z(S, cap + 1)
+
+    def grow(self, need, limit):
+        if need <= self.cap:
+            return
+        new = min(limit, max(need, 2 * self.cap))
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=self.device)
+        R, cs, sn, g = z(self.S, new + 1, new), z(self.S, new), z(self.S, new), z(self.S, new + 1)
+        R[:, :self.cap + 1, :self.cap] = self.R
+        cs[:, :self.cap], sn[:, :self.cap], g[:, :self.cap + 1] = self.cs, self.sn, self.g
+        self.R, self.cs, self.sn, self.g, self.cap = R, cs, sn, g, new
+
+
+def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-8, eps=1e-12,
+          resid_calc_every=1, process_group=None, trace=None, **unused):
+    r"""
+    Solve the linear equations using the Generalised minimal residual method on HIP kernels
+    (reference: gmres, xitorch/_impls/linalg/solve.py:326-433; real operators only, like the reference's).
+
+    Same iterates, same stopping rule and same return value as the reference: un-restarted GMRES from ``x0 = 0``;
+    after ``k`` Arnoldi steps the iterate ``x_k`` minimises the residual over the ``k``-dimensional Krylov space; the
+    TRUE residual ``B - (A x_k - M x_k E)`` decides convergence (``all(|r_col| < max(rtol |b_col|, atol))``) and
+    which iterate is the best one (smallest maximum residual norm over all batches and columns, solve.py:414-425);
+    the best iterate is returned, with a ``ConvergenceWarning`` when the tolerance was not reached.  Like the
+    reference's loop (``for k in range(min(nr, max_niter))`` solving with the first ``k`` columns, :389,403-410) at most
+    ``min(nr, max_niter) - 1`` Krylov vectors contribute.
+
+    How it runs here: the Krylov basis of every system is kept panel-major on the device and grows by one vector per
+    iteration; the new direction is orthogonalised by classical Gram-Schmidt applied twice (two Gram products on
+    the K1 kernel, ``xk_lincomb`` / ``xk_gmres_finish`` — the reference's modified Gram-Schmidt, :391-393, is a
+    sequential chain of k dot / axpy pairs); the Hessenberg column, its Givens rotations and the rotated right-hand
+    side live on the device (``xk_gmres_step``), so the least-squares problem the reference hands to
+    ``torch.linalg.lstsq`` every iteration (:403) is one back substitution (``xk_gmres_solve``); its residual
+    ``|g[k+1]|`` equals the true residual norm in exact arithmetic.  One host read per iteration.
 
     Keyword arguments
     -----------------
@@ -530,6 +561,18 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
         Relative / absolute tolerance of the stopping condition w.r.t. the norm of B
     eps: float
         Replacement of exact zeros in denominators
+    resid_calc_every: int
+        (extension) ``1`` (default): the iterate and its true residual are formed every iteration, exactly like the
+        reference.  ``n > 1``: only every n-th iteration, on the last one, and whenever the least-squares estimate
+        says that every system has converged (one more operator apply and one pass over the basis saved per skipped
+        iteration; stopping decisions are still taken on true residuals only, best-iterate tracking sees the
+        checked iterates).
+    process_group: torch.distributed group or None
+        (extension) batch-sharded multi-GPU run: the stopping test is all-reduced over the group
+
+    With ``E`` the reference returns its column-swapped work layout ``(ncols, *batch, nr, 1)`` without undoing the
+    swap (:432, and fails for more than one column); this function returns ``(*batch, nr, ncols)`` like every other
+    method.
     """
     nr, ncols = A.shape[-1], B.shape[-1]
     if A.dtype.is_complex:
@@ -537,103 +580,108 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
         raise NativeLibraryError("xitorch_amd gmres supports real operators only, like the reference's gmres")
     if max_niter is None:
         max_niter = int(nr)
-    max_niter = min(max_niter, nr)
     bdims = get_batchdims(A, B, E, M)
     # (sharded runs: every rank takes this shortcut or none does — the loop below contains collectives)
     if all_ranks_agree_true(torch.allclose(B, B * 0, rtol=rtol, atol=atol), B.device, process_group):
         return _zeros_like_solution(A, B, bdims)
     prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=False)
+    kr = _Kry(prob)
     S, N, ld = prob.S, prob.N, prob.ld
     dtype, dev = prob.dtype, prob.device
-    stop = _stop_vector(prob, rtol, atol).double().cpu()
-    r = prob.rhs.reshape(S, 1, ld)
-    beta = r.norm(dim=-1).reshape(S)
-    cap = min(max_niter + 1, 32)
-    Q = torch.zeros((S, cap, ld), dtype=dtype, device=dev)
-    Q[:, 0] = (r / torch.where(beta == 0, torch.full_like(beta, eps), beta).reshape(S, 1, 1))[:, 0]
-    w = torch.zeros((S, 1, ld), dtype=dtype, device=dev)
-    # host-side Givens state per system; grows with the basis (the default max_niter = N would otherwise ask for
-    # S*(N+1)*N doubles up front — the reference preallocates likewise, solve.py:384, quirk Q12)
-    hcap = cap
-    H = torch.zeros((S, hcap + 1, hcap), dtype=torch.float64)
-    cs = torch.zeros((S, hcap), dtype=torch.float64)
-    sn = torch.zeros((S, hcap), dtype=torch.float64)
-    g = torch.zeros((S, hcap + 1), dtype=torch.float64)
-    g[:, 0] = beta.double().cpu()
+    sfx = suffix(dtype)
+    stop = _stop_vector(prob, rtol, atol)
+    every = max(1, int(resid_calc_every))
+    msteps = min(nr, max_niter) - 1           # Arnoldi steps whose column enters an iterate (solve.py:389,403)
+    rhs = prob.rhs.reshape(S, ld)
+    beta = rhs.norm(dim=-1)                                                      # (S,)
+    best = float(allreduce_max_(beta.max().double().reshape(1), process_group).item())      # solve.py:380-381
+    xbufs = [torch.zeros((S, 1, ld), dtype=dtype, device=dev) for _ in range(2)]
+    best_i, cur_i = 0, 1                      # xbufs[0] = x0 = 0 is the best iterate so far (:382)
     converged = False
-    niter = 0
-    kdim = 0
-    est = g[:, 0].abs()
-    for k in range(max_niter):
-        niter = k + 1
-        if k + 2 > cap:                                           # grow the basis storage
-            newcap = min(max_niter + 1, 2 * cap)
-            Qn = torch.zeros((S, newcap, ld), dtype=dtype, device=dev)
-            Qn[:, :cap].copy_(Q)
-            Q, cap = Qn, newcap
-        if k + 1 > hcap:                                          # grow the host-side Hessenberg state
-            nh = min(max_niter, 2 * hcap)
-            Hn = torch.zeros((S, nh + 1, nh), dtype=torch.float64)
-            Hn[:, :hcap + 1, :hcap] = H
-            csn, snn, gn = (torch.zeros((S, nh), dtype=torch.float64), torch.zeros((S, nh), dtype=torch.float64),
-                            torch.zeros((S, nh + 1), dtype=torch.float64))
-            csn[:, :hcap], snn[:, :hcap], gn[:, :hcap + 1] = cs, sn, g
-            H, cs, sn, g, hcap = Hn, csn, snn, gn, nh
-        prob.apply(Q[:, k].reshape(prob.Bt, prob.nc, ld), w.reshape(prob.Bt, prob.nc, ld))
-        hcol = torch.zeros((S, k + 1), dtype=dtype, device=dev)
-        for _ in range(2):                                        # CGS2
-            c = K.dense_mm(Q[:, :k + 1, :N], w[:, :, :N])          # (S, 1, k+1): <q_j, w>
-            K.lincomb(Q, c, w, k + 1, 1, coef_layout="ca", alpha=-1.0, beta=1.0)
-            hcol += c[:, 0]
-        hn = w.norm(dim=-1).reshape(S)
-        Q[:, k + 1] = (w / torch.where(hn == 0, torch.full_like(hn, 1.0), hn).reshape(S, 1, 1))[:, 0]
-        col = torch.cat([hcol.double(), hn.double().unsqueeze(-1)], dim=-1).cpu()      # host sync
-        # apply the previous rotations, create the new one (per system, vectorised over S)
-        for j in range(k):
-            a, b2 = col[:, j].clone(), col[:, j + 1].clone()
-            col[:, j] = cs[:, j] * a + sn[:, j] * b2
-            col[:, j + 1] = -sn[:, j] * a + cs[:, j] * b2
-        a, b2 = col[:, k], col[:, k + 1]
-        den = torch.sqrt(a * a + b2 * b2)
-        den = torch.where(den == 0, torch.ones_like(den), den)
-        cs[:, k], sn[:, k] = a / den, b2 / den
-        col[:, k] = cs[:, k] * a + sn[:, k] * b2
-        col[:, k + 1] = 0.0
-        H[:, :k + 2, k] = col
-        g[:, k + 1] = -sn[:, k] * g[:, k]
-        g[:, k] = cs[:, k] * g[:, k]
-        kdim = k + 1
-        est = g[:, k + 1].abs()
-        flags = torch.tensor([float(est.max()), float((~(est < stop)).sum())], dtype=torch.float64)
-        if process_group is not None:
-            flags = allreduce_max_(flags.to(dev), process_group).cpu()
-        if flags[1] == 0:
-            converged = True
-            break
-    # back substitution R y = g on the host, x = Q y on the device
-    ycoef = torch.zeros((S, kdim), dtype=torch.float64)
-    for i in range(kdim - 1, -1, -1):
-        acc = g[:, i].clone()
-        for j in range(i + 1, kdim):
-            acc -= H[:, i, j] * ycoef[:, j]
-        d = H[:, i, i]
-        ycoef[:, i] = acc / torch.where(d == 0, torch.full_like(d, eps), d)
-    x = torch.zeros((S, 1, ld), dtype=dtype, device=dev)
-    yc = ycoef.to(dtype).to(dev).unsqueeze(1).contiguous()          # (S, 1, kdim): "ca" layout
-    K.lincomb(Q, yc, x, kdim, 1, coef_layout="ca", alpha=1.0, beta=0.0)
-    xs = x.reshape(prob.Bt, prob.nc, ld)
-    # true residual (reference computes it every iteration, solve.py:414)
-    tmp = prob.new()
-    prob.apply(xs, tmp)
-    rn = (prob.rhs - tmp).norm(dim=-1).reshape(-1).double().cpu()
-    best = float(rn.max())
-    converged = converged and bool(torch.all(rn < stop * (1 + 1e-6) + 1e-300))
+    nsteps, nsync = 0, 1
+    if msteps > 0:
+        cap = min(msteps + 1, 32)
+        Q = torch.zeros((S, cap, ld), dtype=dtype, device=dev)
+        Q[:, 0] = rhs / torch.where(beta == 0, torch.full_like(beta, eps), beta).unsqueeze(-1)   # :385, _safedenom
+        st = _GmresState(S, cap - 1, dev)
+        st.g[:, 0] = beta.double()
+        inv_hn = torch.zeros((S,), dtype=dtype, device=dev)
+        Pest, Ptrue = kr.partial_real(), kr.partial_real()
+        ycoef = torch.zeros((S, 1, cap), dtype=dtype, device=dev)
+        status4 = torch.zeros((4,), dtype=torch.float64, device=dev)
+        tmp = prob.new()
+        rtrue = prob.new()
+
+        def status_of(Prr, nblk, slot):
+            check(fn("xk_kry_status_" + kr.rsfx)(ptr(Prr), ptr(stop), ptr(kr.rnorm), ptr(status4[2 * slot:]), S, nblk,
+                                                 stream_ptr()), "xk_kry_status")
+
+        def true_residual(kd):
+            """x = Q y with R y = g (the reference's lstsq solution, :403-410), r = B - A x (:414): partials -> Ptrue"""
+            check(fn("xk_gmres_solve_" + sfx)(ptr(st.R), ptr(st.g), ptr(ycoef), ycoef.stride(0), S, kd, st.cap,
+                                              stream_ptr()), "xk_gmres_solve")
+            x = xbufs[cur_i]
+            K.lincomb(Q, ycoef, x, kd, 1, coef_layout="ca", alpha=1.0, beta=0.0)
+            prob.apply(x.reshape(prob.Bt, prob.nc, ld), tmp)
+            kr.resid(prob.rhs, tmp, rtrue, None, Ptrue, None)
+            status_of(Ptrue, kr.nblk, 1)
+
+        for k in range(msteps):
+            nsteps = k + 1
+            if k + 2 > cap:                                           # grow the basis storage
+                newcap = min(msteps + 1, 2 * cap)
+                Qn = torch.zeros((S, newcap, ld), dtype=dtype, device=dev)
+                Qn[:, :cap].copy_(Q)
+                Q, cap = Qn, newcap
+                ycoef = torch.zeros((S, 1, cap), dtype=dtype, device=dev)
+                st.grow(cap - 1, msteps)
+            # w = A q_k (solve.py:390) straight into basis row k+1; with a shift E the fused shift kernel wants
+            # contiguous (S, ld) arrays, so q_k / w pass through two contiguous buffers (O(N) copies)
+            if prob.E is None:
+                prob.apply(Q[:, k].reshape(prob.Bt, prob.nc, ld), Q[:, k + 1].reshape(prob.Bt, prob.nc, ld))
+            else:
+                rtrue.reshape(S, ld).copy_(Q[:, k])
+                prob.apply(rtrue, tmp)
+                Q[:, k + 1].copy_(tmp.reshape(S, ld))
+            wrow = Q[:, k + 1:k + 2]
+            c1 = K.dense_mm(Q[:, :k + 1, :N], wrow[:, :, :N])                      # (S, 1, k+1): <q_j, w>
+            K.lincomb(Q, c1, wrow, k + 1, 1, coef_layout="ca", alpha=-1.0, beta=1.0)
+            c2n = K.dense_mm(Q[:, :k + 2, :N], wrow[:, :, :N])                     # second pass; last entry |w1|^2
+            check(fn("xk_gmres_step_" + sfx)(ptr(c1), c1.stride(0), ptr(c2n), c2n.stride(0), k, st.cap, ptr(st.R),
+                                             ptr(st.cs), ptr(st.sn), ptr(st.g), ptr(inv_hn), ptr(Pest), S,
+                                             stream_ptr()), "xk_gmres_step")
+            check(fn("xk_gmres_finish_" + sfx)(ptr(Q), ptr(c2n), c2n.stride(0), ptr(inv_hn), S, N, k, Q.stride(1),
+                                               Q.stride(0), stream_ptr()), "xk_gmres_finish")
+            status_of(Pest, 1, 0)
+            checked = (k + 1) % every == 0 or k == msteps - 1
+            if checked:
+                true_residual(k + 1)
+            allreduce_max_(status4, process_group)
+            est_mx, est_bad, tr_mx, tr_bad = status4.tolist()                      # the iteration's host read
+            nsync += 1
+            if not checked and est_bad == 0:
+                # the least-squares residual says every system is done: decide on the true residual, like the
+                # reference does every iteration; from here on every iterate is checked
+                true_residual(k + 1)
+                allreduce_max_(status4, process_group)
+                est_mx, est_bad, tr_mx, tr_bad = status4.tolist()
+                nsync += 1
+                checked, every = True, 1
+            if checked:
+                if tr_mx < best:                                                    # solve.py:417-421
+                    best = tr_mx
+                    best_i, cur_i = cur_i, best_i
+                if tr_bad == 0:                                                     # :423-425
+                    converged = True
+                    break
     if trace is not None:
-        trace.update(niter=niter, napply=prob.napply, converged=converged, best_resid=best)
+        # niter counts like the reference's loop: the pass that tests x_k is pass k + 1
+        trace.update(niter=nsteps + 1, napply=prob.napply, converged=converged, best_resid=best, arnoldi_steps=nsteps,
+                     host_syncs=nsync)
     if not converged:
         warnings.warn(ConvergenceWarning("Convergence is not achieved after %d iterations. "
                                          "Max norm of resid: %.3e" % (max_niter, best)))
-    return prob.solution(xs)
+    return prob.solution(xbufs[best_i].reshape(prob.Bt, prob.nc, ld))
 
 
 # ------------------------------------------------------------------------------- root-finder based
