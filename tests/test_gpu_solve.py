@@ -251,6 +251,7 @@ def test_gmres_device_state_semantics(dev):
     Bd = torch.rand(2, n, 1, dtype=torch.float64, generator=g)
     Bd[0] = 0.0
     Bd[0, 3, 0] = 1.0
-    Xd = nk.gmres(xa.LinearOperator.m(D.to(dev), is_hermitian=False), Bd.to(dev), rtol=1e-10, posdef=True).cpu()
+    Xd = nk.gmres(xa.LinearOperator.m(D.to(dev), is_hermitian=False), Bd.to(dev), rtol=1e-10, atol=1e-12,
+                  posdef=True).cpu()
     assert torch.isfinite(Xd).all()
     assert (D @ Xd - Bd).norm().item() <= 1e-9

@@ -39,6 +39,14 @@
 // cannot be shared between waves, so a third wave (<=168 VGPRs) is out of reach and the ring depth is
 // what keeps enough bytes in flight.
 //
+// Measured (round 3, fp64, P = 6, 32 x 16384^2 per launch, same process as the round-2 kernel, profiles/r03_k1s_ab.jsonl):
+//   alone on the GPU 5.68-5.80 ms (6.05-5.93 TB/s = 0.757-0.741 of 8 TB/s), the round-2 kernel 5.69-5.82: the fixed
+//   accumulation order costs nothing.  Builds without the phase barriers: 5.676 vs 5.684 ms (the barriers are free);
+//   ring slots re-issued per row or per 16 B vector instead of per row pair: 5.66 / 5.67 (nothing); runs of L = 2 slabs:
+//   equal alone, 4.6 % slower inside the eigensolver's pipeline; L = 4 / 8: 8 / 29 % slower (the launch has only ~8-11
+//   tiles per resident workgroup, so longer work items lose more in the tail than the saved row partials return).
+//   L = 1 is the default; the knob stays for measurements (xk_dense_symm_tune).
+//
 // Traffic per launch: B*N^2*s/2 (+2 % for the diagonal tiles) + B*(NT + NS/L)*P*N*s of partials written
 // and read once — vs B*N^2*s for the general kernel.
 #include "xk_common.h"
@@ -49,20 +57,6 @@ constexpr int SYMM_TRH = 1024;   // rows per tile
 constexpr int SYMM_QR = 256;     // rows per quarter (phase granularity of the deterministic accumulation)
 constexpr int SYMM_NU = 2;       // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
 constexpr int SYMM_R = 8;        // rows per chunk == ring depth
-
-// build knob (A/B, scripts/k1s_build_ab.sh): when a consumed ring slot is re-issued — 0: per row pair (round 2),
-// 1: per row, 2: per 16 B vector.  A slot is idle from the arrival of its data until its re-issue; the finer the
-// re-issue, the shorter that is (the wave spends ~100 cycles of FMAs per vector, ~400 per row pair).
-#ifndef XK_SYMM_REFILL
-#define XK_SYMM_REFILL 0
-#endif
-// measurement only (-DXK_SYMM_NOBAR): drop the phase barriers — the accumulation order is then no longer fixed;
-// tells what the barriers cost
-#ifdef XK_SYMM_NOBAR
-#define XK_SYMM_PHASE_BARRIER() ((void)0)
-#else
-#define XK_SYMM_PHASE_BARRIER() __syncthreads()
-#endif
 
 // The operator rows of a run are read through ONE buffer descriptor (base = first row of the row tile,
 // wave-uniform): every load is  descriptor + per-lane column offset (one VGPR, loop-invariant) + scalar
@@ -148,13 +142,6 @@ __device__ __forceinline__ void symm_chunk8(
       for (int q = 0; q < 2; ++q) {
         const int r = 4 * g + 2 * h + q;
         const int row = i0 + r;
-        // where slot r of the ring is re-issued from: the row one ring depth ahead in the wave's sequence
-        int nrow = nx.row + r;
-        nrow = nrow < nx.last ? nrow : nx.last;
-        const unsigned soff = (unsigned)(nrow - row_tile0) * ldab + ncoloff;
-        // (diagonal ranges: a lane whose columns all lie strictly below the row fetches nothing — its values
-        //  would be masked to zero anyway; the out-of-range offset returns the zeros without the traffic)
-        const int thr = nx.diag ? nrow - nx.col0 - (VN - 1) + col0 : -0x40000000;
 #pragma unroll
         for (int c = 0; c < P; ++c) s[q][c] = T(0);
 #pragma unroll
@@ -180,24 +167,7 @@ __device__ __forceinline__ void symm_chunk8(
               acc_col[u][c][v] += ac[v] * xi[c][q];
               s[q][c] += ar[v] * xJ[u][c][v];
             }
-#if XK_SYMM_REFILL == 2
-          // the products of this vector are issued: pin them above the re-issue of its ring slot
-#pragma unroll
-          for (int c = 0; c < P; ++c) { asm volatile("" : "+v"(acc_col[u][c])); asm volatile("" : "+v"(s[q][c])); }
-          a[r][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
-          __builtin_amdgcn_sched_barrier(0);
-#endif
         }
-#if XK_SYMM_REFILL == 1
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-          for (int c = 0; c < P; ++c) { asm volatile("" : "+v"(acc_col[u][c])); asm volatile("" : "+v"(s[q][c])); }
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-          a[r][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
       }
 #pragma unroll
       for (int c = 0; c < P; ++c) L1[h][c] = swap_add32(s[0][c], s[1][c]);
@@ -207,7 +177,6 @@ __device__ __forceinline__ void symm_chunk8(
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int c = 0; c < P; ++c) asm volatile("" : "+v"(acc_col[u][c]));
-#if XK_SYMM_REFILL == 0
       // rolling prefetch: the two rows just consumed are refilled with the rows one ring depth ahead in the
       // wave's sequence, so the wave always has ~6 row pairs of loads in flight while it computes.  Issued on
       // every path (a range without successor refills through the out-of-range offset: no data moves), so the
@@ -217,12 +186,13 @@ __device__ __forceinline__ void symm_chunk8(
         int row = nx.row + 4 * g + 2 * h + q;
         row = row < nx.last ? row : nx.last;
         const unsigned soff = (unsigned)(row - row_tile0) * ldab + ncoloff;
+        // (diagonal ranges: a lane whose columns all lie strictly below the row fetches nothing — its values
+        //  would be masked to zero anyway; the out-of-range offset returns the zeros without the traffic)
         const int thr = nx.diag ? row - nx.col0 - (VN - 1) + col0 : -0x40000000;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
           a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);      // keep the row pairs in program order (bounded live ranges)
     }
 #pragma unroll
@@ -474,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         symm_rows<T, P, true>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
                               rowacc, lane);
       }
-      XK_SYMM_PHASE_BARRIER();
+      __syncthreads();
     }
   }
   int j = 0;
@@ -491,11 +461,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         symm_rows<T, P, false>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
                                rowacc, lane);
       }
-      XK_SYMM_PHASE_BARRIER();        // s_waitcnt lgkmcnt(0) + s_barrier: the ring's loads stay in flight
+      __syncthreads();        // s_waitcnt lgkmcnt(0) + s_barrier: the ring's loads stay in flight
     }
-#ifdef XK_SYMM_NOBAR
-    __syncthreads();
-#endif
     // column partial slot I (columns of this slab)
     T* cp = colP + (((long)b * NT + I) * P) * (long)N;
 #pragma unroll
