@@ -281,6 +281,37 @@ int xk_kry_status_f64(const double* Prr, const double* stop, double* rnorm, doub
 int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double* status, int S, int nblk,
                       void* stream);
 
+/* ---- Davidson chain: one C call per stage of an iteration (xitorch/_impls/linalg/symeig.py:160-223) -------------
+ * The stages between two operator-panel products are two to eight small launches each; issued from C++ they cost a
+ * few microseconds of host time instead of an interpreter round trip per launch (what bounds small per-GPU batches).
+ * xk_davidson_ritz: xk_ritz_residual + the group status {max_b rmax (NaN-propagating), max_b info, max_b flag} as
+ *   three doubles; rmax is left zeroed for the next step (symeig.py:178-197).  flag may be NULL.
+ * xk_davidson_orth: rows [k0, k0+q) of the basis V (B, cap, ldv) against rows [0, k0): `passes` rounds of block
+ *   Gram-Schmidt (C[b,c,a] = <V_a, t_c>, t_c -= sum_a C V_a), then CholeskyQR of the q rows — for q <= 8 in ONE kernel
+ *   (Gram, Cholesky, inverse, transform; one workgroup per batch member) — i.e. tallqr of [V, t] restricted to the new
+ *   block (_utils/tensor.py:8-19, symeig.py:207-220).  C: scratch >= B*q*max(k0,q), W: scratch B*q*q, info[b] sticky
+ *   index+1 of a non-positive pivot, ws: xk_dense_mm_workspace_elems(B, cap, N, q, 0).  q <= 32.
+ * xk_davidson_extend_t: Tn[b,c,a] = <V_a, (AV)_{k0+c}> for a < k0+q, written to T[b, k0+c, a] and mirrored to
+ *   T[b, a, k0+c] (symeig.py:170 restricted to the new rows / columns).  Tn: scratch >= B*q*(k0+q). */
+int xk_davidson_ritz_f64(const double* V, const double* AV, const double* Y, const double* lam, double* X, double* Tn,
+                         double* rmax, const int* info, const int* flag, double* status, int B, int k, int N, int P,
+                         long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam, long ldx,
+                         long sX, long ldt, long sT, void* stream);
+int xk_davidson_ritz_f32(const float* V, const float* AV, const float* Y, const float* lam, float* X, float* Tn,
+                         float* rmax, const int* info, const int* flag, double* status, int B, int k, int N, int P,
+                         long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam, long ldx,
+                         long sX, long ldt, long sT, void* stream);
+int xk_davidson_orth_f64(double* V, int B, int N, int k0, int q, long ldv, long sV, double* C, double* W, int* info,
+                         double* ws, long ws_elems, int passes, void* stream);
+int xk_davidson_orth_f32(float* V, int B, int N, int k0, int q, long ldv, long sV, float* C, float* W, int* info,
+                         float* ws, long ws_elems, int passes, void* stream);
+int xk_davidson_extend_t_f64(const double* V, const double* AV, double* T, double* Tn, int B, int N, int k0, int q,
+                             long ldv, long sV, long ldav, long sAV, long ldt, long sT, double* ws, long ws_elems,
+                             void* stream);
+int xk_davidson_extend_t_f32(const float* V, const float* AV, float* T, float* Tn, int B, int N, int k0, int q,
+                             long ldv, long sV, long ldav, long sAV, long ldt, long sT, float* ws, long ws_elems,
+                             void* stream);
+
 /* ---- GMRES: per-system Hessenberg / Givens state on the device (xitorch/_impls/linalg/solve.py:326-433) ----------
  * The reference fills one Hessenberg column per iteration by modified Gram-Schmidt (:390-394) and solves the
  * (k+1) x k least-squares problem from scratch with torch.linalg.lstsq (:403) on every pass of its Python loop.

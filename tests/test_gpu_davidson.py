@@ -6,6 +6,7 @@ import torch
 from oracle import ops as oops, symeig as osym
 from tests import cases
 import xitorch_amd as xa
+from xitorch_amd import kernels as K
 from xitorch_amd.linalg import symeig
 from xitorch_amd.linalg.native_eig import davidson
 
@@ -369,3 +370,61 @@ def test_thick_restart_generalised_problem(dev):
     assert np.abs(ev.cpu().numpy() - gold["evals_exact"]).max() < 1e-9
     Xc = X.cpu()
     assert (torch.matmul(mat, Xc) - torch.matmul(Mmat, Xc) * ev.cpu().unsqueeze(-2)).abs().max().item() < 1e-7
+
+
+def test_chain_calls_match_kernel_by_kernel(dev):
+    """The one-C-call chain stages (xk_davidson_ritz / _orth / _extend_t, fused CholeskyQR of the panel) against the
+    kernel-by-kernel host loop: same iteration count, eigenvalues and residual history to rounding."""
+    from xitorch_amd import synthetic
+    for (B, N, p, dtype, tol) in ((3, 1536, 6, torch.float64, 1e-12), (2, 1000, 4, torch.float64, 1e-12),
+                                  (2, 2048, 6, torch.float32, 2e-5), (2, 900, 10, torch.float64, 1e-12)):
+        mat = synthetic.dense_symmetric(B, N, "S1", dtype=dtype, device=dev)
+        A = xa.LinearOperator.m(mat, is_hermitian=True)
+        eps = 1e-8 if dtype == torch.float64 else 1e-3
+        out = {}
+        for chain in ("calls", "kernels"):
+            tr = {}
+            ev, X = davidson(A, p, "lowest", min_eps=eps, chain=chain, trace=tr)
+            out[chain] = (ev.double().cpu(), tr)
+        (e1, t1), (e2, t2) = out["calls"], out["kernels"]
+        assert t1["niter"] == t2["niter"], (t1["niter"], t2["niter"])
+        assert (e1 - e2).abs().max().item() <= tol * max(1.0, e2.abs().max().item())
+        h1, h2 = np.array(t1["resid_history"]), np.array(t2["resid_history"])
+        assert np.all(np.abs(h1 - h2) <= 1e-3 * np.abs(h2) + 10 * tol)
+
+
+def test_fused_panel_cholqr_vs_separate_kernels(dev):
+    # xk_davidson_orth's one-kernel CholeskyQR (q <= 8) and its wide-panel path against Gram + xk_panel_chol +
+    # xk_panel_transform; orthonormality of the result; the sticky breakdown flag on a rank-deficient panel
+    from xitorch_amd.linalg._panel import pad_len
+    for (B, N, k0, q, dtype, tol) in ((3, 1000, 12, 6, torch.float64, 1e-13), (2, 2048, 0, 8, torch.float64, 1e-13),
+                                      (2, 1536, 20, 12, torch.float64, 1e-13), (2, 777, 5, 3, torch.float32, 1e-5)):
+        g = torch.Generator().manual_seed(N + q)
+        ld = pad_len(N)
+        V = torch.zeros(B, k0 + q, ld, dtype=dtype)
+        Q0, _ = torch.linalg.qr(torch.randn(B, N, k0 + q, dtype=torch.float64, generator=g))
+        V[:, :k0, :N] = Q0[:, :, :k0].transpose(-2, -1).to(dtype)
+        V[:, k0:, :N] = torch.randn(B, q, N, dtype=torch.float64, generator=g).to(dtype)
+        Vd = V.to(dev)
+        C = torch.empty(B * max(q, 8) * (k0 + q + 8), dtype=dtype, device=dev)
+        W = torch.empty(B * q * q, dtype=dtype, device=dev)
+        info = torch.zeros(B, dtype=torch.int32, device=dev)
+        K.davidson_orth(Vd, N, k0, q, C, W, info, passes=2)
+        Qn = Vd[:, :, :N].double().cpu()
+        G = Qn @ Qn.transpose(-2, -1)
+        assert (G - torch.eye(k0 + q, dtype=torch.float64)).abs().max().item() < 50 * tol
+        assert int(info.max()) == 0
+        # the new rows span the same space as the input block projected off the basis
+        t = V[:, k0:, :N].double()
+        tp = t - (t @ Qn[:, :k0].transpose(-2, -1)) @ Qn[:, :k0]
+        resid = tp - (tp @ Qn[:, k0:].transpose(-2, -1)) @ Qn[:, k0:]
+        assert resid.abs().max().item() < 1e3 * tol * t.abs().max().item()
+    # rank-deficient panel: flagged, not silently "orthonormalised"
+    V = torch.zeros(1, 4, 512, dtype=torch.float64)
+    V[0, :2] = torch.randn(2, 512, dtype=torch.float64)
+    V[0, 2] = 0.0                               # a zero vector: the pivot is exactly 0
+    V[0, 3] = torch.randn(512, dtype=torch.float64)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    K.davidson_orth(V.to(dev), 512, 0, 4, torch.empty(1024, dtype=torch.float64, device=dev),
+                    torch.empty(16, dtype=torch.float64, device=dev), info, passes=0)
+    assert int(info[0]) != 0

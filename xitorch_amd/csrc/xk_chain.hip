@@ -1,0 +1,332 @@
+// xitorch_amd :: the per-iteration chain of the block Davidson eigensolver as a handful of C calls.
+//
+// Between two operator-panel products an iteration of `davidson` (xitorch/_impls/linalg/symeig.py:160-223) does
+//   Rayleigh-Ritz rotation + residual + stopping norm            (symeig.py:178-197)
+//   orthonormalisation of the new block against the basis         (:207-220, tallqr of [V, t], _utils/tensor.py:8-19)
+//   extension of T = V^T A V by the new rows / columns            (:163-170 recomputes it whole)
+// Each of these is two to eight small launches.  Issued one by one from the Python host loop they cost more host
+// time than GPU time once the batch per GPU is small (8 operators of order 16384: ~20 launches x ~15 us of
+// interpreter + ctypes per group and iteration against 0.8 ms of panel product), which is what bounds strong scaling.
+// The entry points below enqueue a whole stage from C++ (a launch is ~3 us here) on the caller's stream:
+//
+//   xk_davidson_ritz      ritz_residual + group status (which re-zeroes the per-member max for the next round)
+//   xk_davidson_orth      block Gram-Schmidt of the new panel against the basis (passes x [Gram, projection]) +
+//                         CholeskyQR of the panel in ONE kernel (Gram, Cholesky, inverse, transform; one workgroup per
+//                         batch member, the p x N panel is read twice and written once) — panels up to 8 vectors;
+//                         wider ones take the separate Gram / xk_panel_chol / xk_panel_transform kernels
+//   xk_davidson_extend_t  Gram block of the new A V panel against the basis + scatter into both triangles of T
+//
+// Nothing here changes the arithmetic of the stages: same kernels / same formulas as the separate entry points
+// (the fused CholeskyQR sums its Gram entries per thread, then per wave, then across the 16 waves in fixed order).
+#include "xk_common.h"
+
+extern "C" {
+long xk_dense_mm_workspace_elems(int B, int M, int N, int P, int trans);
+int xk_dense_mm_f64(const double*, const double*, double*, double*, long, int, int, int, int, long, long, long, long,
+                    long, long, int, int, int, void*);
+int xk_dense_mm_f32(const float*, const float*, float*, float*, long, int, int, int, int, long, long, long, long, long,
+                    long, int, int, int, void*);
+int xk_lincomb_f64(const double*, const double*, double*, int, int, int, int, long, long, long, long, long, long, long,
+                   double, double, void*);
+int xk_lincomb_f32(const float*, const float*, float*, int, int, int, int, long, long, long, long, long, long, long,
+                   double, double, void*);
+int xk_ritz_residual_f64(const double*, const double*, const double*, const double*, double*, double*, double*, int,
+                         int, int, int, long, long, long, long, long, long, long, long, long, long, long, long, void*);
+int xk_ritz_residual_f32(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
+                         int, long, long, long, long, long, long, long, long, long, long, long, long, void*);
+int xk_panel_chol_f64(const double*, double*, int*, int, int, long, long, void*);
+int xk_panel_chol_f32(const float*, float*, int*, int, int, long, long, void*);
+int xk_panel_transform_f64(double*, const double*, int, int, int, long, long, void*);
+int xk_panel_transform_f32(float*, const float*, int, int, int, long, long, void*);
+}
+
+namespace xk {
+
+static inline int dense_mm(const double* A, const double* X, double* Y, double* ws, long wsn, int B, int M, int N,
+                           int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* st) {
+  return xk_dense_mm_f64(A, X, Y, ws, wsn, B, M, N, P, lda, sA, ldx, sX, ldy, sY, 0, 0, 1, st);
+}
+static inline int dense_mm(const float* A, const float* X, float* Y, float* ws, long wsn, int B, int M, int N, int P,
+                           long lda, long sA, long ldx, long sX, long ldy, long sY, void* st) {
+  return xk_dense_mm_f32(A, X, Y, ws, wsn, B, M, N, P, lda, sA, ldx, sX, ldy, sY, 0, 0, 1, st);
+}
+static inline int lincomb_c(const double* V, const double* C, double* O, int B, int k, int N, int P, long ldv, long sV,
+                            long sC, long sCa, long sCc, long ldo, long sO, double al, double be, void* st) {
+  return xk_lincomb_f64(V, C, O, B, k, N, P, ldv, sV, sC, sCa, sCc, ldo, sO, al, be, st);
+}
+static inline int lincomb_c(const float* V, const float* C, float* O, int B, int k, int N, int P, long ldv, long sV,
+                            long sC, long sCa, long sCc, long ldo, long sO, double al, double be, void* st) {
+  return xk_lincomb_f32(V, C, O, B, k, N, P, ldv, sV, sC, sCa, sCc, ldo, sO, al, be, st);
+}
+static inline int ritz_c(const double* V, const double* AV, const double* Y, const double* lam, double* X, double* Tn,
+                         double* rmax, int B, int k, int N, int P, long a, long b, long c, long d, long e, long f,
+                         long g, long h, long i, long j, long l, long m, void* st) {
+  return xk_ritz_residual_f64(V, AV, Y, lam, X, Tn, rmax, B, k, N, P, a, b, c, d, e, f, g, h, i, j, l, m, st);
+}
+static inline int ritz_c(const float* V, const float* AV, const float* Y, const float* lam, float* X, float* Tn,
+                         float* rmax, int B, int k, int N, int P, long a, long b, long c, long d, long e, long f, long g,
+                         long h, long i, long j, long l, long m, void* st) {
+  return xk_ritz_residual_f32(V, AV, Y, lam, X, Tn, rmax, B, k, N, P, a, b, c, d, e, f, g, h, i, j, l, m, st);
+}
+static inline int chol_c(const double* G, double* W, int* info, int B, int P, long ldg, long sG, void* st) {
+  return xk_panel_chol_f64(G, W, info, B, P, ldg, sG, st);
+}
+static inline int chol_c(const float* G, float* W, int* info, int B, int P, long ldg, long sG, void* st) {
+  return xk_panel_chol_f32(G, W, info, B, P, ldg, sG, st);
+}
+static inline int transform_c(double* Tp, const double* W, int B, int P, int N, long ldt, long sT, void* st) {
+  return xk_panel_transform_f64(Tp, W, B, P, N, ldt, sT, st);
+}
+static inline int transform_c(float* Tp, const float* W, int B, int P, int N, long ldt, long sT, void* st) {
+  return xk_panel_transform_f32(Tp, W, B, P, N, ldt, sT, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b]} as doubles, then rmax <- 0 for the next
+// Rayleigh-Ritz step (the residual kernel folds into it with an order-independent atomic max).  One wave.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__ rmax, const int* __restrict__ info,
+                                                                 const int* __restrict__ flag,
+                                                                 double* __restrict__ status, int B) {
+  const int lane = threadIdx.x;
+  double m = 0.0;
+  int nan = 0, i1 = 0, i2 = 0;
+  bool first = true;
+  for (int b = lane; b < B; b += 64) {
+    const double v = (double)rmax[b];
+    rmax[b] = T(0);
+    nan |= (v != v);
+    m = first ? v : (v > m ? v : m);
+    const int a = info[b];
+    i1 = first ? a : (a > i1 ? a : i1);
+    if (flag) {
+      const int f = flag[b];
+      i2 = first ? f : (f > i2 ? f : i2);
+    }
+    first = false;
+  }
+  double mm = first ? -__builtin_inf() : m;
+  int a1 = first ? -2147483647 - 1 : i1, a2 = first ? -2147483647 - 1 : i2;
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const double om = __shfl_xor(mm, sft, 64);
+    const int o1 = __shfl_xor(a1, sft, 64), o2 = __shfl_xor(a2, sft, 64), on = __shfl_xor(nan, sft, 64);
+    mm = om > mm ? om : mm;
+    a1 = o1 > a1 ? o1 : a1;
+    a2 = o2 > a2 ? o2 : a2;
+    nan |= on;
+  }
+  if (lane == 0) {
+    status[0] = nan ? __builtin_nan("") : mm;
+    status[1] = (double)a1;
+    status[2] = flag ? (double)a2 : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CholeskyQR of a P-row panel in one kernel (tallqr restricted to the new block, _utils/tensor.py:15-18):
+//   G = t t^T (P x P, symmetrised like xk_panel_chol), G = R^T R, W = R^-1, t <- W^T t   (row c <- sum_{a<=c} W[a,c] t_a)
+// One 1024-thread workgroup per batch member; info[b] = index+1 of the first non-positive pivot (sticky, like
+// xk_panel_chol).  P <= 8.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int P>
+__global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, int* __restrict__ info, int N,
+                                                            long ldt, long sT) {
+  // (N here is the panel length rounded up to whole 16 B vectors: the pad elements are zero by the panel contract)
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int NG = P * (P + 1) / 2;
+  __shared__ T part[16][NG];
+  __shared__ T Wsh[P][P];
+  const int b = blockIdx.x;
+  T* Tb = Tp + (long)b * sT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T g[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) g[i] = T(0);
+  for (int j = tid * VN; j < N; j += 1024 * VN) {
+    VT t[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) t[c] = *reinterpret_cast<const VT*>(Tb + (long)c * ldt + j);
+    int i = 0;
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+      for (int d = c; d < P; ++d, ++i)
+#pragma unroll
+        for (int v = 0; v < VN; ++v) g[i] += t[c][v] * t[d][v];
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const T s = wave_sum(g[i]);
+    if (lane == 0) part[wave][i] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    T G[P][P], R[P][P];
+    int i = 0;
+    for (int c = 0; c < P; ++c)
+      for (int d = c; d < P; ++d, ++i) {
+        T s = T(0);
+        for (int w = 0; w < 16; ++w) s += part[w][i];          // fixed order
+        G[c][d] = s;
+        G[d][c] = s;
+      }
+    int bad = 0;
+    for (int r = 0; r < P; ++r)
+      for (int c = 0; c < P; ++c) R[r][c] = T(0);
+    for (int j = 0; j < P; ++j)
+      for (int r = 0; r <= j; ++r) {
+        T s = G[r][j];
+        for (int m = 0; m < r; ++m) s -= R[m][r] * R[m][j];
+        if (r == j) {
+          if (!(s > T(0))) { if (!bad) bad = j + 1; s = T(1); }
+          R[j][j] = sqrt(s);
+        } else {
+          R[r][j] = s / R[r][r];
+        }
+      }
+    // W = R^-1 (upper triangular), column by column: R W = I
+    for (int c = 0; c < P; ++c) {
+      T col[P];
+      for (int r = P - 1; r >= 0; --r) {
+        T s = (r == c) ? T(1) : T(0);
+        for (int m = r + 1; m <= c; ++m) s -= R[r][m] * col[m];
+        col[r] = (r <= c) ? s / R[r][r] : T(0);
+      }
+      for (int r = 0; r < P; ++r) Wsh[r][c] = col[r];
+    }
+    if (bad) info[b] = bad;
+  }
+  __syncthreads();
+  for (int j = tid * VN; j < N; j += 1024 * VN) {
+    VT t[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) t[c] = *reinterpret_cast<const VT*>(Tb + (long)c * ldt + j);
+#pragma unroll
+    for (int c = P - 1; c >= 0; --c) {
+      VT acc;
+#pragma unroll
+      for (int v = 0; v < VN; ++v) acc[v] = T(0);
+#pragma unroll
+      for (int a = 0; a <= c; ++a) {
+        const T w = Wsh[a][c];
+#pragma unroll
+        for (int v = 0; v < VN; ++v) acc[v] += w * t[a][v];
+      }
+      *reinterpret_cast<VT*>(Tb + (long)c * ldt + j) = acc;
+    }
+  }
+}
+
+// T[b, k0+c, a] = Tn[b, c, a] (a < k0+q) and its mirror T[b, a, k0+c] = Tn[b, c, a] (a < k0)
+template <typename T>
+__global__ __launch_bounds__(256) void t_scatter_kernel(const T* __restrict__ Tn, T* __restrict__ Tm, int k0, int q,
+                                                        long ldt, long sT, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int kq = k0 + q;
+  const long per_b = (long)q * kq;
+  const long b = idx / per_b;
+  const long rem = idx - b * per_b;
+  const int c = (int)(rem / kq), a = (int)(rem - (long)c * kq);
+  const T v = Tn[idx];
+  T* Tb = Tm + b * sT;
+  Tb[(long)(k0 + c) * ldt + a] = v;
+  if (a < k0) Tb[(long)a * ldt + k0 + c] = v;
+}
+
+template <typename T>
+static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT, hipStream_t st) {
+  switch (P) {
+#define XK_CASE(PP)                                                                                        \
+  case PP:                                                                                                 \
+    hipLaunchKernelGGL((panel_cholqr_kernel<T, PP>), dim3(B), dim3(1024), 0, st, Tp, info, N, ldt, sT);    \
+    break;
+    XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
+#undef XK_CASE
+    default: return XK_ERR_UNSUPPORTED;
+  }
+  XK_LAUNCH_CHECK();
+  return XK_OK;
+}
+
+template <typename T>
+static int davidson_orth(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
+                         long ws_elems, int passes, void* stream) {
+  constexpr int VN = Vec16<T>::n;
+  if ((ldv % VN) || (sV % VN) || ((uintptr_t)V & 15) || ldv < (long)((N + VN - 1) / VN) * VN) return XK_ERR_UNSUPPORTED;
+  T* panel = V + (long)k0 * ldv;
+  int rc;
+  if (k0 > 0) {
+    for (int it = 0; it < passes; ++it) {
+      // C[b,c,a] = <V_a, t_c> (a < k0), then t_c -= sum_a C[b,c,a] V_a   (tensor.py:15-18 restricted to the new block)
+      rc = dense_mm(V, panel, C, ws, ws_elems, B, k0, N, q, ldv, sV, ldv, sV, (long)k0, (long)q * k0, stream);
+      if (rc != XK_OK) return rc;
+      rc = lincomb_c(V, C, panel, B, k0, (int)ldv, q, ldv, sV, (long)q * k0, 1L, (long)k0, ldv, sV, -1.0, 1.0, stream);
+      if (rc != XK_OK) return rc;
+    }
+  }
+  if (q <= 8) return cholqr_fused<T>(panel, info, B, q, (N + VN - 1) / VN * VN, ldv, sV, (hipStream_t)stream);
+  // wider panels: Gram on K1, Cholesky + inverse per member, transform
+  T* G = C;                                               // (B, q, q) fits: the caller sizes C for q * max(k0, q)
+  rc = dense_mm(panel, panel, G, ws, ws_elems, B, q, N, q, ldv, sV, ldv, sV, (long)q, (long)q * q, stream);
+  if (rc != XK_OK) return rc;
+  rc = chol_c(G, W, info, B, q, (long)q, (long)q * q, stream);
+  if (rc != XK_OK) return rc;
+  return transform_c(panel, W, B, q, (int)ldv, ldv, sV, stream);
+}
+
+template <typename T>
+static int davidson_extend_t(const T* V, const T* AV, T* Tm, T* Tn, int B, int N, int k0, int q, long ldv, long sV,
+                             long ldav, long sAV, long ldt, long sT, T* ws, long ws_elems, void* stream) {
+  const int kq = k0 + q;
+  // Tn[b, c, a] = <V_a, (A V)_{k0+c}>, a < k0+q   (symeig.py:170 restricted to the new rows)
+  int rc = dense_mm(V, AV + (long)k0 * ldav, Tn, ws, ws_elems, B, kq, N, q, ldv, sV, ldav, sAV, (long)kq, (long)q * kq,
+                    stream);
+  if (rc != XK_OK) return rc;
+  const long total = (long)B * q * kq;
+  hipLaunchKernelGGL((t_scatter_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     Tn, Tm, k0, q, ldt, sT, total);
+  XK_LAUNCH_CHECK();
+  return XK_OK;
+}
+
+}  // namespace xk
+
+extern "C" {
+
+#define XK_DEFINE_CHAIN(SUF, T)                                                                                    \
+  int xk_davidson_ritz_##SUF(const T* V, const T* AV, const T* Y, const T* lam, T* X, T* Tn, T* rmax,              \
+                             const int* info, const int* flag, double* status, int B, int k, int N, int P,         \
+                             long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam,       \
+                             long ldx, long sX, long ldt, long sT, void* stream) {                                 \
+    if (B <= 0 || k <= 0 || N <= 0 || P <= 0 || !rmax || !info || !status) return XK_ERR_ARG;                      \
+    int rc = xk::ritz_c(V, AV, Y, lam, X, Tn, rmax, B, k, N, P, ldv, sV, ldav, sAV, sY, sYa, sYc, sLam, ldx, sX,   \
+                        ldt, sT, stream);                                                                          \
+    if (rc != XK_OK) return rc;                                                                                    \
+    hipLaunchKernelGGL((xk::group_status_rezero_kernel<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, rmax, info,  \
+                       flag, status, B);                                                                           \
+    XK_LAUNCH_CHECK();                                                                                             \
+    return XK_OK;                                                                                                  \
+  }                                                                                                                \
+  int xk_davidson_orth_##SUF(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,   \
+                             long ws_elems, int passes, void* stream) {                                            \
+    if (B < 0 || N <= 0 || k0 < 0 || q <= 0 || q > 32 || passes < 0) return XK_ERR_ARG;                            \
+    if (B == 0) return XK_OK;                                                                                      \
+    return xk::davidson_orth<T>(V, B, N, k0, q, ldv, sV, C, W, info, ws, ws_elems, passes, stream);                \
+  }                                                                                                                \
+  int xk_davidson_extend_t_##SUF(const T* V, const T* AV, T* Tm, T* Tn, int B, int N, int k0, int q, long ldv,     \
+                                 long sV, long ldav, long sAV, long ldt, long sT, T* ws, long ws_elems,            \
+                                 void* stream) {                                                                   \
+    if (B < 0 || N <= 0 || k0 < 0 || q <= 0) return XK_ERR_ARG;                                                    \
+    if (B == 0) return XK_OK;                                                                                      \
+    return xk::davidson_extend_t<T>(V, AV, Tm, Tn, B, N, k0, q, ldv, sV, ldav, sAV, ldt, sT, ws, ws_elems,         \
+                                    stream);                                                                       \
+  }
+
+XK_DEFINE_CHAIN(f64, double)
+XK_DEFINE_CHAIN(f32, float)
+
+}  // extern "C"

@@ -109,11 +109,13 @@ class _Group:
         self.MVs = z(B, self.cap, Npad) if opM is not None else None
         self.T = z(B, self.cap, self.cap)
         self.Wflat = torch.empty((B * 32 * 32,), dtype=dtype, device=device)
+        self._cscratch = None                     # coefficient scratch of the one-call chain stages, B * p * cap
         self.info = torch.zeros((B,), dtype=torch.int32, device=device)
         self.status = torch.zeros((3,), dtype=torch.float64, device=device)   # max|resid|, chol flag, K3t self-check flag
         self.rmax = z(B)
         self.Xbuf = [z(B, p, Npad), z(B, p, Npad)]
         self.k = 0
+        self.fast = True          # chain stages as single C calls (xk_davidson_*); False: kernel by kernel (A/B, tests)
         self.best_slot, self.best_evals = -1, None
         self.slot, self.lam, self.newpanel, self.nadd = 0, None, None, 0
 
@@ -133,9 +135,18 @@ class _Group:
         Tn[:, :self.cap, :self.cap].copy_(self.T)
         self.T, self.cap = Tn, new
 
+    def scratch(self, q):
+        n = self.B * max(q, self.p) * (self.cap + q)
+        if self._cscratch is None or self._cscratch.numel() < n:
+            self._cscratch = torch.empty((n,), dtype=self.dtype, device=self.device)
+        return self._cscratch
+
     def cholqr(self, k0, q):
         """Orthonormalise basis rows k0..k0+q among themselves (M-inner product if M)."""
         N = self.N
+        if self.opM is None and self.fast:
+            K.davidson_orth(self.Vs, N, k0, q, self.scratch(q), self.Wflat, self.info, passes=0)
+            return
         panel = self.Vs[:, k0:k0 + q]
         if self.opM is None:
             G = K.dense_mm(panel[:, :, :N], panel[:, :, :N])
@@ -158,6 +169,9 @@ class _Group:
     def extend_T(self, k0, q):
         """rows/cols k0..k0+q of T = V^T A V from the new A V panel only."""
         N = self.N
+        if self.fast:
+            K.davidson_extend_t(self.Vs, self.AVs, self.T, self.scratch(q), N, k0, q)
+            return
         Tn = K.dense_mm(self.Vs[:, :k0 + q, :N], self.AVs[:, k0:k0 + q, :N])     # (B, q, k0+q): <V_a, AV_c>
         self.T[:, k0:k0 + q, :k0 + q] = Tn
         self.T[:, :k0, k0:k0 + q] = Tn[:, :, :k0].transpose(-2, -1)
@@ -239,12 +253,18 @@ class _Group:
         self.nadd = min(p, N - k)
         self.slot = 1 - self.best_slot if self.best_slot >= 0 else 0
         X = self.Xbuf[self.slot]
-        self.rmax.zero_()
+        if not (self.fast and self.opM is None and self.precond is None):
+            self.rmax.zero_()
         if self.nadd == p and not due:
             self.newpanel = self.Vs[:, k:k + p]                 # the next panel is produced in place
         else:
             self.newpanel = torch.empty((self.B, p, self.Npad), dtype=self.dtype, device=self.device)
-        if self.opM is None:
+        fused_status = self.fast and self.opM is None and self.precond is None
+        if fused_status:
+            # rotation + residual + status in one C call; rmax comes back zeroed for the next step
+            K.davidson_ritz(self.Vs, self.AVs, Y, lam, X, self.newpanel, self.rmax, self.info, tri_flag, self.status,
+                            k, p)
+        elif self.opM is None:
             K.ritz_residual(self.Vs, self.AVs, Y, lam, X, self.newpanel, self.rmax, k, p)
         else:
             # residual A X - lam (M X): rotate M V instead of V, then the eigenvectors separately
@@ -259,7 +279,8 @@ class _Group:
                 self.precond[1].apply(self.newpanel, tmp)
                 self.newpanel.copy_(tmp)
         self.lam = lam
-        K.group_status(self.rmax, self.info, tri_flag, self.status)
+        if not fused_status:
+            K.group_status(self.rmax, self.info, tri_flag, self.status)
         end_ritz()
 
     def compress(self):
@@ -291,9 +312,13 @@ class _Group:
         if nadd != self.p or restarted:
             self.Vs[:, k:k + nadd].copy_(self.newpanel[:, :nadd])
         end = self._mark("orth")
-        for _ in range(max(1, self.orth_passes)):
-            self.project_out(k, nadd)
-        self.cholqr(k, nadd)
+        if self.fast and self.opM is None:
+            K.davidson_orth(self.Vs, self.N, k, nadd, self.scratch(nadd), self.Wflat, self.info,
+                            passes=max(1, self.orth_passes))
+        else:
+            for _ in range(max(1, self.orth_passes)):
+                self.project_out(k, nadd)
+            self.cholqr(k, nadd)
         end()
         self.apply_A(self.Vs[:, k:k + nadd], self.AVs[:, k:k + nadd])
         end = self._mark("extT")
@@ -343,7 +368,7 @@ def _sub_operator(A, B, N, b0, b1):
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
-             groups="auto", **unused):
+             groups="auto", chain="calls", **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -390,6 +415,11 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         (extension) compute units the panel-product stream leaves to the small kernels (default 64 of 256: the
         HBM-bound panel product is as fast on 192 CUs as on all of them; whole 32-CU mask words measured best:
         224.2 ms per config-2 call with 64, 227.5 with 32, 233 with 48 or 8, 241 with 96)
+    chain: str
+        (extension) ``"calls"`` (default): every stage between two operator-panel products (rotation + residual +
+        status, orthonormalisation of the new block, extension of T) is enqueued by one C call
+        (``xk_davidson_ritz`` / ``_orth`` / ``_extend_t``); ``"kernels"``: kernel by kernel from the host loop — the
+        same arithmetic up to the summation order inside the panel's Gram matrix (A/B, tests)
     precond: None, str, tensor or LinearOperator
         (extension; the reference has no preconditioner, symeig.py:206-207) ``None`` (default): new directions
         are the negated residuals, exactly like the reference.  ``"diag"``: Davidson's diagonal correction
@@ -517,6 +547,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
                          precond=_pc_slice(b0, b1), restart=restart)
             grp.k1_stream = k1_stream
+            grp.fast = (chain != "kernels")
             if trace is not None and "timeline" in trace:
                 grp.timeline, grp.tag = trace["timeline"], g
             grp.start(V0p[b0:b1])
