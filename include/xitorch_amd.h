@@ -290,7 +290,8 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  *   Gram-Schmidt (C[b,c,a] = <V_a, t_c>, t_c -= sum_a C V_a), then CholeskyQR of the q rows — for q <= 8 in ONE kernel
  *   (Gram, Cholesky, inverse, transform; one workgroup per batch member) — i.e. tallqr of [V, t] restricted to the new
  *   block (_utils/tensor.py:8-19, symeig.py:207-220).  C: scratch >= B*q*max(k0,q), W: scratch B*q*q, info[b] sticky
- *   index+1 of a non-positive pivot, ws: xk_dense_mm_workspace_elems(B, cap, N, q, 0).  q <= 32.
+ *   index+1 of a non-positive pivot, ws: xk_dense_mm_workspace_elems(B, cap, N, q, 0).  Any q: panels wider than
+ *   32 are taken 32 rows at a time, each chunk against everything before it (twice), then among itself.
  * xk_davidson_extend_t: Tn[b,c,a] = <V_a, (AV)_{k0+c}> for a < k0+q, written to T[b, k0+c, a] and mirrored to
  *   T[b, a, k0+c] (symeig.py:170 restricted to the new rows / columns).  Tn: scratch >= B*q*(k0+q). */
 int xk_davidson_ritz_f64(const double* V, const double* AV, const double* Y, const double* lam, double* X, double* Tn,

@@ -18,6 +18,8 @@ only = extra.pop("overlap_only", None)
 variants = [dict(extra)]
 if "," in str(extra.get("chain", "")):
     variants = [dict(v, chain=c) for v in variants for c in str(extra["chain"]).split(",")]
+if "," in str(extra.get("orth_passes", "")):
+    variants = [dict(v, orth_passes=int(g)) for v in variants for g in str(extra["orth_passes"]).split(",")]
 if "," in str(extra.get("groups", "")):
     variants = [dict(v, groups=int(g)) for v in variants for g in str(extra["groups"]).split(",")]
 N, p = 16384, 6

@@ -428,3 +428,53 @@ def test_fused_panel_cholqr_vs_separate_kernels(dev):
     K.davidson_orth(V.to(dev), 512, 0, 4, torch.empty(1024, dtype=torch.float64, device=dev),
                     torch.empty(16, dtype=torch.float64, device=dev), info, passes=0)
     assert int(info[0]) != 0
+
+
+def test_wide_blocks_neig40_and_restart_neig20(dev):
+    """No width cliff: neig = 40 > 32 goes through the chunked panel orthonormalisation
+    (the reference has no limit: symeig.py:100-140); thick restart with 16 < neig <= 32 keeps at least the wanted
+    vectors.  Both against the dense eigendecomposition."""
+    from xitorch_amd import synthetic
+    mat = synthetic.dense_symmetric(2, 1536, "S1", dtype=torch.float64, device=dev)
+    mat = mat + torch.diag_embed(torch.linspace(0.0, 3.0, 1536, dtype=torch.float64, device=dev)).unsqueeze(0)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    lam_all = torch.linalg.eigvalsh(mat)
+    tr = {}
+    ev, X = davidson(A, 40, "lowest", min_eps=1e-8, trace=tr)
+    assert ev.shape == (2, 40) and X.shape == (2, 1536, 40)
+    assert (ev - lam_all[:, :40]).abs().max().item() <= 1e-9 * lam_all.abs().max().item()
+    R = mat @ X - X * ev.unsqueeze(-2)
+    assert R.abs().max().item() <= 1e-7
+    G = X.transpose(-2, -1) @ X
+    assert (G - torch.eye(40, dtype=torch.float64, device=dev)).abs().max().item() <= 1e-9
+    ev_u, _ = davidson(A, 36, "uppest", min_eps=1e-8, nguess=40)
+    assert (ev_u - lam_all[:, -36:]).abs().max().item() <= 1e-9 * lam_all.abs().max().item()
+    # restart with 16 < neig <= 32
+    tr = {}
+    ev20, X20 = davidson(A, 20, "lowest", min_eps=1e-8, restart=80, trace=tr)
+    assert tr["restarts"] >= 1
+    assert (ev20 - lam_all[:, :20]).abs().max().item() <= 1e-9 * lam_all.abs().max().item()
+    assert (mat @ X20 - X20 * ev20.unsqueeze(-2)).abs().max().item() <= 1e-7
+
+
+def test_one_gram_schmidt_pass_equals_two(dev):
+    """orth_passes='auto' takes ONE pass of the new residual block against the basis (a Ritz residual is orthogonal
+    to it up to rounding); the iteration must be the one two passes give: same count, same eigenvalues, same residual
+    history to rounding, and an orthonormal result — on the clustered and on the slowly converging spectrum, fp64 and
+    fp32."""
+    from xitorch_amd import synthetic
+    for (kind, B, N, p, dtype, eps, tol) in (("S1", 2, 2048, 6, torch.float64, 1e-8, 1e-11),
+                                             ("S2", 2, 1024, 4, torch.float64, 1e-8, 1e-11),
+                                             ("S1", 2, 2048, 6, torch.float32, 1e-3, 2e-5)):
+        mat = synthetic.dense_symmetric(B, N, kind, dtype=dtype, device=dev)
+        A = xa.LinearOperator.m(mat, is_hermitian=True)
+        res = {}
+        for passes in (1, 2):
+            tr = {}
+            ev, X = davidson(A, p, "lowest", min_eps=eps, orth_passes=passes, trace=tr)
+            res[passes] = (ev.double().cpu(), X.double().cpu(), tr)
+        (e1, X1, t1), (e2, X2, t2) = res[1], res[2]
+        assert abs(t1["niter"] - t2["niter"]) <= (0 if dtype == torch.float64 else 1), (kind, t1["niter"], t2["niter"])
+        assert (e1 - e2).abs().max().item() <= tol * max(1.0, e2.abs().max().item())
+        G = X1.transpose(-2, -1) @ X1
+        assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() <= (1e-10 if dtype == torch.float64 else 1e-4)

@@ -38,6 +38,23 @@ __global__ __launch_bounds__(256) void lincomb_kernel(
 #pragma unroll
     for (int v = 0; v < VN; ++v) acc[c][v] = T(0);
   int a = 0;
+  // eight basis rows per trip: with few batch members the launch has only a few waves per CU, and what bounds it is
+  // the number of loads each of them keeps in flight (4 ops x k = 57 x N = 16384: 52 us with four, r03)
+  for (; a + 8 <= k; a += 8) {
+    VT v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const VT*>(Vb + (long)(a + u) * ldv);
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      T cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cc[u] = Cb[(long)(a + u) * sCa + c * sCc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[c][e] += cc[u] * v[u][e];
+    }
+  }
   for (; a + 4 <= k; a += 4) {
     VT v0 = *reinterpret_cast<const VT*>(Vb + (long)(a + 0) * ldv);
     VT v1 = *reinterpret_cast<const VT*>(Vb + (long)(a + 1) * ldv);
@@ -106,6 +123,28 @@ __global__ __launch_bounds__(256) void ritz_residual_kernel(
 #pragma unroll
       for (int v = 0; v < VN; ++v) { ax[c][v] = T(0); xx[c][v] = T(0); }
     int a = 0;
+    // four basis rows (eight 16 B loads) per trip, see lincomb_kernel
+    for (; a + 4 <= k; a += 4) {
+      VT v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const VT*>(Vb + (long)(a + u) * ldv);
+        w[u] = *reinterpret_cast<const VT*>(AVb + (long)(a + u) * ldav);
+      }
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        T yy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yy[u] = Yb[(long)(a + u) * sYa + c * sYc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < VN; ++e) {
+            xx[c][e] += yy[u] * v[u][e];
+            ax[c][e] += yy[u] * w[u][e];
+          }
+      }
+    }
     for (; a + 2 <= k; a += 2) {
       VT v0 = *reinterpret_cast<const VT*>(Vb + (long)a * ldv);
       VT v1 = *reinterpret_cast<const VT*>(Vb + (long)(a + 1) * ldv);

@@ -253,10 +253,9 @@ static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT
 }
 
 template <typename T>
-static int davidson_orth(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
-                         long ws_elems, int passes, void* stream) {
+static int davidson_orth_block(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
+                               long ws_elems, int passes, void* stream) {
   constexpr int VN = Vec16<T>::n;
-  if ((ldv % VN) || (sV % VN) || ((uintptr_t)V & 15) || ldv < (long)((N + VN - 1) / VN) * VN) return XK_ERR_UNSUPPORTED;
   T* panel = V + (long)k0 * ldv;
   int rc;
   if (k0 > 0) {
@@ -276,6 +275,25 @@ static int davidson_orth(T* V, int B, int N, int k0, int q, long ldv, long sV, T
   rc = chol_c(G, W, info, B, q, (long)q, (long)q * q, stream);
   if (rc != XK_OK) return rc;
   return transform_c(panel, W, B, q, (int)ldv, ldv, sV, stream);
+}
+
+// Panels wider than the 32 columns of the per-member Cholesky kernel are taken 32 rows at a time: every chunk is
+// orthogonalised (twice: its vectors are not nearly orthogonal to the earlier chunks of the same panel, unlike a
+// residual block against the basis) against everything before it, then among itself — block Gram-Schmidt with
+// CholeskyQR inside the blocks, the same Q as one CholeskyQR of the whole panel in exact arithmetic.  The reference has
+// no width limit (tallqr, _utils/tensor.py:8-19; symeig.py:100-140 for any neig / nguess).
+template <typename T>
+static int davidson_orth(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
+                         long ws_elems, int passes, void* stream) {
+  constexpr int VN = Vec16<T>::n;
+  if ((ldv % VN) || (sV % VN) || ((uintptr_t)V & 15) || ldv < (long)((N + VN - 1) / VN) * VN) return XK_ERR_UNSUPPORTED;
+  for (int off = 0; off < q; off += 32) {
+    const int qc = q - off < 32 ? q - off : 32;
+    const int np = off == 0 ? passes : (passes > 2 ? passes : 2);
+    const int rc = davidson_orth_block<T>(V, B, N, k0 + off, qc, ldv, sV, C, W, info, ws, ws_elems, np, stream);
+    if (rc != XK_OK) return rc;
+  }
+  return XK_OK;
 }
 
 template <typename T>
@@ -313,7 +331,7 @@ extern "C" {
   }                                                                                                                \
   int xk_davidson_orth_##SUF(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,   \
                              long ws_elems, int passes, void* stream) {                                            \
-    if (B < 0 || N <= 0 || k0 < 0 || q <= 0 || q > 32 || passes < 0) return XK_ERR_ARG;                            \
+    if (B < 0 || N <= 0 || k0 < 0 || q <= 0 || passes < 0) return XK_ERR_ARG;                            \
     if (B == 0) return XK_OK;                                                                                      \
     return xk::davidson_orth<T>(V, B, N, k0, q, ldv, sV, C, W, info, ws, ws_elems, passes, stream);                \
   }                                                                                                                \

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
   __syncthreads();
 
   XK_TRI_STAMP(2)
+  if (tid == 0) red[15] = T(0);                              // "an iterate was annihilated" flag of step 3
   // ---- 3. inverse iteration (dstein): lane j of wave 0 owns eigenvalue j ---------------------------------
   // coincident eigenvalues get distinct shifts so that their factorizations (and iterates) differ
   const T pfloor = eps * tnorm + pivmin;                     // floor of a pivot's magnitude
@@ -349,6 +350,9 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
         for (int i = lane; i < n; i += 64) nn += zj[i] * zj[i];
         nn = wave_sum_dpp(nn);
         const T inv = nn > T(0) ? rsqrt(nn) : T(0);
+        // a vector annihilated by the Gram-Schmidt step (or non-finite) would pass the residual / overlap checks
+        // below as a zero vector: remember it (red[15] is read with the self-check)
+        if (lane == 0 && !(nn > T(0) && nn < T(INFINITY))) red[15] = T(1);
         for (int i = lane; i < n; i += 64) zj[i] *= inv;
       }
     }
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
     }
     nonfinite = __any(nonfinite) ? 1 : 0;
     if (!(tnorm < T(INFINITY))) nonfinite = 1;
+    if (red[15] != T(0)) nonfinite = 1;                      // zero / non-finite iterate in the last normalisation
     if (lane == 0) {
       const T tol = T(100) * eps * tnorm + T(8) * pivmin;
       info_out[b] = (worst <= tol && !nonfinite) ? 0 : 1;

@@ -119,6 +119,16 @@ def group_status(rmax, info, flag, status):
     check(rc, "xk_group_status")
 
 
+def _check_ritz_shapes(V, AV, Y, lam, X, Tn, k, P):
+    """the kernels take raw pointers: a coefficient block narrower than P would be read past its end"""
+    B = V.shape[0]
+    if Y.dim() != 3 or Y.shape[0] != B or Y.shape[1] < k or Y.shape[2] < P or lam.shape[0] != B or lam.shape[-1] < P:
+        raise _capi.NativeLibraryError("ritz_residual: Y must be (B, >=k, >=P) and lam (B, >=P); got %s / %s for "
+                                       "k = %d, P = %d" % (tuple(Y.shape), tuple(lam.shape), k, P))
+    if V.shape[1] < k or AV.shape[1] < k or X.shape[1] < P or Tn.shape[1] < P:
+        raise _capi.NativeLibraryError("ritz_residual: basis / output panels are smaller than (k, P) = (%d, %d)" % (k, P))
+
+
 def ritz_residual(V, AV, Y, lam, X, Tn, rmax, k, P):
     """Fused K4/K5 (symeig.py:178-188): X = Y^T V, AX = Y^T AV, Tn = -(AX - lam X), rmax[b] = max|AX - lam X|.
 
@@ -128,6 +138,7 @@ def ritz_residual(V, AV, Y, lam, X, Tn, rmax, k, P):
     B, N = V.shape[0], V.shape[2]
     if lam.stride(-1) != 1 and P > 1:
         raise _capi.NativeLibraryError("lam must have unit stride along its last dim")
+    _check_ritz_shapes(V, AV, Y, lam, X, Tn, k, P)
     rc = fn("xk_ritz_residual_" + suffix(V.dtype))(
         ptr(V), ptr(AV), ptr(Y), ptr(lam), ptr(X), ptr(Tn), ptr(rmax), B, k, N, P,
         V.stride(1), V.stride(0), AV.stride(1), AV.stride(0), Y.stride(0), Y.stride(1), Y.stride(2),
@@ -180,6 +191,7 @@ def davidson_ritz(V, AV, Y, lam, X, Tn, rmax, info, flag, status, k, P):
     B, N = V.shape[0], V.shape[2]
     if lam.stride(-1) != 1 and P > 1:
         raise _capi.NativeLibraryError("lam must have unit stride along its last dim")
+    _check_ritz_shapes(V, AV, Y, lam, X, Tn, k, P)
     rc = fn("xk_davidson_ritz_" + suffix(V.dtype))(
         ptr(V), ptr(AV), ptr(Y), ptr(lam), ptr(X), ptr(Tn), ptr(rmax), ptr(info), ptr(flag) if flag is not None else None,
         ptr(status), B, k, N, P, V.stride(1), V.stride(0), AV.stride(1), AV.stride(0), Y.stride(0), Y.stride(1),
@@ -528,7 +540,7 @@ def dense_symm(A, X, out=None):
 # once per process in the benchmark's timed region).  Cross-stream ordering therefore re-records two cached events per
 # issuing stream, and timing events come from a pool that measurement code can pre-fill.
 _SYNC_EVENTS = {}
-_TIMING_POOL = []
+_TIMING_POOL = {}            # device index -> pre-created timing events (events belong to the device they were made on)
 
 
 def sync_events(stream):
@@ -542,8 +554,9 @@ def sync_events(stream):
 
 
 def timing_event_pair():
-    if len(_TIMING_POOL) >= 2:
-        return _TIMING_POOL.pop(), _TIMING_POOL.pop()
+    pool = _TIMING_POOL.get(torch.cuda.current_device())
+    if pool is not None and len(pool) >= 2:
+        return pool.pop(), pool.pop()
     return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
@@ -554,7 +567,7 @@ def prefill_timing_events(n):
     for e in fresh:
         e.record(st)
     st.synchronize()
-    _TIMING_POOL.extend(fresh)
+    _TIMING_POOL.setdefault(torch.cuda.current_device(), []).extend(fresh)
 
 
 def dense_symm_split(A, X, out, tiles_stream, timed=False):

@@ -95,7 +95,8 @@ class _Group:
         # (extension) thick restart: None = never (the reference's ever-growing basis); an int = largest basis
         # width; `keep` Ritz vectors survive a restart
         self.restart = restart
-        self.keep = min(2 * p, K.SMALL_EIGH_MAX_P)
+        # at least the p wanted vectors survive (neig > 16: the small eigensolver then is the library eigh)
+        self.keep = max(p, min(2 * p, K.SMALL_EIGH_MAX_P))
         self._compress = None                     # (Yt (B, pk, k), lam_all (B, pk)) of a pending restart
         self.nrestart = 0
         self.k1_stream = None                     # two-group pipeline: the (CU-masked) stream of the panel products
@@ -366,7 +367,7 @@ def _sub_operator(A, B, N, b0, b1):
 
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
-             min_eps=1e-6, verbose=False, V0=None, orth_passes=2, process_group=None, trace=None,
+             min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
              groups="auto", chain="calls", **unused):
     """
@@ -428,14 +429,20 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     restart: int or None
         (extension) ``None`` (default): the basis grows until convergence, like the reference, which never restarts
         (symeig.py:132-135).  An integer: thick restart — whenever the next expansion would exceed this many basis
-        vectors, the basis is replaced by the ``min(2*neig, 16)`` Ritz vectors nearest the wanted end (the wanted
-        ``neig`` among them) before the new residual block is appended.  Bounds the memory (2 x restart x N per
+        vectors, the basis is replaced by the ``max(neig, min(2*neig, 16))`` Ritz vectors nearest the wanted end (the
+        wanted ``neig`` among them) before the new residual block is appended.  Bounds the memory (2 x restart x N per
         batch member) and keeps the Rayleigh–Ritz matrix inside the LDS-resident eigensolver on slowly converging
         spectra; costs extra iterations.  Must be >= ``3 * neig``.
     V0: tensor or None
         (extension) start block ``(*batch, na, nguess)`` replacing the random draw
-    orth_passes: int
-        (extension) Gram–Schmidt passes of the new panel against the basis (2 = CGS2)
+    orth_passes: int or str
+        (extension) Gram–Schmidt passes of the new panel against the basis.  ``"auto"`` (default): ONE pass when the
+        new directions are the negated residuals (no preconditioner) — a Ritz residual is orthogonal to the basis by
+        construction (``V^T (A X - X lam) = T Y - Y lam = 0``), what one pass removes is the rounding-sized component
+        that forming it left (measured <= 1e-6 of its norm), and "twice is enough" only matters when the first pass
+        cancels most of the vector; the reference does not re-orthogonalise at all (one CholeskyQR of ``[V, t]``,
+        symeig.py:207-220).  Two passes (CGS2) with a preconditioner, whose output has no such property.  An integer
+        forces the number of passes
     process_group: torch.distributed group or None
         (extension) when given, the batch is sharded over the group's ranks and the stopping test
         uses the all-reduced (MAX) residual, so all ranks iterate in lock step (RCCL over xGMI)
@@ -461,10 +468,11 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         restart = int(restart)
         if restart < 3 * p or restart < nguess + p:
             raise ValueError("restart must be at least 3 * neig (and nguess + neig), got %d" % restart)
-    if nguess > 32:
-        raise NativeLibraryError("nguess > 32 is not supported by the native panel Cholesky")
-    if p > 32:
-        raise NativeLibraryError("neig > 32 is not supported by the native davidson")
+    if (nguess > 32 or p > 32) and M is not None:
+        raise NativeLibraryError("neig / nguess > 32 with an overlap operator M is not supported by the native "
+                                 "davidson (the chunked panel orthonormalisation serves M = None)")
+    if orth_passes == "auto":
+        orth_passes = 1 if precond is None else 2
     events = trace.get("k1_events") if trace is not None else None
 
     # ---- batch groups: one, or two pipelined on two streams ---------------------------------
@@ -547,7 +555,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
                          precond=_pc_slice(b0, b1), restart=restart)
             grp.k1_stream = k1_stream
-            grp.fast = (chain != "kernels")
+            # (panels wider than 32 need the chunked orthonormalisation of xk_davidson_orth)
+            grp.fast = (chain != "kernels") or p > 32 or nguess > 32
             if trace is not None and "timeline" in trace:
                 grp.timeline, grp.tag = trace["timeline"], g
             grp.start(V0p[b0:b1])

@@ -137,7 +137,9 @@ class _LowRank:
         """out = g_v * v + g_extra * extra + gamma * (low-rank part of G (or G^T)) v.
         G v = alpha v + sum_n c_n inv_n <v_n, v>;  G^T v = alpha v + sum_n v_n inv_n <c_n, v>."""
         first, second = (self.C, self.D) if transpose else (self.D, self.C)
-        v = v.reshape(-1)
+        v = v.reshape(-1).contiguous()            # the update kernel reads it with unit stride
+        if extra is not None:
+            extra = extra.reshape(-1).contiguous()
         if self.rank == 0:
             return K.broyden_axpy(out, v, g_v, extra, g_extra)
         coef = self._coef(first, v)
@@ -363,6 +365,11 @@ def _line_search(func, x, y, dx, red, phi0, smin=1e-2):
         if state["dx2"] is None:
             p, x2, dx2 = red.dots([(v, v), (xt, xt), (dx, dx)])
             state["dx2"] = dx2
+            if dx2 == 0:
+                # |dx|^2 arrives with the first trial's reduction: raise here, one function evaluation after the
+                # reference would (rootsolver.py:100 tests it before the search), not after a full backtracking
+                raise ValueError("Jacobian inversion yielded zero vector. "
+                                 "This indicates a bug in the Jacobian approximation.")
         else:
             p, x2 = red.dots([(v, v), (xt, xt)])
         state.update(s=s, y=v, x=xt, phi=p, x2=x2)
@@ -432,18 +439,24 @@ def _nonlin_solver(fcn, x0, params, jacobian, maxiter=None, f_tol=None, f_rtol=N
         # a complex unknown is solved as the real vector [Re x; Im x] of twice the length, exactly like the
         # reference (rootsolver.py:52-73): real parts first, then imaginary parts
         def ravel(t):
-            return torch.cat((t.real, t.imag), dim=0).reshape(-1)
+            return torch.cat((t.real, t.imag), dim=0).reshape(-1).contiguous()
 
         def pack(v):
             n = v.numel() // 2
             return torch.complex(v[:n], v[n:]).reshape(xshape)
     else:
         def ravel(t):
-            return t.reshape(-1)
+            # unit stride: the fused reductions / updates take raw pointers (a strided 1-D view such as M[:, 0]
+            # stays strided under reshape)
+            return t.reshape(-1).contiguous()
 
         def pack(v):
             return v.reshape(xshape)
-    func = lambda x: ravel(fcn(pack(x), *params))
+    xdtype = ravel(x0).dtype
+
+    def func(x):
+        out = ravel(fcn(pack(x), *params))
+        return out if out.dtype == xdtype else out.to(xdtype)      # (torch would promote in the reference's dots)
     nfev = [0]
 
     def cfunc(x):
