@@ -63,6 +63,9 @@ def parse():
                     help="auto: upper-triangle kernel when the storage is exactly symmetric; general: full matrix")
     ap.add_argument("--k1s-run", type=int, default=0,
                     help="measurement: column slabs per workgroup run of the upper-triangle kernel (0 = library default)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: run the launcher / process-group / timing / JSON plumbing of the N > 1 path on CPU "
+                         "ranks over gloo with a tiny sharded stand-in step (no performance numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="4x4096", help="BxN of the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -167,10 +170,108 @@ def _k1_roofline(k1_events, N, p, esize, symm, b_local):
     return roof, durs
 
 
+def main_dry(args):
+    """`--dry-run`: everything of the N > 1 path that does not need a GPU, end to end on CPU ranks over gloo — the
+    self-respawn under torch.distributed.run, the rendezvous, the strong / weak shard arithmetic, the fenced timing
+    with its MAX all-reduce, the weak-scaling extra and rank 0's single JSON line.  The step is a stand-in: the
+    product's batch-sharded quasi-Newton driver (linear mixing: global SUM all-reduces, needs no device kernel) on a
+    tiny tanh system.  No number in the line is a measurement (`value` is null)."""
+    import torch.distributed as dist
+    from xitorch_amd import dist as xd, synthetic
+    from xitorch_amd.optimize import native_root as nr
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.set_num_threads(1)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (gloo reports its connections on the C-level stdout: same fd 1 -> fd 2 detour as for RCCL's banner below)
+        import ctypes
+        libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            libc.fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+        group = dist.group.WORLD
+
+    def fcn(y, A):
+        return torch.tanh(torch.einsum("bij,bj->bi", A, y) + 0.1) + y / 2.0
+
+    def run(b_local, offset, steps, warmup):
+        A = synthetic.root_matrix(offset + b_local, 24)[offset:offset + b_local] * 2.0
+        y0 = torch.zeros((b_local, 24), dtype=torch.float64)
+        tr = {}
+
+        def step():
+            return nr.linearmixing(fcn, y0, (A,), alpha=-1.0, f_tol=1e-10, x_tol=1e-10, maxiter=400,
+                                   process_group=group, trace=tr)
+        for _ in range(warmup):
+            step()
+        if group is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = step()
+        if group is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if group is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = tt.item()
+        return elapsed, fcn(y, A).abs().max().item(), tr
+
+    def shard(scaling):
+        if scaling == "weak":
+            return args.batch, args.batch * world, rank * args.batch
+        lo, hi = xd.shard_range(args.batch, world, rank)          # uneven batches allowed here (the GPU job asserts)
+        return hi - lo, args.batch, lo
+
+    b_local, b_total, offset = shard(args.scaling)
+    elapsed, fmax, tr = run(b_local, offset, args.steps, args.warmup)
+    weak_extra = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak_extra:
+        wl, wt, woff = shard("weak")
+        w_el, _, _ = run(wl, woff, 2, 1)
+        weak_extra = {"scaling": "weak", "value": None, "ms_per_step": w_el / 2 * 1e3, "global_batch": wt,
+                      "batch_per_gpu": wl, "steps": 2, "warmup": 1}
+    # every rank ran the same number of iterations (the whole batch is one flat system)
+    nit = torch.tensor([float(tr["niter"]), -float(tr["niter"])], dtype=torch.float64)
+    if group is not None:
+        dist.all_reduce(nit, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "eigpairs/sec of symeig(davidson) + Lanczos-role matvec GB/s (roofline.achieved), batch=64 N=16384",
+            "dry_run": True, "value": None, "unit": "eigpairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "DRY RUN on CPU ranks (gloo): sharded linear-mixing root solve, tanh system 24 "
+                                   "unknowns x %d members; plumbing only, no measurement" % b_total,
+                       "global_batch": b_total, "batch_per_gpu": b_local,
+                       "parallelism": "batch-sharded x%d (%s)" % (world, args.scaling),
+                       "comm_backend": dist.get_backend(group) if group is not None else None,
+                       "comm_world_size": dist.get_world_size(group) if group is not None else 1},
+            "roofline": None, "weak_extra": weak_extra,
+            "check": {"ok": bool(fmax < 1e-8 and nit[0].item() == -nit[1].item()), "max_abs_f": fmax,
+                      "iterations": int(nit[0].item())}}), flush=True)
+    if group is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         _respawn(args)
+    if args.dry_run:
+        return main_dry(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -112,3 +112,65 @@ def test_world_size_2_gloo():
     assert results[0]["stops"] == results[1]["stops"]
     expect = [max(a, b) for a, b in zip(results[0]["own_hist"], results[1]["own_hist"])]
     assert results[0]["stops"] == expect
+
+
+def _worker8(rank, world, port, results):
+    """world_size 8 on an UNEVEN batch (13 members: shards of 2,2,2,2,2,1,1,1): the sharded quasi-Newton driver against
+    the unsharded one, and the Davidson stopping rule completed by the MAX all-reduce."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from xitorch_amd import dist as xd, synthetic
+        from xitorch_amd.optimize import native_root as nr
+        from oracle import ops as oops, symeig as osym
+        grp = dist.group.WORLD
+        out = {}
+        nb, n = 13, 10
+        out["span"] = xd.shard_range(nb, world, rank)
+        lo, hi = out["span"]
+        fcn, y0, (A,) = cases.root_inputs(dict(kind="tanh", nbatch=nb, n=n))
+        tr_s, tr_f = {}, {}
+        y_shard = nr.linearmixing(fcn, y0[lo:hi], (A[lo:hi],), alpha=-1.0, f_tol=1e-10, x_tol=1e-10, maxiter=400,
+                                  process_group=grp, trace=tr_s)
+        y_full = nr.linearmixing(fcn, y0, (A,), alpha=-1.0, f_tol=1e-10, x_tol=1e-10, maxiter=400, trace=tr_f)
+        out["root_err"] = (y_shard - y_full[lo:hi]).abs().max().item()
+        out["root_iters"] = (tr_s["niter"], tr_f["niter"], tr_s["nfev"], tr_f["nfev"])
+        # Davidson: the unsharded run's iteration count must be what the all-reduced shard residuals dictate
+        B, N = 13, 64
+        mat = synthetic.dense_symmetric(B, N, "S1")
+        trf, trs = {}, {}
+        osym.davidson(oops.DenseOp(mat, True), 2, "lowest", min_eps=1e-8, trace=trf)
+        osym.davidson(oops.DenseOp(mat[lo:hi].contiguous(), True), 2, "lowest", min_eps=0.0,
+                      max_niter=trf["niter"], trace=trs)
+        hist = list(trs["resid_history"][:trf["niter"]])
+        hist += [0.0] * (trf["niter"] - len(hist))           # a shard whose basis became square stops early
+        st = torch.tensor(hist, dtype=torch.float64)
+        xd.allreduce_max_(st, grp)
+        out["stops"] = st.tolist()
+        out["own_hist"] = hist
+        out["full_niter"] = trf["niter"]
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world_size_8_gloo_uneven_shards():
+    world = 8
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker8, args=(world, port, results), nprocs=world, join=True)
+    assert len(results) == world
+    sizes = [results[r]["span"][1] - results[r]["span"][0] for r in range(world)]
+    assert sizes == [2, 2, 2, 2, 2, 1, 1, 1] and results[7]["span"][1] == 13
+    for r in range(world):
+        assert results[r]["root_err"] < 1e-12
+        it = results[r]["root_iters"]
+        assert it[0] == it[1] and it[2] == it[3]
+        assert results[r]["stops"] == results[0]["stops"]
+    expect = [max(results[r]["own_hist"][i] for r in range(world)) for i in range(results[0]["full_niter"])]
+    assert results[0]["stops"] == expect
