@@ -101,15 +101,82 @@ def cpu_baseline(args):
     t = sorted(times)[len(times) // 2]
     s = 8
     k1_bytes = tr["napply"] * (b * n * n * s + 2 * b * n * args.neig * s)
-    return {"value": b * args.neig / t, "unit": "eigpairs/s", "cores": cores, "kind": "port",
-            "sample": "oracle davidson (torch-CPU restatement of the reference), dense symmetric %s, batch=%d "
-                      "N=%d fp64 neig=%d min_eps=%g, median of %d runs (%.2f s each, %d iterations); "
-                      "full config does not fit host RAM" % (args.spectrum, b, n, args.neig, args.min_eps,
-                                                             len(times), t, tr["niter"]),
-            "seconds": t, "matvec_GBps": k1_bytes / t / 1e9, "threads": torch.get_num_threads(),
-            "physical_cores": physical, "logical_cpus": logical,
-            "note": "cores = threads actually used (torch-CPU collapses when oversubscribed on these skinny "
-                    "products); the box has physical_cores / logical_cpus"}
+    out = {"value": b * args.neig / t, "unit": "eigpairs/s", "cores": cores, "kind": "port",
+           "sample": "oracle davidson (torch-CPU restatement of the reference), dense symmetric %s, batch=%d "
+                     "N=%d fp64 neig=%d min_eps=%g, median of %d runs (%.2f s each, %d iterations); "
+                     "full config does not fit host RAM" % (args.spectrum, b, n, args.neig, args.min_eps,
+                                                            len(times), t, tr["niter"]),
+           "seconds": t, "matvec_GBps": k1_bytes / t / 1e9, "threads": torch.get_num_threads(),
+           "physical_cores": physical, "logical_cpus": logical,
+           "note": "cores = threads actually used (torch-CPU collapses when oversubscribed on these skinny "
+                   "products); the box has physical_cores / logical_cpus"}
+    del mat, op
+    # ---- BASELINE configs[0] exactly: N=512, batch=1, lowest 6, fp64 — the reference's CPU
+    # case, `davidson` and `exacteig`, with the native call on the GPU beside it
+    try:
+        from tests import cases as _cases
+        from oracle.symeig import exacteig as _oexact
+        m1 = _cases.random_symmetric(512, -1.0, 1.0, 123)
+        op1 = oops.DenseOp(m1, True)
+
+        def med(f, nmin=3, budget=4.0):
+            ts, t_all = [], time.time()
+            while len(ts) < nmin or (time.time() - t_all < budget and len(ts) < 50):
+                t0 = time.time()
+                r = f()
+                ts.append(time.time() - t0)
+            return sorted(ts)[len(ts) // 2], r
+        t_dav, (ev_d, _) = med(lambda: osym.davidson(op1, 6, "lowest", min_eps=1e-8))
+        t_ex, (ev_x, _) = med(lambda: _oexact(op1, 6, "lowest", None))
+        c1 = {"workload": "BASELINE configs[0]: symeig lowest-6, dense symmetric N=512 batch=1 fp64 "
+                          "(benchmarks_solve.py shape), oracle on %d CPU threads" % cores,
+              "cpu_davidson_ms": t_dav * 1e3, "cpu_exacteig_ms": t_ex * 1e3,
+              "cpu_davidson_eigpairs_per_s": 6 / t_dav, "cpu_exacteig_eigpairs_per_s": 6 / t_ex,
+              "max_abs_diff_davidson_vs_exacteig": (ev_d - ev_x).abs().max().item()}
+        if torch.cuda.is_available():
+            from xitorch_amd import LinearOperator as _LO
+            from xitorch_amd.linalg import symeig as _symeig
+            Ag = _LO.m(m1.cuda(), is_hermitian=True)
+
+            def gpu_call():
+                with torch.no_grad():
+                    r = _symeig(Ag, neig=6, mode="lowest", method="davidson", min_eps=1e-8)
+                torch.cuda.synchronize()
+                return r
+            gpu_call()
+            t_g, (ev_g, _) = med(gpu_call, nmin=5, budget=2.0)
+            c1.update(gpu_davidson_ms=t_g * 1e3, gpu_davidson_eigpairs_per_s=6 / t_g,
+                      max_abs_diff_gpu_vs_cpu_exacteig=(ev_g.cpu() - ev_x).abs().max().item(),
+                      gpu_note="one 512 x 512 operator: latency-bound (a few dozen small launches per iteration), "
+                               "not what the GPU path is built for")
+        out["config1_n512_b1"] = c1
+    except Exception as err:                    # a baseline extra never costs the headline line
+        out["config1_n512_b1"] = {"error": repr(err)}
+    # ---- the K1 panel product alone on the CPU at the metric's N, largest batch that fits host RAM comfortably
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+        n1 = args.n
+        bk = int(max(1, min(4, (avail * 0.25) // (n1 * n1 * 8))))
+        matk = synthetic.dense_symmetric(bk, n1, args.spectrum)
+        xk_ = torch.randn(bk, n1, args.neig, dtype=torch.float64)
+        torch.matmul(matk, xk_)
+        ts = []
+        t_all = time.time()
+        while len(ts) < 3 or (time.time() - t_all < 5.0 and len(ts) < 20):
+            t0 = time.time()
+            torch.matmul(matk, xk_)
+            ts.append(time.time() - t0)
+        tk = sorted(ts)[len(ts) // 2]
+        kb = bk * n1 * n1 * 8 + 2 * bk * n1 * args.neig * 8
+        out["k1_product_cpu"] = {"workload": "torch.matmul(mat (%d, %d, %d), x (.., %d)) fp64 = the reference's "
+                                             "MatrixLinearOperator._mm (linop.py:695-696)" % (bk, n1, n1, args.neig),
+                                 "ms": tk * 1e3, "GBps": kb / tk / 1e9, "threads": torch.get_num_threads(),
+                                 "bytes": kb, "note": "batch bounded by host RAM (a quarter of what is available)"}
+        del matk
+    except Exception as err:
+        out["k1_product_cpu"] = {"error": repr(err)}
+    return out
 
 
 def _respawn(args):
