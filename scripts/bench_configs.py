@@ -69,9 +69,9 @@ def c4(B=64, N=8192):
             "fnorm": fcn(y, Ad).norm().item()}
 
 
-def c5(B=16, N=32768, p=6):
+def c5(B=16, N=32768, p=6, kind="S1"):
     mat = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-    syn.dense_symmetric(B, N, "S1", dtype=torch.float32, device=dev, out=mat)
+    syn.dense_symmetric(B, N, kind, dtype=torch.float32, device=dev, out=mat)
     A = xa.LinearOperator.m(mat, is_hermitian=True)        # the symmetry scan finds exactly symmetric storage -> K1s
     ev = []
     for i in range(2):
@@ -84,11 +84,19 @@ def c5(B=16, N=32768, p=6):
     ms = [a.elapsed_time(b) for (a, b, pc, nb) in ev if pc == p]
     nbl = [nb for (a, b, pc, nb) in ev if pc == p][0]              # operators per launch (half the batch when pipelined)
     k1b = nbl * N * N * 4 + 2 * nbl * N * p * 4
-    exact = syn.spectrum("S1", N, device=dev)[:p]
-    return {"config": "c5 symeig fp32 per-GPU shard (16 x 32768^2)", "B": B, "N": N, "ms": t * 1e3, "niter": tr["niter"],
-            "panel_kernel": "K1s (upper triangle)" if getattr(A, "symmetric_storage", False) else "K1 general",
-            "eigpairs_per_s": B * p / t, "operators_per_launch": nbl, "k1_ms": sum(ms) / len(ms), "k1_GBps": k1b / (sum(ms) / len(ms)) / 1e6,
+    exact = syn.spectrum(kind, N, device=dev)[:p]
+    k1ms = sum(ms) / len(ms)
+    return {"config": "c5 symeig fp32 per-GPU shard (16 x 32768^2), %d-column eigen-block, spectrum %s" % (p, kind),
+            "B": B, "N": N, "p": p, "ms": t * 1e3, "niter": tr["niter"], "panel_kernel": tr.get("panel_kernel"),
+            "eigpairs_per_s": B * p / t, "operators_per_launch": nbl, "k1_ms": k1ms,
+            "k1_GBps_full_matrix_bytes": k1b / k1ms / 1e6, "k1_frac_of_8TBps_full_matrix_bytes": k1b / k1ms / 1e6 / 8000.0,
+            "k1_TFLOPs": 2.0 * nbl * N * N * p / (k1ms * 1e-3) / 1e12,
             "max_eval_err": (evals.double() - exact).abs().max().item()}
+
+
+def c5w():
+    """configs[4] as stated: fp32, 16-column eigen-block -> the MFMA wide-panel kernel K1w inside symeig"""
+    return c5(p=16, kind="S1:16")
 
 
 def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000):
@@ -124,7 +132,7 @@ if __name__ == "__main__":
                 _, spec, rs = name.split(":")
                 r = c2_hard(spec, int(rs) if int(rs) > 0 else None)
             else:
-                r = {"c3": c3, "c4": c4, "c5": c5}[name]()
+                r = {"c3": c3, "c4": c4, "c5": c5, "c5w": c5w}[name]()
         except Exception as e:      # keep going: this is a measurement script
             r = {"config": name, "error": repr(e)}
         print(json.dumps(r), flush=True)

@@ -188,6 +188,37 @@ def test_fullsize_config5_shard_fp32_symeig(dev):
 
 
 @pytest.mark.timeout(900)
+def test_fullsize_config5_shard_fp32_wide_panel_on_the_matrix_cores(dev):
+    """BASELINE configs[4] AS STATED ("fp32, MFMA A@V panel"): the per-GPU shard 16 x 32768^2 fp32 with a 16-column
+    eigen-block (neig = nguess = 16), so that every operator-panel product of the eigensolver goes through K1w — the
+    wide-panel kernel on the matrix cores (v_mfma_f32_32x32x2_f32, xk_wide.hip) — inside the two-group pipeline.
+    Eigenvalues against the closed form at fp32 accuracy, residual identity, orthonormality."""
+    B, N, p = 16, 32768, 16
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80e9:
+        pytest.skip("needs ~70 GB of free HBM")
+    mat = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    syn.dense_symmetric(B, N, "S1:16", dtype=torch.float32, device=dev, out=mat)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    tr = {}
+    with torch.no_grad():
+        ev, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=2e-3, rng_device="device", max_niter=60,
+                       trace=tr)
+    assert ev.dtype == torch.float32 and tr["stop_reason"] == "converged"
+    assert tr["panel_kernel"] == "K1w", tr["panel_kernel"]
+    exact = syn.spectrum("S1:16", N, device=dev)[:p]
+    assert (ev.double() - exact).abs().max().item() <= 1e-3
+    Xp = X.transpose(-2, -1).contiguous()
+    AX = K.dense_mm(mat, Xp)
+    assert (AX - Xp * ev.unsqueeze(-1)).abs().max().item() <= 3e-2
+    G = torch.matmul(Xp, Xp.transpose(-2, -1))
+    assert (G - torch.eye(p, device=dev)).abs().max().item() <= 1e-4
+    del mat
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
 def test_fullsize_config4_shard_rootfinder_backward(dev):
     """The per-GPU shard of BASELINE configs[3] (64 x 8192^2 fp64 = 34.4 GB of operators, f(y) = tanh(A y + 0.1) + y/2,
     batch 512 over 8 GPUs): the Broyden root, and the implicit gradient of sum(y) w.r.t. A (BiCGStab on the

@@ -434,9 +434,20 @@ def test_wide_blocks_neig40_and_restart_neig20(dev):
     """No width cliff: neig = 40 > 32 goes through the chunked panel orthonormalisation
     (the reference has no limit: symeig.py:100-140); thick restart with 16 < neig <= 32 keeps at least the wanted
     vectors.  Both against the dense eigendecomposition."""
-    from xitorch_amd import synthetic
-    mat = synthetic.dense_symmetric(2, 1536, "S1", dtype=torch.float64, device=dev)
-    mat = mat + torch.diag_embed(torch.linspace(0.0, 3.0, 1536, dtype=torch.float64, device=dev)).unsqueeze(0)
+    # 48 separated eigenvalues at each end of the spectrum (so that 40 wanted pairs converge long before the basis is
+    # square), the rest in a band in between; dense through a Householder similarity, symmetrised exactly
+    N = 1536
+    d = torch.cat([torch.arange(1.0, 49.0, dtype=torch.float64),
+                   200.0 + 100.0 * torch.arange(N - 96, dtype=torch.float64) / (N - 96),
+                   400.0 + torch.arange(1.0, 49.0, dtype=torch.float64)]).to(dev)
+    mats = []
+    for b in range(2):
+        w = torch.sin(0.37 * torch.arange(1, N + 1, dtype=torch.float64, device=dev) + 0.11 * b) + 1.5
+        w = w / w.norm()
+        Dw = d * w
+        m = torch.diag(d) - 2.0 * torch.outer(w, Dw) - 2.0 * torch.outer(Dw, w) + 4.0 * (w @ Dw) * torch.outer(w, w)
+        mats.append((m + m.T) * 0.5)
+    mat = torch.stack(mats)
     A = xa.LinearOperator.m(mat, is_hermitian=True)
     lam_all = torch.linalg.eigvalsh(mat)
     tr = {}

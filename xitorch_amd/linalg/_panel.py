@@ -39,6 +39,7 @@ class PanelOperator:
         self.kind = "generic"
         self.symm = False
         self.napply = 0
+        self.last_kernel = None     # which panel kernel served the last native apply (K1s / K1w / K1wr / K1 / banded)
         self.events = None          # when a list: (start, end, p) HIP events around every native launch
         self.hermitian = bool(getattr(A, "is_hermitian", False))
         nA = 1
@@ -110,6 +111,7 @@ class PanelOperator:
         N = self.N
         if self.kind == "dense" and self.symm and X.shape[1] <= 6 and not self.flip:
             self.napply += 1
+            self.last_kernel = "K1s"
             e0, e1 = K.dense_symm_split(self.mat, X[:, :, :N], out[:, :, :N], k1_stream,
                                         timed=self.events is not None)
             if self.events is not None:
@@ -133,6 +135,7 @@ class PanelOperator:
                                adjoint=(self.flip != trans), conj_io=(self.flip != self.cj), out=out[:, :, :N])
             return out
         if self.kind == "dense" and self.symm and X.shape[1] < K.WIDE_MIN_P:
+            self.last_kernel = "K1s"
             K.dense_symm(self.mat, X[:, :, :N], out=out[:, :, :N])
         elif self.kind == "dense":
             t = (trans != self.flip)
@@ -144,7 +147,16 @@ class PanelOperator:
                 t = True
             # (many columns in the ROW orientation — A X, non-Hermitian A — go to K1wr inside dense_mm: one pass over
             # the operator per 32 columns, no transposed copy)
-            K.dense_mm(self.mat, X[:, :, :N], out=out[:, :, :N], trans=t)
+            Xn = X[:, :, :N]
+            wide = Xn.shape[1] >= K.WIDE_MIN_P
+            if t:
+                mat3 = self.mat
+                self.last_kernel = "K1w" if wide and K._wide_ok(mat3, mat3.shape[-1], mat3.stride(-2),
+                                                                mat3.stride(0) if mat3.dim() == 3 else 0) else "K1"
+            else:
+                self.last_kernel = "K1wr" if wide else "K1"
+            K.dense_mm(self.mat, Xn, out=out[:, :, :N], trans=t)
         else:
+            self.last_kernel = "banded"
             K.banded_mm(self.band, X[:, :, :N], out=out[:, :, :N], trans=trans)
         return out

@@ -650,7 +650,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     if trace is not None:
         trace.update(niter=niter, napply=sum(op.napply for op in ops) // G, resid_history=history,
                      basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G,
-                     k3_fallbacks=n_fallback[0], restarts=groups[0].nrestart)
+                     k3_fallbacks=n_fallback[0], restarts=groups[0].nrestart, panel_kernel=ops[0].last_kernel)
     evals = evals.reshape(*bdims, p)
     evecs = Xall[:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
     return evals, evecs

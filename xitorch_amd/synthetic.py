@@ -16,14 +16,16 @@ def spectrum(kind, n, dtype=torch.float64, device="cpu"):
     """Exact eigenvalues D_i, i = 0..n-1, of the synthetic dense operators.
 
     S1 "clustered": 6 isolated low eigenvalues 1..6 then a band [50, 100]   (primary, eigpairs/s)
+    S1:m   the same with m isolated low eigenvalues 1..m ("S1:16": a 16-column eigen-block, configs[4]'s MFMA panel)
     S2: sqrt(i+1)                                                           (stress)
     S3: i + 0.5 sin(i)                                                      (slow convergence)
     """
     i = torch.arange(n, dtype=dtype, device=device)
     kind = kind.upper()
-    if kind == "S1":
-        d = 50.0 + 50.0 * (i - 6.0) / max(n - 7, 1)
-        return torch.where(i < 6, i + 1.0, d)
+    if kind == "S1" or kind.startswith("S1:"):
+        m = 6 if kind == "S1" else int(kind[3:])
+        d = 50.0 + 50.0 * (i - float(m)) / max(n - m - 1, 1)
+        return torch.where(i < m, i + 1.0, d)
     if kind == "S2":
         return torch.sqrt(i + 1.0)
     if kind == "S3":
