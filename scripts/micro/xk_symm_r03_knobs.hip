@@ -1,0 +1,668 @@
+// xitorch_amd :: K1s — operator-panel product for EXACTLY symmetric dense storage, reading only the
+// upper triangle:   Y[b,c,:] = A_b X[b,c,:],  A_b = A_b^T.
+//
+// The general K1 (xk_dense.hip) streams all N^2 elements per panel product.  A symmetric matrix
+// carries every off-diagonal value twice, so here each tile on/above the diagonal is read ONCE
+// and used for both of its contributions
+//        y_I += A_IJ x_J      (row part)          y_J += A_IJ^T x_I     (column part)
+// which halves the HBM traffic of the eigensolver's panel product (symeig operators are always
+// Hermitian: xitorch/linalg/symeig.py:103; the product itself: _impls/linalg/symeig.py:163,221).
+// Opt-in: the caller asserts exact symmetry of the storage (LinearOperator.m verifies it bit for
+// bit, linop.py:97-105 in the reference only checks allclose); anything else takes the general kernel.
+//
+// Mapping (round 3).  Tiles of TRH = 1024 rows x SLAB columns (1024 fp64 / 2048 fp32) on/above the
+// diagonal.  One 256-thread block owns a RUN of up to L consecutive tiles of one row tile (same rows,
+// adjacent column slabs); its 4 waves own 4 x WCOLS columns of the current slab (lane: two 16 B vectors,
+// so every load instruction is a contiguous 1 KB) and walk down rows in chunks of 8 through a ring of
+// 8 rows per wave (16 buffer loads = 16 KB always in flight: descriptor + loop-invariant lane offset +
+// scalar row/column offset, no 64-bit vector address arithmetic).  The ring never drains inside a run:
+// the last chunk of a row range refills it with the first rows of the wave's next range, which may
+// belong to the next tile.
+//   * column part: per-lane register accumulators acc_col[NU][P] over the tile (panel values x_I are
+//     wave-uniform scalar loads), flushed once per tile to the column partials colP[I][c][j];
+//   * row part: per-lane products a[r]*x_J, folded across the 64 lanes by an eager transposing tree
+//     (half-exchange swaps, then DPP partner exchanges), then added into an LDS accumulator
+//     rowacc[1024][P] that lives for the whole run: one row partial rowP[slot][c][i] per RUN.
+//   * DETERMINISTIC accumulation (round 3): the four waves never add into the same accumulator rows at
+//     the same time.  A tile is processed in four phases separated by block barriers; in phase q wave w
+//     works on row quarter (w + q) mod 4, so every accumulator entry receives its four waves'
+//     contributions in a fixed order (phase order) and every wave's own contributions in program
+//     order.  Two runs of the same launch give bit-identical results (round 2 let the LDS float atomics
+//     of the four waves race).  `s_barrier` does not drain vector memory (the ring stays in flight).
+//   * a fold kernel adds, for every output element, exactly the partial slots that exist, in fixed order:
+//        y[c][n] = sum_{slot < runs(n>>10)} rowP[slot][c][n] + sum_{I <= Imax(n)} colP[I][c][n].
+//   Quarters that reach the diagonal mask the strictly-lower elements (and count the diagonal once);
+//   a wave skips quarters that lie entirely below its columns.  Lanes past the last column of a ragged
+//   matrix read through an out-of-range offset (the hardware bounds check returns zeros).
+//
+// Register budget (fp64, P=6): ~200 VGPRs -> 2 waves per SIMD; the panel/accumulator registers (96)
+// cannot be shared between waves, so a third wave (<=168 VGPRs) is out of reach and the ring depth is
+// what keeps enough bytes in flight.
+//
+// Traffic per launch: B*N^2*s/2 (+2 % for the diagonal tiles) + B*(NT + NS/L)*P*N*s of partials written
+// and read once — vs B*N^2*s for the general kernel.
+#include "xk_common.h"
+
+namespace xk {
+
+constexpr int SYMM_TRH = 1024;   // rows per tile
+constexpr int SYMM_QR = 256;     // rows per quarter (phase granularity of the deterministic accumulation)
+constexpr int SYMM_NU = 2;       // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
+constexpr int SYMM_R = 8;        // rows per chunk == ring depth
+
+// build knob (A/B, scripts/k1s_build_ab.sh): when a consumed ring slot is re-issued — 0: per row pair (round 2),
+// 1: per row, 2: per 16 B vector.  A slot is idle from the arrival of its data until its re-issue; the finer the
+// re-issue, the shorter that is (the wave spends ~100 cycles of FMAs per vector, ~400 per row pair).
+#ifndef XK_SYMM_REFILL
+#define XK_SYMM_REFILL 0
+#endif
+// measurement only (-DXK_SYMM_NOBAR): drop the phase barriers — the accumulation order is then no longer fixed;
+// tells what the barriers cost
+#ifdef XK_SYMM_NOBAR
+#define XK_SYMM_PHASE_BARRIER() ((void)0)
+#else
+#define XK_SYMM_PHASE_BARRIER() __syncthreads()
+#endif
+
+// The operator rows of a run are read through ONE buffer descriptor (base = first row of the row tile,
+// wave-uniform): every load is  descriptor + per-lane column offset (one VGPR, loop-invariant) + scalar
+// (row, slab) offset.  aux = 2: non-temporal (the operator is touched once per product).
+typedef __amdgpu_buffer_rsrc_t TileRsrc;
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+constexpr unsigned SYMM_OOR = 0x7ffffff0u;     // beyond any descriptor range: returns zeros, moves no data
+
+template <typename VT>
+__device__ __forceinline__ VT ld_tile(const TileRsrc rsrc, unsigned lane_off, unsigned s_off) {
+  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)s_off, 2);
+  return __builtin_bit_cast(VT, raw);
+}
+
+template <typename T>
+__device__ __forceinline__ TileRsrc make_tile_rsrc(const T* tile_base, long bytes) {
+  const uint64_t v = reinterpret_cast<uint64_t>(tile_base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  void* base = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0x7fffffe0L ? 0x7fffffe0L : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)nrec, 0x00020000);
+}
+
+// Where the ring is refilled from while a chunk is consumed (everything wave-uniform but `loff`):
+// the chunk one ring depth ahead in the wave's sequence — usually the next 8 rows of the same range,
+// at the end of a range the first rows of the wave's next range (next phase, or next tile of the run).
+struct SymmNext {
+  int row;          // first row of that chunk (absolute)
+  int last;         // last row of its range: rows past it re-read this one (masked when consumed)
+  int col0;         // first column of its tile
+  int diag;         // its range reaches the diagonal: lanes strictly below the row fetch nothing
+};
+
+// ---------------------------------------------------------------------------------------------
+// 8-row chunk.  The row sums are folded EAGERLY so that the 48 partial sums never coexist:
+//   rows (2h, 2h+1)  -> half-exchange over lane bit 5      (6 values per row pair)
+//   row pairs        -> half-exchange over lane bit 4      (6 values per 4 rows)
+//   the two 4-groups -> select + xor-8 exchange            (6 values per 8 rows)
+//   panel columns    -> (even P) select + xor-4 exchange, then xor-2 / xor-1 butterflies
+// afterwards lane l holds, for row r = 4*bit3 + 2*bit4 + bit5 of the chunk, the complete sums of
+// columns c = 2w + bit2 (w < P/2); lanes with bits 1,0 clear add them into the LDS accumulator
+// (ds_add_f64/f32: a single wave owns these accumulator rows during the phase, see above).
+// DIAG: the chunk's rows reach the wave's columns (mask strictly-lower elements, diagonal once).
+// TAIL: the chunk is the ragged end of its range (rows >= i_end are masked).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int P, bool DIAG, bool TAIL>
+__device__ __forceinline__ void symm_chunk8(
+    typename Vec16<T>::type (&a)[SYMM_R][SYMM_NU], const TileRsrc Ab, const T* __restrict__ Xb, unsigned ldab,
+    long ldx, int i0, int i_end, int row_tile0, int col0, int N, const int (&jj)[SYMM_NU], const SymmNext nx,
+    typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
+    T* rowacc, int lane) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int R = SYMM_R, NU = SYMM_NU;
+  const int i_last = i_end - 1;
+  const unsigned ncoloff = (unsigned)nx.col0 * (unsigned)sizeof(T);
+  // per-lane byte offset inside a row of the successor's tile; lanes past the last column of a ragged matrix get
+  // an offset beyond the descriptor's range (the hardware bounds check returns zeros: no branch, no select later)
+  unsigned nloff[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    nloff[u] = (jj[u] - col0 + nx.col0 < N) ? (unsigned)(jj[u] - col0) * (unsigned)sizeof(T) : SYMM_OOR;
+  T L2[2][P];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    T L1[2][P];
+    // the panel values of a row group are fetched when the group starts (not all 8 rows up front: 96 SGPRs)
+    if (g > 0) asm volatile("" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      T xi[P][2];
+#pragma unroll
+      for (int c = 0; c < P; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          int row = i0 + 4 * g + 2 * h + q;
+          if (TAIL) row = row < i_last ? row : i_last;
+          xi[c][q] = Xb[(long)c * ldx + row];
+        }
+      T s[2][P];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = 4 * g + 2 * h + q;
+        const int row = i0 + r;
+        // where slot r of the ring is re-issued from: the row one ring depth ahead in the wave's sequence
+        int nrow = nx.row + r;
+        nrow = nrow < nx.last ? nrow : nx.last;
+        const unsigned soff = (unsigned)(nrow - row_tile0) * ldab + ncoloff;
+        // (diagonal ranges: a lane whose columns all lie strictly below the row fetches nothing — its values
+        //  would be masked to zero anyway; the out-of-range offset returns the zeros without the traffic)
+        const int thr = nx.diag ? nrow - nx.col0 - (VN - 1) + col0 : -0x40000000;
+#pragma unroll
+        for (int c = 0; c < P; ++c) s[q][c] = T(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          VT ar = a[r][u], ac = a[r][u];
+          if (DIAG) {
+#pragma unroll
+            for (int v = 0; v < VN; ++v) {
+              if (jj[u] + v < row) { ar[v] = T(0); ac[v] = T(0); }
+              if (jj[u] + v == row) ac[v] = T(0);
+            }
+          }
+          if (TAIL) {
+            if (row >= i_end) {
+#pragma unroll
+              for (int v = 0; v < VN; ++v) { ar[v] = T(0); ac[v] = T(0); }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < P; ++c)
+#pragma unroll
+            for (int v = 0; v < VN; ++v) {
+              acc_col[u][c][v] += ac[v] * xi[c][q];
+              s[q][c] += ar[v] * xJ[u][c][v];
+            }
+#if XK_SYMM_REFILL == 2
+          // the products of this vector are issued: pin them above the re-issue of its ring slot
+#pragma unroll
+          for (int c = 0; c < P; ++c) { asm volatile("" : "+v"(acc_col[u][c])); asm volatile("" : "+v"(s[q][c])); }
+          a[r][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#if XK_SYMM_REFILL == 1
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int c = 0; c < P; ++c) { asm volatile("" : "+v"(acc_col[u][c])); asm volatile("" : "+v"(s[q][c])); }
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          a[r][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+#pragma unroll
+      for (int c = 0; c < P; ++c) L1[h][c] = swap_add32(s[0][c], s[1][c]);
+      // the column sums of this row pair must be complete here: without the pin the optimiser sinks all
+      // of them below the reduction, which keeps the whole 8-row chunk of matrix data live until then
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int c = 0; c < P; ++c) asm volatile("" : "+v"(acc_col[u][c]));
+#if XK_SYMM_REFILL == 0
+      // rolling prefetch: the two rows just consumed are refilled with the rows one ring depth ahead in the
+      // wave's sequence, so the wave always has ~6 row pairs of loads in flight while it computes.  Issued on
+      // every path (a range without successor refills through the out-of-range offset: no data moves), so the
+      // compiler's vmcnt bookkeeping stays exact.
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int row = nx.row + 4 * g + 2 * h + q;
+        row = row < nx.last ? row : nx.last;
+        const unsigned soff = (unsigned)(row - row_tile0) * ldab + ncoloff;
+        const int thr = nx.diag ? row - nx.col0 - (VN - 1) + col0 : -0x40000000;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);      // keep the row pairs in program order (bounded live ranges)
+    }
+#pragma unroll
+    for (int c = 0; c < P; ++c) L2[g][c] = swap_add16(L1[0][c], L1[1][c]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  T L3[P];
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const T keep = hi ? L2[1][c] : L2[0][c];
+      const T send = hi ? L2[0][c] : L2[1][c];
+      L3[c] = keep + lane_partner<8>(send);
+    }
+  }
+  const int r = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+  const int lrow = i0 + r - row_tile0;
+  const bool rowok = !TAIL || (i0 + r < i_end);
+  if (P % 2 == 0) {
+    constexpr int PH = P / 2 > 0 ? P / 2 : 1;
+    T L4[PH];
+    const bool hi = (lane & 4) != 0;
+#pragma unroll
+    for (int w = 0; w < P / 2; ++w) {
+      const T keep = hi ? L3[2 * w + 1] : L3[2 * w];
+      const T send = hi ? L3[2 * w] : L3[2 * w + 1];
+      L4[w] = keep + lane_partner<4>(send);
+    }
+#pragma unroll
+    for (int w = 0; w < P / 2; ++w) {
+      L4[w] += lane_partner<2>(L4[w]);
+      L4[w] += lane_partner<1>(L4[w]);
+    }
+    if ((lane & 3) == 0 && rowok) {
+#pragma unroll
+      for (int w = 0; w < P / 2; ++w)
+        __hip_atomic_fetch_add(&rowacc[lrow * P + 2 * w + (hi ? 1 : 0)], L4[w], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      L3[c] += lane_partner<4>(L3[c]);
+      L3[c] += lane_partner<2>(L3[c]);
+      L3[c] += lane_partner<1>(L3[c]);
+    }
+    if ((lane & 7) == 0 && rowok) {
+#pragma unroll
+      for (int c = 0; c < P; ++c)
+        __hip_atomic_fetch_add(&rowacc[lrow * P + c], L3[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+// The geometry of one run as seen by one wave (all wave-uniform).
+struct SymmRun {
+  int row0;         // first row of the row tile
+  int tile_end;     // one past its last row (ragged last tile: N)
+  int J0;           // first column slab of the run
+  int ntile;        // slabs in the run
+  int N;
+  int wave;
+  int sig;          // the wave's quarter in phase q is q ^ sig (a bijection wave -> quarter in every phase)
+};
+
+// Rows [rb, re) wave `wave` handles in phase q of tile j of the run, and whether they reach the diagonal.
+template <typename T>
+__device__ __forceinline__ bool symm_range(const SymmRun& run, int j, int q, int& rb, int& re, int& col0, int& diag) {
+  constexpr int VN = Vec16<T>::n;
+  constexpr int WCOLS = SYMM_NU * 64 * VN, SLAB = 4 * WCOLS;
+  col0 = (run.J0 + j) * SLAB;
+  const int wc0 = col0 + run.wave * WCOLS, wc1 = wc0 + WCOLS;
+  // rows that can hold an element on/above the diagonal for this wave: row <= its last column
+  int wend = run.tile_end < wc1 ? run.tile_end : wc1;
+  if (wc0 >= run.N) wend = run.row0;                       // ragged last slab: the wave has no columns
+  const int k = q ^ run.sig;
+  rb = run.row0 + k * SYMM_QR;
+  re = rb + SYMM_QR;
+  re = re < wend ? re : wend;
+  diag = (re - 1 >= wc0) ? 1 : 0;
+  return rb < re;
+}
+
+// first non-empty range after (j, q) in the wave's sequence; nx.row < 0 when there is none
+template <typename T>
+__device__ __forceinline__ SymmNext symm_next_range(const SymmRun& run, int j, int q) {
+  SymmNext nx;
+  nx.row = -1; nx.last = 0; nx.col0 = 0; nx.diag = 0;
+#pragma unroll 1
+  for (int s = 0; s < 8; ++s) {
+    if (++q == 4) { q = 0; ++j; }
+    if (j >= run.ntile) break;
+    int rb, re, c0, dg;
+    if (symm_range<T>(run, j, q, rb, re, c0, dg)) {
+      nx.row = rb; nx.last = re - 1; nx.col0 = c0; nx.diag = dg;
+      break;
+    }
+  }
+  return nx;
+}
+
+template <typename T, int P, bool DIAG>
+__device__ __forceinline__ void symm_rows(
+    typename Vec16<T>::type (&a)[SYMM_R][SYMM_NU], const TileRsrc Ab, const T* __restrict__ Xb, unsigned ldab,
+    long ldx, int rb, int re, int row_tile0, int col0, int N, const int (&jj)[SYMM_NU], const SymmNext after,
+    typename Vec16<T>::type (&acc_col)[SYMM_NU][P], const typename Vec16<T>::type (&xJ)[SYMM_NU][P],
+    T* rowacc, int lane) {
+  const int nfull = (re - rb) / SYMM_R;
+  const bool tail = ((re - rb) % SYMM_R) != 0;
+  int i0 = rb;
+  for (int c = 0; c < nfull; ++c, i0 += SYMM_R) {
+    // the successor of a chunk lies in this same range, except for the last chunk of the range: there the ring
+    // moves on to the wave's next range (scalar selects; the chunk's loads are the same on both paths)
+    const bool last = !tail && c == nfull - 1;
+    SymmNext nx;
+    nx.row = last ? after.row : i0 + SYMM_R;
+    nx.last = last ? after.last : re - 1;
+    nx.col0 = last ? after.col0 : col0;
+    nx.diag = last ? after.diag : (DIAG ? 1 : 0);
+    symm_chunk8<T, P, DIAG, false>(a, Ab, Xb, ldab, ldx, i0, re, row_tile0, col0, N, jj, nx, acc_col, xJ, rowacc,
+                                   lane);
+  }
+  if (tail)
+    symm_chunk8<T, P, DIAG, true>(a, Ab, Xb, ldab, ldx, i0, re, row_tile0, col0, N, jj, after, acc_col, xJ, rowacc,
+                                  lane);
+}
+
+// per-tile set-up of one wave: absolute columns of its lanes, zeroed column sums, the panel values x_J of its columns
+template <typename T, int P>
+__device__ __forceinline__ void symm_tile_setup(const T* __restrict__ Xb, int ldx, int col0, int N,
+                                                const int (&lanecol)[SYMM_NU], int (&jj)[SYMM_NU],
+                                                typename Vec16<T>::type (&acc_col)[SYMM_NU][P],
+                                                typename Vec16<T>::type (&xJ)[SYMM_NU][P]) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+#pragma unroll
+  for (int u = 0; u < SYMM_NU; ++u) {
+    jj[u] = col0 + lanecol[u];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+#pragma unroll
+      for (int v = 0; v < VN; ++v) acc_col[u][c][v] = T(0);
+      if (jj[u] < N) {
+        xJ[u][c] = *reinterpret_cast<const VT*>(Xb + (long)c * ldx + jj[u]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VN; ++v) xJ[u][c][v] = T(0);
+      }
+    }
+  }
+  // Drain here, once per tile: the x_J loads above (and the previous tile's column-partial stores) are YOUNGER than
+  // the ring loads already in flight for this tile's first rows.  Left pending, the wait for x_J at the head of the
+  // chunk loop would be vmcnt(0) on every iteration (the compiler's counts are per program point, it cannot peel
+  // the first one) and drain the whole ring once per chunk.  vmcnt(0), expcnt/lgkmcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+template <typename T, int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
+    const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int nruns,
+    int N, long lda, long sA, long ldx, long sX, int NS, int NT, int NSL, int L, int flags) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int NU = SYMM_NU;
+  constexpr int WCOLS = NU * 64 * VN;          // columns per wave
+  constexpr int SLAB = 4 * WCOLS;              // columns per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
+  // run list in row-tile-major order: row tile I owns the slabs J >= (I*TRH)/SLAB, cut into runs of L
+  int b = blockIdx.x / nruns;
+  int I = 0, slot = 0, jmin = 0, cnt = 0;
+  {
+    int rem = blockIdx.x - b * nruns;
+    for (;; ++I) {
+      jmin = (I * SYMM_TRH) / SLAB;
+      cnt = NS - jmin;
+      const int nr = (cnt + L - 1) / L;
+      if (rem < nr) { slot = rem; break; }
+      rem -= nr;
+    }
+  }
+  // the integer divisions above run on the vector ALU: pin their (wave-uniform) results in SGPRs so that
+  // everything derived from them (row offsets, loop bounds, panel addresses) is scalar arithmetic
+  b = __builtin_amdgcn_readfirstlane(b);
+  I = __builtin_amdgcn_readfirstlane(I);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  jmin = __builtin_amdgcn_readfirstlane(jmin);
+  cnt = __builtin_amdgcn_readfirstlane(cnt);
+  const int lane = threadIdx.x & 63;
+  SymmRun run;
+  run.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+  run.row0 = I * SYMM_TRH;
+  run.tile_end = run.row0 + SYMM_TRH <= N ? run.row0 + SYMM_TRH : N;
+  run.J0 = jmin + slot * L;
+  run.ntile = (cnt - slot * L) < L ? (cnt - slot * L) : L;
+  run.N = N;
+  // phase -> quarter map q ^ sig: sig = wave when a wave's columns span one quarter of rows (fp64); with two quarters
+  // per wave (fp32) waves 1 and 2 swap, so that both quarters of a wave's diagonal block come in phases 0 and 1
+  run.sig = (WCOLS == SYMM_QR) ? run.wave : ((run.wave & 1) << 1 | (run.wave >> 1));
+  const int wave = run.wave;
+  int lanecol[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) lanecol[u] = wave * WCOLS + u * 64 * VN + lane * VN;   // 1 KB contiguous per load
+  const T* Ab = A + (long)b * sA;
+  const T* Xb = X + (long)b * sX;
+  const unsigned ldab = (unsigned)(lda * (long)sizeof(T));
+  const TileRsrc tile = make_tile_rsrc(Ab + (long)run.row0 * lda,
+                                       (long)(run.tile_end - run.row0) * lda * (long)sizeof(T));
+  // ---- ring fill: the first rows of the wave's first range (unconditional: a wave without any range fills
+  // through the out-of-range offset) — issued BEFORE the LDS set-up so that the set-up runs under the loads
+  VT a[SYMM_R][NU];
+  {
+    SymmNext first = symm_next_range<T>(run, 0, -1);
+    const int ncols = first.row >= 0 ? N : 0;          // no range at all: every lane fills through the OOR offset
+    if (first.row < 0) { first.row = run.row0; first.last = run.row0; }
+    unsigned floff[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      floff[u] = (first.col0 + lanecol[u] < ncols) ? (unsigned)lanecol[u] * (unsigned)sizeof(T) : SYMM_OOR;
+#pragma unroll
+    for (int r = 0; r < SYMM_R; ++r) {
+      int row = first.row + r;
+      row = row < first.last ? row : first.last;
+      const unsigned soff = (unsigned)(row - run.row0) * ldab + (unsigned)first.col0 * (unsigned)sizeof(T);
+      const int thr = first.diag ? row - first.col0 - (VN - 1) : -0x40000000;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) a[r][u] = ld_tile<VT>(tile, lanecol[u] >= thr ? floff[u] : SYMM_OOR, soff);
+    }
+  }
+  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
+  __syncthreads();
+
+  VT acc_col[NU][P], xJ[NU][P];
+  int jj[NU];
+  int col0 = run.J0 * SLAB;
+  symm_tile_setup<T, P>(Xb, (int)ldx, col0, N, lanecol, jj, acc_col, xJ);
+  int q = 0;
+  if (slot == 0) {
+    // The first tile of a row tile's first run reaches the diagonal.  With the phase -> quarter map above every
+    // range that needs the diagonal masks lies in the first WCOLS/QR phases of that tile: they run here, on the
+    // masked instantiation (all four waves, whatever their own range needs), so the loop below is mask-free.
+#pragma unroll 1
+    for (; q < WCOLS / SYMM_QR; ++q) {
+      int rb, re, c0, dg;
+      if (symm_range<T>(run, 0, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T>(run, 0, q);
+        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
+        symm_rows<T, P, true>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
+                              rowacc, lane);
+      }
+      XK_SYMM_PHASE_BARRIER();
+    }
+  }
+  int j = 0;
+#pragma unroll 1
+  for (;;) {
+#pragma unroll 1
+    for (; q < 4; ++q) {
+      int rb, re, c0, dg;
+      if (symm_range<T>(run, j, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T>(run, j, q);
+        // no successor (end of the run for this wave): refill through the out-of-range offset (a tile starting at
+        // column N: every lane is beyond the last column), so that every chunk issues the same loads
+        if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
+        symm_rows<T, P, false>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
+                               rowacc, lane);
+      }
+      XK_SYMM_PHASE_BARRIER();        // s_waitcnt lgkmcnt(0) + s_barrier: the ring's loads stay in flight
+    }
+#ifdef XK_SYMM_NOBAR
+    __syncthreads();
+#endif
+    // column partial slot I (columns of this slab)
+    T* cp = colP + (((long)b * NT + I) * P) * (long)N;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (jj[u] < N) {
+        if (flags & 1) {
+#pragma unroll
+          for (int c = 0; c < P; ++c) __builtin_nontemporal_store(acc_col[u][c], reinterpret_cast<VT*>(cp + (long)c * N + jj[u]));
+        } else {
+#pragma unroll
+          for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(cp + (long)c * N + jj[u]) = acc_col[u][c];
+        }
+      }
+    if (++j >= run.ntile) break;
+    q = 0;
+    col0 = (run.J0 + j) * SLAB;
+    symm_tile_setup<T, P>(Xb, (int)ldx, col0, N, lanecol, jj, acc_col, xJ);
+  }
+  {
+    // the run's row sums of quarter 3 ^ sig are complete: the other three waves added theirs in the earlier
+    // phases (barriers), this wave just added the last ones (LDS operations of one wave execute in order).
+    // Row partial slot `slot` of this row tile.
+    const int k3 = 3 ^ run.sig;
+    const int fb = run.row0 + k3 * SYMM_QR;
+    int fe = fb + SYMM_QR;
+    fe = fe < run.tile_end ? fe : run.tile_end;
+    const int nr = fe - fb;
+    T* rp = rowP + (((long)b * NSL + slot) * P) * (long)N;
+    for (int idx = lane; idx < nr * P; idx += 64) {
+      const int c = idx / nr, lr = idx - c * nr;
+      const T v = rowacc[(fb - run.row0 + lr) * P + c];
+      if (flags & 1) __builtin_nontemporal_store(v, &rp[(long)c * N + fb + lr]);
+      else rp[(long)c * N + fb + lr] = v;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, const T* __restrict__ colP,
+                                                  T* __restrict__ Y, int N, int P, int NS, int NT, int NSL, int L,
+                                                  int slab, long ldy, long sY, long total, int flags) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*P*N
+  if (idx >= total) return;
+  const long per_b = (long)P * N;
+  const long b = idx / per_b;
+  const long rem = idx - b * per_b;
+  const int c = (int)(rem / N);
+  const int n = (int)(rem - (long)c * N);
+  const int It = n / SYMM_TRH;                 // row tile of n
+  const int jmin = (It * SYMM_TRH) / slab;     // first column slab that owns a tile with row tile It
+  const int nslot = (NS - jmin + L - 1) / L;   // runs (= row partial slots) of that row tile
+  T s = T(0);
+  const int Imax = ((n / slab) * slab + slab - 1) / SYMM_TRH;   // row tiles I with I*TRH <= last column of n's slab
+  if (flags & 2) {                                              // the partials are read exactly once
+    for (int r = 0; r < nslot; ++r) s += __builtin_nontemporal_load(&rowP[(((long)b * NSL + r) * P + c) * (long)N + n]);
+    for (int I = 0; I <= Imax && I < NT; ++I)
+      s += __builtin_nontemporal_load(&colP[(((long)b * NT + I) * P + c) * (long)N + n]);
+  } else {
+    for (int r = 0; r < nslot; ++r) s += rowP[(((long)b * NSL + r) * P + c) * (long)N + n];
+    for (int I = 0; I <= Imax && I < NT; ++I) s += colP[(((long)b * NT + I) * P + c) * (long)N + n];
+  }
+  Y[b * sY + (long)c * ldy + n] = s;
+}
+
+// Tuning state (process-wide; written only through xk_dense_symm_tune, a measurement hook):
+//   [0] bit 0: the row / column partials leave with non-temporal stores, bit 1: the fold reads them with
+//       non-temporal loads (written once, read once, milliseconds apart: keeping them out of L2's way was worth
+//       1.2 % of the eigensolver call in round 2);
+//   [1] L: column slabs per run (row partials per row tile = ceil(slabs / L)).
+static int g_symm_tune[2] = {3, 1};
+
+}  // namespace xk
+
+extern "C" {
+
+// measurement hook: set tuning value `what` (0: non-temporal flags, 1: slabs per run), return the previous one.
+// Results do not depend on either (the run length changes the summation order of the row partials — still a
+// fixed order).  Not meant to be flipped while launches are being issued from other threads.
+int xk_dense_symm_tune(int what, int value) {
+  if (what < 0 || what > 1) return XK_ERR_ARG;
+  const int old = xk::g_symm_tune[what];
+  if (what == 0 && value >= 0 && value <= 3) xk::g_symm_tune[0] = value;
+  if (what == 1 && value >= 1 && value <= 64) xk::g_symm_tune[1] = value;
+  return old;
+}
+
+// workspace (elements): row partials (B, NS, P, N) + column partials (B, NT, P, N) — sized for runs of one slab
+long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
+  const int vn = 16 / elem_size;
+  const long slab = 256L * vn * xk::SYMM_NU;
+  const long NS = (N + slab - 1) / slab, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;
+  const long pc = P > 6 ? 6 : P;
+  return (long)B * (NS + NT) * pc * N;
+}
+
+#define XK_DEFINE_SYMM(SUF, T)                                                                              \
+  static int symm_launch_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P,     \
+                               long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream,       \
+                               int phase) {                                                                 \
+    if (B < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                                         \
+    if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
+    if (phase != 0 && P > 6) return XK_ERR_UNSUPPORTED;   /* split phases: one column chunk only */         \
+    constexpr int VN = xk::Vec16<T>::n;                                                                     \
+    constexpr int SLAB = 256 * VN * xk::SYMM_NU;                                                            \
+    if ((N % VN) || (lda % VN) || (sA % VN) || (ldx % VN) || (sX % VN) || ((uintptr_t)A & 15) ||             \
+        ((uintptr_t)X & 15) || ((uintptr_t)ws & 15))                                                        \
+      return XK_ERR_UNSUPPORTED;                                                                            \
+    if ((long)xk::SYMM_TRH * lda * (long)sizeof(T) > 0x7fffffe0L) return XK_ERR_UNSUPPORTED;               \
+    hipStream_t st = (hipStream_t)stream;                                                                   \
+    const int L = xk::g_symm_tune[1], fl = xk::g_symm_tune[0];                                              \
+    const int NS = (N + SLAB - 1) / SLAB, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;                       \
+    const int NSL = (NS + L - 1) / L;                                                                       \
+    int nruns = 0;                                                                                          \
+    for (int I = 0; I < NT; ++I) nruns += (NS - (I * xk::SYMM_TRH) / SLAB + L - 1) / L;                     \
+    int c0 = 0;                                                                                             \
+    while (c0 < P) {                                                                                        \
+      const int pc = (P - c0) >= 6 ? 6 : (P - c0);                                                          \
+      const long nrow = (long)B * NSL * pc * N, ncol = (long)B * NT * pc * N;                               \
+      if (ws_elems < nrow + ncol) return XK_ERR_ARG;                                                        \
+      T* rowP = ws;                                                                                         \
+      T* colP = ws + nrow;                                                                                  \
+      const size_t lds = (size_t)xk::SYMM_TRH * pc * sizeof(T);                                             \
+      const dim3 grid((unsigned)((long)B * nruns));                                                         \
+      const T* Xc = X + (long)c0 * ldx;                                                                     \
+      if (phase != 2) {                                                                                     \
+        switch (pc) {                                                                                       \
+          XK_SYMM_CASE(1) XK_SYMM_CASE(2) XK_SYMM_CASE(3) XK_SYMM_CASE(4) XK_SYMM_CASE(5) XK_SYMM_CASE(6)   \
+        }                                                                                                   \
+        XK_LAUNCH_CHECK();                                                                                  \
+      }                                                                                                     \
+      if (phase != 1) {                                                                                     \
+        const long total = (long)B * pc * N;                                                                \
+        hipLaunchKernelGGL((xk::symm_fold<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,     \
+                           rowP, colP, Y + (long)c0 * ldy, N, pc, NS, NT, NSL, L, SLAB, ldy, sY, total,     \
+                           fl);                                                                             \
+        XK_LAUNCH_CHECK();                                                                                  \
+      }                                                                                                     \
+      c0 += pc;                                                                                             \
+    }                                                                                                       \
+    return XK_OK;                                                                                           \
+  }                                                                                                         \
+  int xk_dense_symm_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P, long lda, \
+                          long sA, long ldx, long sX, long ldy, long sY, void* stream) {                    \
+    return symm_launch_##SUF(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, stream, 0);         \
+  }                                                                                                         \
+  int xk_dense_symm_tiles_##SUF(const T* A, const T* X, T* ws, long ws_elems, int B, int N, int P,          \
+                                long lda, long sA, long ldx, long sX, void* stream) {                       \
+    return symm_launch_##SUF(A, X, (T*)nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, stream, 1);  \
+  }                                                                                                         \
+  int xk_dense_symm_fold_##SUF(T* Y, const T* ws, long ws_elems, int B, int N, int P, long ldy, long sY,    \
+                               void* stream) {                                                              \
+    /* the fold never touches A or X: alignment-checked placeholders */                                     \
+    return symm_launch_##SUF((const T*)ws, (const T*)ws, Y, (T*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, \
+                             stream, 2);                                                                    \
+  }
+
+#define XK_SYMM_CASE(PP)                                                                                  \
+  case PP:                                                                                                \
+    hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP>), grid, dim3(256), lds, st, A, Xc, rowP, colP,       \
+                       nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl);                                   \
+    break;
+
+#define TT double
+XK_DEFINE_SYMM(f64, double)
+#undef TT
+#define TT float
+XK_DEFINE_SYMM(f32, float)
+#undef TT
+
+}  // extern "C"
