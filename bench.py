@@ -199,6 +199,14 @@ def _panel_bytes(nb, N, p, esize, symm):
     return mat + 2 * nb * N * p * esize
 
 
+def _k1s_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("xk_symm.hip", "xk_common.h"):
+        h.update(open(os.path.join(ROOT, "xitorch_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
 def _k1_roofline(k1_events, N, p, esize, symm, b_local):
     launches = [(e0.elapsed_time(e1) * 1e-3, nb) for (e0, e1, pc, nb) in k1_events if pc == p]
     durs = [d for d, _ in launches]
@@ -215,16 +223,25 @@ def _k1_roofline(k1_events, N, p, esize, symm, b_local):
         kernel = "K1 xk::dense_rmm_cols + fold_slabs (column-oriented panel product, full matrix)"
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "k1s_pmc_traffic.json" if symm else "k1_pmc_traffic.json")
+    traffic_note = None
     if os.path.exists(pmc_file):
         try:
             rec = json.load(open(pmc_file))
             if rec.get("N") == N and rec.get("P") == p and rec.get("B"):
-                # PMC record of a launch over rec["B"] members; traffic scales linearly with the batch
-                traffic = rec.get("hbm_bytes_per_launch") * nb_launch / rec["B"]
+                # PMC record of a launch over rec["B"] members; traffic scales linearly with the batch.  The record
+                # carries the hash of the kernel source it was measured on (scripts/pmc_traffic.sh): a record of
+                # another kernel is not reported
+                stamp = rec.get("kernel_source_sha256")
+                if symm and stamp != _k1s_source_hash():
+                    traffic_note = "PMC record is stale (kernel source changed since scripts/pmc_traffic.sh ran): not reported"
+                else:
+                    traffic = rec.get("hbm_bytes_per_launch") * nb_launch / rec["B"]
+                    traffic_note = "PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of a whole-batch launch of the same " \
+                                   "kernel source, scaled to the launch's batch members (profiles/%s)" % os.path.basename(pmc_file)
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": traffic, "kernel": kernel, "launches_timed": len(durs), "avg_launch_ms": k1_avg * 1e3,
+            "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel, "launches_timed": len(durs), "avg_launch_ms": k1_avg * 1e3,
             "algorithmic_bytes_per_launch": need, "batch_members_per_launch": nb_launch,
             "bytes_formula": ("B*N*(N+1)/2*s + 2*B*N*p*s (triangle incl. diagonal + panel in + panel out)" if symm
                               else "B*N^2*s + 2*B*N*p*s (SURVEY 8d)")}

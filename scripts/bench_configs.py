@@ -48,6 +48,29 @@ def c3(B=256, N=65536, hb=63):
             "solves_per_s": B / t}
 
 
+def c3g(B=256, N=65536, hb=63, m=30):
+    """configs[2]'s operator through the native GMRES (reference: solve.py:326-433), at most m = 30 iterations: with the
+    reference's semantics (iterate + true residual every iteration) and with resid_calc_every = 10"""
+    band = syn.banded(B, N, hb=hb, device=dev)
+    xs = syn.banded_rhs_solution(B, N, device=dev)
+    A = xa.BandedLinearOperator(band)
+    Bm = A.mm(xs)
+    out = {"config": "c3g gmres banded (256 x 65536, bw 127), max_niter = %d" % m, "B": B, "N": N, "hb": hb}
+    for every in (1, 10):
+        tr = {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            nk.gmres(A, Bm, rtol=1e-10, atol=1e-12, posdef=True, max_niter=m, resid_calc_every=every)     # warm-up
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            Xs = nk.gmres(A, Bm, rtol=1e-10, atol=1e-12, posdef=True, max_niter=m, resid_calc_every=every, trace=tr)
+            torch.cuda.synchronize(); t = time.perf_counter() - t0
+        out["every_%d" % every] = {"solve_ms": t * 1e3, "arnoldi_steps": tr["arnoldi_steps"], "napply": tr["napply"],
+                                   "converged": tr["converged"], "best_resid": tr["best_resid"],
+                                   "host_syncs": tr["host_syncs"], "max_err_vs_xstar": (Xs - xs).abs().max().item(),
+                                   "solves_per_s": B / t}
+    return out
+
+
 def c4(B=64, N=8192):
     A = syn.root_matrix(B, N, device=dev) * 2.0
     y0 = torch.zeros(B, N, dtype=torch.float64, device=dev)
@@ -132,7 +155,7 @@ if __name__ == "__main__":
                 _, spec, rs = name.split(":")
                 r = c2_hard(spec, int(rs) if int(rs) > 0 else None)
             else:
-                r = {"c3": c3, "c4": c4, "c5": c5, "c5w": c5w}[name]()
+                r = {"c3": c3, "c3g": c3g, "c4": c4, "c5": c5, "c5w": c5w}[name]()
         except Exception as e:      # keep going: this is a measurement script
             r = {"config": name, "error": repr(e)}
         print(json.dumps(r), flush=True)

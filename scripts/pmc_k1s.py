@@ -1,6 +1,6 @@
 """K1s (upper-triangle panel product) alone at the config-2 shape for the rocprofv3 PMC passes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from xitorch_amd.kernels import dense_symm
 from xitorch_amd import synthetic

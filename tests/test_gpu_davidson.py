@@ -430,13 +430,9 @@ def test_fused_panel_cholqr_vs_separate_kernels(dev):
     assert int(info[0]) != 0
 
 
-def test_wide_blocks_neig40_and_restart_neig20(dev):
-    """No width cliff: neig = 40 > 32 goes through the chunked panel orthonormalisation
-    (the reference has no limit: symeig.py:100-140); thick restart with 16 < neig <= 32 keeps at least the wanted
-    vectors.  Both against the dense eigendecomposition."""
-    # 48 separated eigenvalues at each end of the spectrum (so that 40 wanted pairs converge long before the basis is
-    # square), the rest in a band in between; dense through a Householder similarity, symmetrised exactly
-    N = 1536
+def _separated_ends_operator(dev, N=1536):
+    """48 separated eigenvalues at each end of the spectrum (so that 40 wanted pairs converge long before the basis is
+    square), the rest in a band in between; dense through a Householder similarity, symmetrised exactly."""
     d = torch.cat([torch.arange(1.0, 49.0, dtype=torch.float64),
                    200.0 + 100.0 * torch.arange(N - 96, dtype=torch.float64) / (N - 96),
                    400.0 + torch.arange(1.0, 49.0, dtype=torch.float64)]).to(dev)
@@ -448,24 +444,28 @@ def test_wide_blocks_neig40_and_restart_neig20(dev):
         m = torch.diag(d) - 2.0 * torch.outer(w, Dw) - 2.0 * torch.outer(Dw, w) + 4.0 * (w @ Dw) * torch.outer(w, w)
         mats.append((m + m.T) * 0.5)
     mat = torch.stack(mats)
+    return mat, torch.linalg.eigvalsh(mat)
+
+
+@pytest.mark.parametrize("neig,nguess,mode,restart", [(40, None, "lowest", None), (36, 40, "uppest", None),
+                                                      (20, None, "lowest", 80), (16, None, "lowest", None)])
+def test_wide_blocks_and_restart_beyond_16(dev, neig, nguess, mode, restart):
+    """No width cliff: neig / nguess > 32 go through the chunked panel orthonormalisation
+    (the reference has no limit: symeig.py:100-140); thick restart with 16 < neig <= 32 keeps at least the wanted
+    vectors.  Against the dense eigendecomposition."""
+    mat, lam_all = _separated_ends_operator(dev)
     A = xa.LinearOperator.m(mat, is_hermitian=True)
-    lam_all = torch.linalg.eigvalsh(mat)
     tr = {}
-    ev, X = davidson(A, 40, "lowest", min_eps=1e-8, trace=tr)
-    assert ev.shape == (2, 40) and X.shape == (2, 1536, 40)
-    assert (ev - lam_all[:, :40]).abs().max().item() <= 1e-9 * lam_all.abs().max().item()
-    R = mat @ X - X * ev.unsqueeze(-2)
-    assert R.abs().max().item() <= 1e-7
+    ev, X = davidson(A, neig, mode, min_eps=1e-8, nguess=nguess, restart=restart, trace=tr)
+    assert tr["stop_reason"] == "converged", tr["stop_reason"]
+    assert ev.shape == (2, neig) and X.shape == (2, 1536, neig)
+    want = lam_all[:, :neig] if mode == "lowest" else lam_all[:, -neig:]
+    assert (ev - want).abs().max().item() <= 1e-9 * lam_all.abs().max().item()
+    assert (mat @ X - X * ev.unsqueeze(-2)).abs().max().item() <= 1e-7
     G = X.transpose(-2, -1) @ X
-    assert (G - torch.eye(40, dtype=torch.float64, device=dev)).abs().max().item() <= 1e-9
-    ev_u, _ = davidson(A, 36, "uppest", min_eps=1e-8, nguess=40)
-    assert (ev_u - lam_all[:, -36:]).abs().max().item() <= 1e-9 * lam_all.abs().max().item()
-    # restart with 16 < neig <= 32
-    tr = {}
-    ev20, X20 = davidson(A, 20, "lowest", min_eps=1e-8, restart=80, trace=tr)
-    assert tr["restarts"] >= 1
-    assert (ev20 - lam_all[:, :20]).abs().max().item() <= 1e-9 * lam_all.abs().max().item()
-    assert (mat @ X20 - X20 * ev20.unsqueeze(-2)).abs().max().item() <= 1e-7
+    assert (G - torch.eye(neig, dtype=torch.float64, device=dev)).abs().max().item() <= 1e-9
+    if restart is not None:
+        assert tr["restarts"] >= 1
 
 
 def test_one_gram_schmidt_pass_equals_two(dev):

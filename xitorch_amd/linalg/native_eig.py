@@ -220,6 +220,7 @@ class _Group:
         the driver repeats it with force_jacobi=True when the tridiagonalisation kernel flagged its own result."""
         k, p, N = self.k, self.p, self.N
         tri_flag = None
+        self._orth_done = False                   # a new residual panel is about to replace the one orthonormalised
         # thick restart due after this Rayleigh-Ritz?  then the small eigensolver also returns the extra Ritz pairs
         # that will survive (pk >= p of them; the wanted p are the first / last p of the ascending list)
         due = self.restart is not None and k + p > self.restart and k > self.keep and k < N
@@ -304,8 +305,11 @@ class _Group:
         self.k = pk
         self.nrestart += 1
 
-    def expand(self):
-        """Orthonormalise the residual panel against the basis, apply the operator to it, extend T."""
+    def expand_orth(self):
+        """First half of the expansion: (thick restart if due,) the residual panel of the last Rayleigh-Ritz step is
+        orthonormalised against the basis.  Cheap and free of side effects beyond basis rows >= k, so the driver
+        enqueues it BEFORE it reads the step's status: the host round trip (status -> decision -> next launches)
+        then runs under these kernels instead of leaving the GPU idle.  `undo_orth` takes it back."""
         restarted = self._compress is not None
         if restarted:
             self.compress()
@@ -321,11 +325,29 @@ class _Group:
                 self.project_out(k, nadd)
             self.cholqr(k, nadd)
         end()
+        self._orth_done = True
+
+    def speculate_orth(self):
+        """expand_orth ahead of the status read — unless the step is not repeatable afterwards (a pending thick
+        restart rewrites the basis) or there is nothing to add (square basis)"""
+        if self._compress is None and self.nadd > 0 and self.k < self.N:
+            self.expand_orth()
+
+    def expand_apply(self):
+        """Second half: the operator applied to the new block, T extended."""
+        k, nadd = self.k, self.nadd
         self.apply_A(self.Vs[:, k:k + nadd], self.AVs[:, k:k + nadd])
         end = self._mark("extT")
         self.extend_T(k, nadd)
         end()
         self.k = k + nadd
+        self._orth_done = False
+
+    def expand(self):
+        """Orthonormalise the residual panel against the basis, apply the operator to it, extend T."""
+        if not getattr(self, "_orth_done", False):
+            self.expand_orth()
+        self.expand_apply()
 
 
 def tallqr_extend(V, t, M=None, orth_passes=2):
@@ -573,35 +595,43 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         niter = it + 1
         local_max, bad = 0.0, 0.0
         deferred = []
-        with torch.cuda.stream(streams[0]):
-            groups[0].small()
+        k_rr = groups[0].k                      # the basis width this iteration's Rayleigh-Ritz runs on (all groups)
+        # Every group's Rayleigh-Ritz chain AND the orthonormalisation of its next block are enqueued before the host
+        # blocks on any status: the chain starts the moment the group's panel product is done, and the host round
+        # trip (read the status, decide, launch the next panel product) runs under the orthonormalisation kernels.
+        # Only the cheap half of the expansion is speculative: the panel product is launched once the status rules
+        # out convergence, so nothing expensive is ever wasted.
+        for g in range(G):
+            if g == 0 or _PRELAUNCH:
+                with torch.cuda.stream(streams[g]):
+                    groups[g].small()
+                    groups[g].speculate_orth()
         for g in range(G):
             if not _PRELAUNCH and g > 0:
                 with torch.cuda.stream(streams[g]):
                     groups[g].small()
-            if _PRELAUNCH and g + 1 < G:
-                # the next group's Rayleigh-Ritz chain is enqueued BEFORE the host blocks on this group's status:
-                # it starts the moment its own panel product is done instead of one host round trip later
-                with torch.cuda.stream(streams[g + 1]):
-                    groups[g + 1].small()
+                    groups[g].speculate_orth()
             with torch.cuda.stream(streams[g]):
                 st_g, bad_g, tri_g = groups[g].status.tolist()        # host waits for THIS group's stream only
                 if tri_g != 0:
-                    # the tridiagonalisation kernel's self-check failed for some member: same step on Jacobi
+                    # the tridiagonalisation kernel's self-check failed for some member: same step on Jacobi (the
+                    # speculative orthonormalisation consumed its output: redo that too, it only touched rows >= k)
                     groups[g].small(force_jacobi=True)
+                    groups[g].speculate_orth()
                     st_g, bad_g, tri_g = groups[g].status.tolist()
                     n_fallback[0] += 1
             if st_g != st_g:
                 st_g = float("inf")
             local_max, bad = max(local_max, st_g), max(bad, bad_g)
-            if g < G - 1:
-                # a local residual above the threshold already rules out global convergence: its expansion is
-                # certain, enqueue it now so its panel product runs under the next group's small kernels
-                if st_g >= min_eps and bad_g == 0 and groups[g].k < N:
-                    with torch.cuda.stream(streams[g]):
-                        groups[g].expand()
-                else:
-                    deferred.append(g)
+            # a local residual above the threshold already rules out global convergence (the global value is the max
+            # over groups and ranks): the panel product of this group — and of the ones deferred so far — is certain
+            if local_max >= min_eps and bad == 0 and k_rr < N:
+                for gg in deferred + [g]:
+                    with torch.cuda.stream(streams[gg]):
+                        groups[gg].expand()
+                deferred = []
+            else:
+                deferred.append(g)
         max_resid = local_max
         if distributed:
             with torch.cuda.stream(streams[G - 1]):
@@ -617,7 +647,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                                "(linearly dependent guess/residual vectors)")
         history.append(max_resid)
         if verbose:
-            print("Iter %3d (guess size: %d): resid: %.3e" % (it + 1, groups[0].k, max_resid))
+            print("Iter %3d (guess size: %d): resid: %.3e" % (it + 1, k_rr, max_resid))
         if max_resid < best_resid:
             best_resid = max_resid
             for grp in groups:
@@ -625,12 +655,10 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         if max_resid < min_eps:
             stop_reason = "converged"
             break
-        # the LAST group is never expanded early, so its width is the width this iteration's Rayleigh-Ritz ran
-        # on for every group (groups[0] may already have been grown inside the loop above)
-        if groups[G - 1].k == N:
+        if k_rr == N:
             stop_reason = "full_basis"
             break
-        for g in deferred + [G - 1]:
+        for g in deferred:                      # (every local residual was below the threshold, another rank's is not)
             with torch.cuda.stream(streams[g]):
                 groups[g].expand()
 
