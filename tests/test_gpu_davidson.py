@@ -448,7 +448,7 @@ def _separated_ends_operator(dev, N=1536):
 
 
 @pytest.mark.parametrize("neig,nguess,mode,restart", [(40, None, "lowest", None), (36, 40, "uppest", None),
-                                                      (20, None, "lowest", 80), (16, None, "lowest", None)])
+                                                      (20, None, "lowest", 100), (10, None, "lowest", 40), (16, None, "lowest", None)])
 def test_wide_blocks_and_restart_beyond_16(dev, neig, nguess, mode, restart):
     """No width cliff: neig / nguess > 32 go through the chunked panel orthonormalisation
     (the reference has no limit: symeig.py:100-140); thick restart with 16 < neig <= 32 keeps at least the wanted

@@ -95,8 +95,10 @@ class _Group:
         # (extension) thick restart: None = never (the reference's ever-growing basis); an int = largest basis
         # width; `keep` Ritz vectors survive a restart
         self.restart = restart
-        # at least the p wanted vectors survive (neig > 16: the small eigensolver then is the library eigh)
-        self.keep = max(p, min(2 * p, K.SMALL_EIGH_MAX_P))
+        # 2p Ritz vectors survive a restart: the p wanted ones and the p nearest unwanted ones, which is what keeps the
+        # convergence of the unrestarted iteration (with only the wanted ones the restarted iteration stagnates:
+        # measured, 10 of 1536 never converge).  Beyond 16 the restart step's Rayleigh-Ritz is the library eigh.
+        self.keep = 2 * p
         self._compress = None                     # (Yt (B, pk, k), lam_all (B, pk)) of a pending restart
         self.nrestart = 0
         self.k1_stream = None                     # two-group pipeline: the (CU-masked) stream of the panel products
@@ -451,8 +453,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     restart: int or None
         (extension) ``None`` (default): the basis grows until convergence, like the reference, which never restarts
         (symeig.py:132-135).  An integer: thick restart — whenever the next expansion would exceed this many basis
-        vectors, the basis is replaced by the ``max(neig, min(2*neig, 16))`` Ritz vectors nearest the wanted end (the
-        wanted ``neig`` among them) before the new residual block is appended.  Bounds the memory (2 x restart x N per
+        vectors, the basis is replaced by the ``2 * neig`` Ritz vectors nearest the wanted end (the wanted ``neig``
+        among them) before the new residual block is appended.  Bounds the memory (2 x restart x N per
         batch member) and keeps the Rayleigh–Ritz matrix inside the LDS-resident eigensolver on slowly converging
         spectra; costs extra iterations.  Must be >= ``3 * neig``.
     V0: tensor or None
@@ -463,8 +465,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         construction (``V^T (A X - X lam) = T Y - Y lam = 0``), what one pass removes is the rounding-sized component
         that forming it left (measured <= 1e-6 of its norm), and "twice is enough" only matters when the first pass
         cancels most of the vector; the reference does not re-orthogonalise at all (one CholeskyQR of ``[V, t]``,
-        symeig.py:207-220).  Two passes (CGS2) with a preconditioner, whose output has no such property.  An integer
-        forces the number of passes
+        symeig.py:207-220).  Two passes (CGS2) with a preconditioner, whose output has no such property, and with
+        ``restart=``.  An integer forces the number of passes
     process_group: torch.distributed group or None
         (extension) when given, the batch is sharded over the group's ranks and the stopping test
         uses the all-reduced (MAX) residual, so all ranks iterate in lock step (RCCL over xGMI)
@@ -494,7 +496,9 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         raise NativeLibraryError("neig / nguess > 32 with an overlap operator M is not supported by the native "
                                  "davidson (the chunked panel orthonormalisation serves M = None)")
     if orth_passes == "auto":
-        orth_passes = 1 if precond is None else 2
+        # (with thick restarts one pass proved marginal — a 20-pair run failed its panel Cholesky where two passes
+        # converge, r03 — so the restarted extension keeps CGS2)
+        orth_passes = 1 if (precond is None and restart is None) else 2
     events = trace.get("k1_events") if trace is not None else None
 
     # ---- batch groups: one, or two pipelined on two streams ---------------------------------
