@@ -476,6 +476,7 @@ def test_one_gram_schmidt_pass_equals_two(dev):
     from xitorch_amd import synthetic
     for (kind, B, N, p, dtype, eps, tol) in (("S1", 2, 2048, 6, torch.float64, 1e-8, 1e-11),
                                              ("S2", 2, 1024, 4, torch.float64, 1e-8, 1e-11),
+                                             ("S3", 2, 1024, 4, torch.float64, 1e-8, 1e-11),     # > 100 iterations
                                              ("S1", 2, 2048, 6, torch.float32, 1e-3, 2e-5)):
         mat = synthetic.dense_symmetric(B, N, kind, dtype=dtype, device=dev)
         A = xa.LinearOperator.m(mat, is_hermitian=True)
