@@ -281,6 +281,20 @@ int xk_kry_status_f64(const double* Prr, const double* stop, double* rnorm, doub
 int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double* status, int S, int nblk,
                       void* stream);
 
+/* ---- K3g: the same p wanted eigenpairs for Rayleigh-Ritz matrices of order 129 .. 768 (xk_eigh_big.hip) ---------
+ * torch.linalg.eigh + _take_eigpairs (symeig.py:174-175, 255-264) once the un-restarted basis has outgrown the
+ * LDS-resident kernels: Householder tridiagonalisation on a work copy in global memory (L2 / Infinity-Cache resident;
+ * ws: xk_small_eigh_big_workspace_elems(B, k) elements), bisection / inverse iteration / self-check in LDS like K3t,
+ * back-transformation from the reflectors parked in the work copy.  lam (B, p) ascending, Y (B, p, k) eigenvectors,
+ * info[b] != 0 -> redo that call on the library solver.  xk_small_eigh_big_batch(k, p, elem_size): shifts
+ * factorised at a time (> 0) when the problem fits the 160 KiB of LDS, 0 when it does not.  p <= 16. */
+int xk_small_eigh_big_batch(int k, int p, int elem_size);
+long xk_small_eigh_big_workspace_elems(int B, int k);
+int xk_small_eigh_big_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* info, int B, int k,
+                          int p, int uppest, long ldt, long sT, void* stream);
+int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long ws_elems, int* info, int B, int k,
+                          int p, int uppest, long ldt, long sT, void* stream);
+
 /* ---- Davidson chain: one C call per stage of an iteration (xitorch/_impls/linalg/symeig.py:160-223) -------------
  * The stages between two operator-panel products are two to eight small launches each; issued from C++ they cost a
  * few microseconds of host time instead of an interpreter round trip per launch (what bounds small per-GPU batches).

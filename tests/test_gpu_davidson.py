@@ -490,3 +490,23 @@ def test_one_gram_schmidt_pass_equals_two(dev):
         assert (e1 - e2).abs().max().item() <= tol * max(1.0, e2.abs().max().item())
         G = X1.transpose(-2, -1) @ X1
         assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() <= (1e-10 if dtype == torch.float64 else 1e-4)
+
+
+def test_unrestarted_run_beyond_128_vectors_stays_native(dev, monkeypatch):
+    """The reference-default (un-restarted) iteration on a slowly converging spectrum grows its basis far beyond the
+    128 vectors of the LDS-resident eigensolvers (symeig.py:132-135, 174-175); from 129 to 768 vectors the
+    Rayleigh-Ritz step runs on K3g — no library eigh on the way — and reproduces the closed-form eigenvalues."""
+    from xitorch_amd import synthetic
+    B, N, p = 2, 4096, 6
+    mat = synthetic.dense_symmetric(B, N, "S2", dtype=torch.float64, device=dev)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    calls = []
+    real_eigh = torch.linalg.eigh
+    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (calls.append(1), real_eigh(*a, **k))[1])
+    tr = {}
+    ev, X = davidson(A, p, "lowest", min_eps=1e-8, trace=tr)
+    assert tr["stop_reason"] == "converged" and tr["basis_size"] > 128 and tr["basis_size"] <= 768, tr["basis_size"]
+    assert not calls and tr["k3_fallbacks"] == 0
+    exact = synthetic.spectrum("S2", N, device=dev)[:p]
+    assert (ev - exact).abs().max().item() <= 1e-10
+    assert (mat @ X - X * ev.unsqueeze(-2)).abs().max().item() <= 1e-7

@@ -361,3 +361,43 @@ def test_group_status_kernel(dev, dtype, B):
     K.group_status(rmax, info, flag, st)
     out = st.tolist()
     assert out[0] != out[0] and out[1] == float(info.max())
+
+
+@pytest.mark.parametrize("B,k,p,uppest,dtype", [(3, 130, 6, False, torch.float64), (2, 200, 6, True, torch.float64),
+                                                (2, 333, 4, False, torch.float64), (2, 512, 6, False, torch.float64),
+                                                (1, 600, 6, False, torch.float64), (1, 768, 6, True, torch.float64),
+                                                (2, 300, 12, False, torch.float64), (2, 256, 16, False, torch.float32),
+                                                (2, 400, 6, False, torch.float32), (2, 129, 1, False, torch.float64)])
+def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
+    """K3g (orders 129 .. 768, matrix in global memory) against LAPACK: eigenvalues, residual, orthonormality, on
+    matrices shaped like a Davidson T (a few separated eigenvalues below a dense band) and on random ones; the
+    matrix is handed over inside a larger allocation (ldt > k), only its lower triangle holds the data."""
+    assert K.small_eigh_big_ok(k, p, dtype)
+    g = torch.Generator().manual_seed(k + p)
+    cap = k + 7
+    for kind in ("ritz", "random"):
+        if kind == "ritz":
+            Q, _ = torch.linalg.qr(torch.randn(B, k, k, dtype=torch.float64, generator=g))
+            d = torch.cat([torch.arange(1.0, 9.0, dtype=torch.float64),
+                           50.0 + 50.0 * torch.arange(k - 8, dtype=torch.float64) / (k - 8)])
+            Tm = Q @ torch.diag_embed(d.expand(B, k)) @ Q.transpose(-2, -1)
+        else:
+            R = torch.randn(B, k, k, dtype=torch.float64, generator=g)
+            Tm = R + R.transpose(-2, -1)
+        Tm = (Tm + Tm.transpose(-2, -1)) * 0.5
+        lam_ref = torch.linalg.eigvalsh(Tm)
+        buf = torch.full((B, cap, cap), float("nan"), dtype=dtype)
+        buf[:, :k, :k] = torch.tril(Tm).to(dtype) + torch.triu(torch.full((k, k), float("nan"), dtype=dtype), 1)
+        lam, Y, info = K.small_eigh_big(buf.to(dev), k, p, uppest=uppest)
+        assert int(info.max()) == 0
+        lam, Y = lam.cpu().double(), Y.cpu().double()
+        sl = slice(k - p, k) if uppest else slice(0, p)
+        tol = 1e-12 if dtype == torch.float64 else 3e-5
+        scale = lam_ref.abs().max().item()
+        assert (lam - lam_ref[:, sl]).abs().max().item() < tol * scale * 10, kind
+        assert torch.all(lam[:, 1:] >= lam[:, :-1])
+        Yc = Y.transpose(-2, -1)
+        res = torch.matmul(Tm, Yc) - Yc * lam.unsqueeze(-2)
+        assert res.abs().max().item() < tol * scale * 100, kind
+        G = torch.matmul(Yc.transpose(-2, -1), Yc)
+        assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, kind

@@ -73,6 +73,10 @@ def _declare(L):
     sigs["xk_small_eigh_tri_set_profile"] = (I, [P])
     for sfx in ("f64", "f32"):
         sigs["xk_small_eigh_tri_" + sfx] = (I, [P, P, P, P, I, I, I, I, Lg, Lg, P])
+    sigs["xk_small_eigh_big_batch"] = (I, [I, I, I])
+    sigs["xk_small_eigh_big_workspace_elems"] = (Lg, [I, I])
+    for sfx in ("f64", "f32"):
+        sigs["xk_small_eigh_big_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, Lg, Lg, P])
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
     sigs["xk_dense_symm_tune"] = (I, [I, I])

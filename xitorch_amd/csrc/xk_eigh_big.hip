@@ -1,0 +1,537 @@
+// xitorch_amd :: K3g — the p wanted eigenpairs of Rayleigh–Ritz matrices of order 129 .. 768, one workgroup per batch
+// member, the MATRIX in global memory (L2 / Infinity-Cache resident: 2 MB at order 512), everything else in LDS.
+//
+// The un-restarted Davidson iteration of the reference (xitorch/_impls/linalg/symeig.py:132-135: the basis grows by
+// neig vectors per iteration until convergence, :174-175: torch.linalg.eigh of the full T every iteration) reaches
+// bases of 300-800 vectors on slowly converging spectra.  The LDS-resident kernels (xk_eigh.hip, xk_eigh_tri.hip)
+// stop at order 128; beyond that round 2 fell back to torch.linalg.eigh -> rocSOLVER: 8.7 / 14.7 / 22 ms for the 32
+// matrices of a batch group at order 256 / 384 / 512, against 6.4 ms of operator-panel product to hide under, i.e.
+// two thirds of the call on the S2 spectrum (profiles/r03_secondary_configs.jsonl).
+//
+// Same route as K3t (LAPACK's dsyevx: dsytd2 / dstebz / dstein / dormtr):
+//   0. copy:             the lower triangle of T (eigh's UPLO = 'L') mirrored into a full symmetric work copy S
+//   1. tridiagonalise:   Householder, k-2 steps, 2 barriers each.  Every wave recomputes the reflector from row j
+//                        (lane <-> columns j+1+lane+64t), accumulates the column form of S v over ITS rows (no
+//                        cross-lane reduction per row), partials meet in LDS; rank-2 update of the rows; the reflector
+//                        is parked in row j (contiguous: the back-transformation reads it coalesced).
+//                        S is read with sc1 loads (L2-served: another wave's stores are never seen through this CU's
+//                        L1) and every step ends with vmcnt(0) before its barrier (the stores have reached L2).
+//   2. bisection, 3. inverse iteration (in batches of pb shifts: the LU factors of 5 n pb elements are what limits LDS),
+//   5. self-check, 4. back-transformation y = H_0 ... H_{k-3} z (one wave per vector, next reflector prefetched).
+// The result is checked like K3t's (residual on the tridiagonal level, orthogonality, non-finite, annihilated iterate);
+// a flagged member makes the caller repeat the step on the library solver.
+#include "xk_common.h"
+
+namespace xk {
+
+template <typename T> struct BigEps;
+template <> struct BigEps<double> { static constexpr double eps = 2.220446049250313e-16; static constexpr double tiny = 2.2250738585072014e-308; };
+template <> struct BigEps<float> { static constexpr float eps = 1.1920929e-07f; static constexpr float tiny = 1.17549435e-38f; };
+
+constexpr int BIG_MAXP = 16;
+
+__device__ __forceinline__ double big_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float big_readlane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double big_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float big_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  r = fmaf(fmaf(-x, r, 1.0f), r, r);
+  return r;
+}
+// L2-served load: bypasses this CU's vector L1, which a store of another wave does not refresh
+template <typename T>
+__device__ __forceinline__ T ld_l2(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all outstanding vector memory operations of this wave have completed (stores acknowledged by L2)
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+
+// value of element r (0-based, wave-uniform) of a vector distributed as slot[t] of lane l <-> element l + 64 t
+template <typename T, int NT>
+__device__ __forceinline__ T dist_get(const T (&v)[NT], int r) {
+  const int t = r >> 6, l = r & 63;
+  T out = T(0);
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+    if (u == t) out = big_readlane(v[u], l);        // t is wave-uniform: a scalar branch per slot
+  return out;
+}
+
+template <typename T>
+__device__ __forceinline__ int big_sturm(const T* __restrict__ dd, const T* __restrict__ e2, int n, T sigma, T pivmin) {
+  T q = dd[0] - sigma;
+  if (fabs(q) < pivmin) q = -pivmin;
+  int cnt = q < T(0) ? 1 : 0;
+  for (int i = 1; i < n; ++i) {
+    q = dd[i] - sigma - e2[i - 1] * big_rcp(q);
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += q < T(0) ? 1 : 0;
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ unsigned big_hash(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
+    const T* __restrict__ Tin, T* __restrict__ Sws, T* __restrict__ lam_out, T* __restrict__ Y_out,
+    int* __restrict__ info_out, int n, int p, int pb, int uppest, long ldt, long sT) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* dd = reinterpret_cast<T*>(smem);                 // n  diagonal of the tridiagonal matrix
+  T* ee = dd + n;                                     // n  sub-diagonal
+  T* e2 = ee + n;                                     // n  squares
+  T* tau = e2 + n;                                    // n
+  T* red = tau + n;                                   // 16 scratch scalars
+  T* lamv = red + 16;                                 // BIG_MAXP eigenvalues
+  T* Z = lamv + BIG_MAXP;                             // p x n eigenvectors of (d, e)
+  T* lu = Z + (long)p * n;                            // max(nw x n partial products, 5 x n x pb LU factors); nw = 8 waves (512 threads:
+                                                      // 2 waves per SIMD, 256 VGPRs each for the NT-slot vectors)
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, nw = nt >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* Tb = Tin + (long)b * sT;
+  T* S = Sws + (long)b * n * n;
+  const T eps = BigEps<T>::eps;
+
+  // ---- 0. work copy: lower triangle mirrored ----------------------------------------------------------
+  for (int idx = tid; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    S[idx] = (i >= j) ? Tb[(long)i * ldt + j] : Tb[(long)j * ldt + i];
+  }
+  vm_drain();
+  __syncthreads();
+
+  // ---- 1. Householder tridiagonalisation on the global copy ---------------------------------------------
+  T* part = lu;                                       // nw x n
+  for (int j = 0; j + 2 < n; ++j) {
+    const T* rowj = S + (long)j * n;
+    T x[NT], v[NT];
+    T ss = T(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = j + 1 + lane + 64 * t;
+      x[t] = c < n ? ld_l2(rowj + c) : T(0);
+      if (!(t == 0 && lane == 0)) ss += x[t] * x[t];
+    }
+    const T sigma = wave_sum_dpp(ss);
+    const T alpha = big_readlane(x[0], 0);
+    T tj = T(0), scale = T(0), beta = alpha;
+    if (!(sigma == T(0))) {                           // (a NaN row must poison the result, not be skipped)
+      const T nrm = sqrt(alpha * alpha + sigma);
+      beta = alpha >= T(0) ? -nrm : nrm;
+      tj = (beta - alpha) * big_rcp(beta);
+      scale = big_rcp(alpha - beta);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = (t == 0 && lane == 0) ? T(1) : x[t] * scale;
+    if (tj != T(0)) {                                 // (wave-uniform and identical in every wave)
+      T acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = T(0);
+      int i = j + 1 + wave;
+      for (; i + nw < n; i += 2 * nw) {               // two rows per trip: 2 NT loads in flight
+        const T* r0 = S + (long)i * n;
+        const T* r1 = S + (long)(i + nw) * n;
+        const T vi0 = dist_get<T, NT>(v, i - j - 1), vi1 = dist_get<T, NT>(v, i + nw - j - 1);
+        T s0[NT], s1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = j + 1 + lane + 64 * t;
+          s0[t] = c < n ? ld_l2(r0 + c) : T(0);
+          s1[t] = c < n ? ld_l2(r1 + c) : T(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += s0[t] * vi0 + s1[t] * vi1;
+      }
+      if (i < n) {
+        const T* r0 = S + (long)i * n;
+        const T vi0 = dist_get<T, NT>(v, i - j - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = j + 1 + lane + 64 * t;
+          acc[t] += (c < n ? ld_l2(r0 + c) : T(0)) * vi0;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = j + 1 + lane + 64 * t;
+        if (c < n) part[wave * n + c] = acc[t];
+      }
+    }
+    __syncthreads();
+    if (tj != T(0)) {
+      T w[NT], q[NT];
+      T wv = T(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = j + 1 + lane + 64 * t;
+        T sw_ = T(0);
+        if (c < n)
+          for (int ww_ = 0; ww_ < nw; ++ww_) sw_ += part[ww_ * n + c];
+        w[t] = sw_ * tj;
+        wv += w[t] * v[t];
+      }
+      const T K = T(0.5) * tj * wave_sum_dpp(wv);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) q[t] = w[t] - K * v[t];
+      int i = j + 1 + wave;
+      for (; i + nw < n; i += 2 * nw) {
+        T* r0 = S + (long)i * n;
+        T* r1 = S + (long)(i + nw) * n;
+        const int ra = i - j - 1, rb = ra + nw;
+        const T via = dist_get<T, NT>(v, ra), qia = dist_get<T, NT>(q, ra);
+        const T vib = dist_get<T, NT>(v, rb), qib = dist_get<T, NT>(q, rb);
+        T s0[NT], s1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = j + 1 + lane + 64 * t;
+          s0[t] = c < n ? ld_l2(r0 + c) : T(0);
+          s1[t] = c < n ? ld_l2(r1 + c) : T(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = j + 1 + lane + 64 * t;
+          if (c < n) {
+            r0[c] = s0[t] - (via * q[t] + qia * v[t]);
+            r1[c] = s1[t] - (vib * q[t] + qib * v[t]);
+          }
+        }
+      }
+      if (i < n) {
+        T* r0 = S + (long)i * n;
+        const int ra = i - j - 1;
+        const T vi = dist_get<T, NT>(v, ra), qi = dist_get<T, NT>(q, ra);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = j + 1 + lane + 64 * t;
+          if (c < n) r0[c] = ld_l2(r0 + c) - (vi * q[t] + qi * v[t]);
+        }
+      }
+    }
+    if (wave == 0) {
+      // row j (right of the diagonal) is no longer read by anybody: park the reflector there
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = j + 1 + lane + 64 * t;
+        if (c < n && c > j + 1) S[(long)j * n + c] = v[t];
+      }
+      if (lane == 0) { tau[j] = tj; ee[j] = beta; dd[j] = ld_l2(S + (long)j * n + j); }
+    }
+    vm_drain();
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (n >= 2) { dd[n - 2] = ld_l2(S + (long)(n - 2) * n + (n - 2)); ee[n - 2] = ld_l2(S + (long)(n - 2) * n + (n - 1)); }
+    dd[n - 1] = ld_l2(S + (long)(n - 1) * n + (n - 1));
+    if (n >= 1) ee[n - 1] = T(0);
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) e2[i] = ee[i] * ee[i];
+  __syncthreads();
+
+  // ---- 2. bisection: wave w -> wanted eigenvalue number w (ascending) ---------------------------------
+  T gl = T(INFINITY), gu = T(-INFINITY), emax = T(0);
+  for (int i = lane; i < n; i += 64) {
+    const T r = (i > 0 ? fabs(ee[i - 1]) : T(0)) + (i < n - 1 ? fabs(ee[i]) : T(0));
+    gl = fmin(gl, dd[i] - r);
+    gu = fmax(gu, dd[i] + r);
+    emax = fmax(emax, e2[i]);
+  }
+  gl = -wave_max(-gl);
+  gu = wave_max(gu);
+  emax = wave_max(emax);
+  const T tnorm = fmax(fabs(gl), fabs(gu));
+  const T pivmin = BigEps<T>::tiny * fmax(T(1), emax);
+  for (int w = wave; w < p; w += nw) {
+    const int target = (uppest ? n - p + w : w) + 1;
+    T lo = gl - (T(2) * eps * tnorm * n + T(2) * pivmin);
+    T hi = gu + (T(2) * eps * tnorm * n + T(2) * pivmin);
+    for (int round = 0; round < 24; ++round) {
+      const T width = hi - lo;
+      if (!(width > T(2) * eps * fmax(fabs(lo), fabs(hi)) + T(2) * pivmin)) break;
+      const T sig = lo + width * (T(lane + 1) / T(65));
+      const int c = big_sturm(dd, e2, n, sig, pivmin);
+      const unsigned long long ge = __ballot(c >= target);
+      const int f = ge ? __ffsll((long long)ge) - 1 : 64;
+      const T sig_f = __shfl(sig, f < 64 ? f : 63, 64);
+      const T sig_fm = __shfl(sig, f > 0 ? f - 1 : 0, 64);
+      const T nlo = f > 0 ? sig_fm : lo;
+      const T nhi = f < 64 ? sig_f : hi;
+      if (!(nhi > nlo)) break;
+      lo = nlo; hi = nhi;
+    }
+    if (lane == 0) lamv[w] = T(0.5) * (lo + hi);
+  }
+  if (tid == 0) red[15] = T(0);                       // "an iterate was annihilated / non-finite" flag of step 3
+  __syncthreads();
+
+  // ---- 3. inverse iteration (dstein), vectors in order, pb shifts factorised at a time -----------------
+  const T pfloor = eps * tnorm + pivmin;
+#define AT(arr, i) (arr)[(long)(i) * pb]
+  for (int j0 = 0; j0 < p; j0 += pb) {
+    const int nb = p - j0 < pb ? p - j0 : pb;
+    if (tid < nb) {
+      const int jl = tid, j = j0 + tid;
+      T shift = lamv[j];
+      for (int q = j - 1; q >= 0; --q) {
+        if (lamv[j] - lamv[q] < T(10) * eps * tnorm) shift += T(10) * eps * tnorm; else break;
+      }
+      T* dl = lu + ((long)0 * n) * pb + jl;
+      T* dg = lu + ((long)1 * n) * pb + jl;
+      T* du = lu + ((long)2 * n) * pb + jl;
+      T* du2 = lu + ((long)3 * n) * pb + jl;
+      T* sw = lu + ((long)4 * n) * pb + jl;
+      for (int i = 0; i < n; ++i) {
+        AT(dg, i) = dd[i] - shift;
+        AT(dl, i) = (i < n - 1) ? ee[i] : T(0);
+        AT(du, i) = (i < n - 1) ? ee[i] : T(0);
+        AT(du2, i) = T(0);
+        AT(sw, i) = T(0);
+      }
+      for (int i = 0; i + 1 < n; ++i) {               // LU with partial pivoting (dgttrf)
+        T di = AT(dg, i);
+        const T li = AT(dl, i);
+        if (fabs(di) >= fabs(li)) {
+          if (fabs(di) < pfloor) { di = di < T(0) ? -pfloor : pfloor; AT(dg, i) = di; }
+          const T fact = li * big_rcp(di);
+          AT(dl, i) = fact;
+          AT(dg, i + 1) -= fact * AT(du, i);
+        } else {
+          const T fact = di * big_rcp(li);
+          AT(dg, i) = li;
+          AT(dl, i) = fact;
+          const T tmp = AT(du, i);
+          const T dn = AT(dg, i + 1);
+          AT(du, i) = dn;
+          AT(dg, i + 1) = tmp - fact * dn;
+          if (i + 2 < n) {
+            const T un = AT(du, i + 1);
+            AT(du2, i) = un;
+            AT(du, i + 1) = -fact * un;
+          }
+          AT(sw, i) = T(1);
+        }
+      }
+      {
+        T dl_ = AT(dg, n - 1);
+        if (fabs(dl_) < pfloor) AT(dg, n - 1) = dl_ < T(0) ? -pfloor : pfloor;
+      }
+      for (int i = 0; i < n; ++i) AT(dg, i) = big_rcp(AT(dg, i));
+      T* z = Z + (long)j * n;
+      for (int i = 0; i < n; ++i) {
+        const unsigned h = big_hash((unsigned)(i * 131 + j * 7919 + 12345));
+        z[i] = T((int)(h & 0xffffff) - 0x800000) / T(0x800000);
+      }
+    }
+    __syncthreads();
+    for (int it = 0; it < 3; ++it) {
+      if (tid < nb) {
+        const int jl = tid, j = j0 + tid;
+        T* dl = lu + ((long)0 * n) * pb + jl;
+        T* dg = lu + ((long)1 * n) * pb + jl;
+        T* du = lu + ((long)2 * n) * pb + jl;
+        T* du2 = lu + ((long)3 * n) * pb + jl;
+        T* sw = lu + ((long)4 * n) * pb + jl;
+        T* z = Z + (long)j * n;
+        T cur = z[0];
+        for (int i = 0; i + 1 < n; ++i) {
+          const T nxt = z[i + 1];
+          const T l = AT(dl, i);
+          if (AT(sw, i) == T(0)) { z[i] = cur; cur = nxt - l * cur; }
+          else { z[i] = nxt; cur = cur - l * nxt; }
+        }
+        T zp1 = cur * AT(dg, n - 1), zp2 = T(0);
+        z[n - 1] = zp1;
+        if (n > 1) {
+          const T t = (z[n - 2] - AT(du, n - 2) * zp1) * AT(dg, n - 2);
+          z[n - 2] = t;
+          zp2 = zp1; zp1 = t;
+        }
+        for (int i = n - 3; i >= 0; --i) {
+          const T t = (z[i] - AT(du, i) * zp1 - AT(du2, i) * zp2) * AT(dg, i);
+          z[i] = t;
+          zp2 = zp1; zp1 = t;
+        }
+        T mx = T(0);
+        for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(z[i]));
+        const T inv = mx > T(0) ? T(1) / mx : T(1);
+        for (int i = 0; i < n; ++i) z[i] *= inv;
+      }
+      __syncthreads();
+      // modified Gram–Schmidt against ALL earlier vectors (finished batches and this batch) + normalisation
+      if (wave == 0) {
+        for (int j = j0; j < j0 + nb; ++j) {
+          T* zj = Z + (long)j * n;
+          for (int q = j - 1; q >= 0; --q) {
+            const T* zq = Z + (long)q * n;
+            T dp = T(0);
+            for (int i = lane; i < n; i += 64) dp += zq[i] * zj[i];
+            dp = wave_sum_dpp(dp);
+            for (int i = lane; i < n; i += 64) zj[i] -= dp * zq[i];
+          }
+          T nn = T(0);
+          for (int i = lane; i < n; i += 64) nn += zj[i] * zj[i];
+          nn = wave_sum_dpp(nn);
+          const T inv = nn > T(0) ? rsqrt(nn) : T(0);
+          if (lane == 0 && it == 2 && !(nn > T(0) && nn < T(INFINITY))) red[15] = T(1);
+          for (int i = lane; i < n; i += 64) zj[i] *= inv;
+        }
+      }
+      __syncthreads();
+    }
+  }
+#undef AT
+
+  // ---- 5. checks on the tridiagonal level ----------------------------------------------------------------
+  if (wave == 0) {
+    T worst = T(0);
+    int nonfinite = 0;
+    for (int j = 0; j < p; ++j) {
+      const T* zj = Z + (long)j * n;
+      const T lam = lamv[j];
+      T r = T(0);
+      for (int i = lane; i < n; i += 64) {
+        T t = (dd[i] - lam) * zj[i];
+        if (i > 0) t += ee[i - 1] * zj[i - 1];
+        if (i < n - 1) t += ee[i] * zj[i + 1];
+        if (!(fabs(t) < T(INFINITY))) nonfinite = 1;
+        r = fmax(r, fabs(t));
+      }
+      r = wave_max(r);
+      worst = fmax(worst, r);
+      if (j > 0) {
+        const T* zq = Z + (long)(j - 1) * n;
+        T dp = T(0);
+        for (int i = lane; i < n; i += 64) dp += zq[i] * zj[i];
+        dp = fabs(wave_sum_dpp(dp));
+        if (!(dp < T(INFINITY))) nonfinite = 1;
+        worst = fmax(worst, dp * tnorm);
+      }
+    }
+    nonfinite = __any(nonfinite) ? 1 : 0;
+    if (!(tnorm < T(INFINITY))) nonfinite = 1;
+    if (red[15] != T(0)) nonfinite = 1;
+    if (lane == 0) {
+      const T tol = T(100) * eps * tnorm * T(n > 128 ? 4 : 1) + T(8) * pivmin;
+      info_out[b] = (worst <= tol && !nonfinite) ? 0 : 1;
+    }
+  }
+  __syncthreads();
+
+  // ---- 4. back-transformation y = H_0 ... H_{n-3} z, one wave per vector, next reflector prefetched -------
+  for (int j = wave; j < p; j += nw) {
+    const T* zj = Z + (long)j * n;
+    T y[NT], vn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int i = lane + 64 * t;
+      y[t] = i < n ? zj[i] : T(0);
+    }
+    int r = n - 3;
+    if (r >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int i = lane + 64 * t;
+        vn[t] = (i < n && i > r + 1) ? ld_l2(S + (long)r * n + i) : T(0);
+      }
+    }
+    for (; r >= 0; --r) {
+      T vc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int i = lane + 64 * t;
+        vc[t] = (i == r + 1) ? T(1) : vn[t];        // v_r: rows <= r are 0, row r+1 is 1, rows > r+1 parked in row r
+      }
+      if (r > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int i = lane + 64 * t;
+          vn[t] = (i < n && i > r) ? ld_l2(S + (long)(r - 1) * n + i) : T(0);
+        }
+      }
+      const T tr = tau[r];
+      if (tr == T(0)) continue;
+      T dp = T(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dp += vc[t] * y[t];
+      dp = wave_sum_dpp(dp);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) y[t] -= tr * dp * vc[t];
+    }
+    T* Yb = Y_out + ((long)b * p + j) * n;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int i = lane + 64 * t;
+      if (i < n) Yb[i] = y[t];
+    }
+    if (lane == 0) lam_out[(long)b * p + j] = lamv[j];
+  }
+}
+
+// LDS elements for order n, p wanted pairs, LU batches of pb shifts, nw waves
+static long big_lds_elems(long n, long p, long pb, long nw) {
+  const long scratch = 5L * n * pb > nw * n ? 5L * n * pb : nw * n;
+  return 4 * n + 16 + BIG_MAXP + p * n + scratch;
+}
+
+}  // namespace xk
+
+extern "C" {
+
+/* the LU batch size (shifts factorised at a time) the kernel would use for order k, p pairs, or 0 when it does not
+ * fit the 160 KiB of LDS at all (elem_size 8 / 4) */
+int xk_small_eigh_big_batch(int k, int p, int elem_size) {
+  if (k < 2 || k > 768 || p < 1 || p > xk::BIG_MAXP || p > k) return 0;
+  for (int pb = p; pb >= 1; --pb)
+    if (xk::big_lds_elems(k, p, pb, 8) * elem_size + 64 <= 160 * 1024) return pb;
+  return 0;
+}
+
+long xk_small_eigh_big_workspace_elems(int B, int k) { return (long)B * k * k; }
+
+#define XK_DEFINE_EIGH_BIG(SUF, T)                                                                            \
+  int xk_small_eigh_big_##SUF(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k,      \
+                              int p, int uppest, long ldt, long sT, void* stream) {                           \
+    if (B < 0 || k < 2 || k > 768 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                   \
+    if (B == 0) return XK_OK;                                                                                 \
+    if (ws == nullptr || ws_elems < (long)B * k * k) return XK_ERR_ARG;                                       \
+    const int pb = xk_small_eigh_big_batch(k, p, (int)sizeof(T));                                             \
+    if (pb == 0) return XK_ERR_UNSUPPORTED;                                                                   \
+    const long lds = xk::big_lds_elems(k, p, pb, 8) * (long)sizeof(T) + 64;                                  \
+    hipError_t e;                                                                                             \
+    if (k <= 512) {                                                                                           \
+      e = hipFuncSetAttribute((const void*)xk::tridiag_eigh_big_kernel<T, 8>,                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+      if (e != hipSuccess) return (int)e;                                                                     \
+      hipLaunchKernelGGL((xk::tridiag_eigh_big_kernel<T, 8>), dim3(B), dim3(512), (size_t)lds,               \
+                         (hipStream_t)stream, Tin, ws, lam, Y, info, k, p, pb, uppest, ldt, sT);              \
+    } else {                                                                                                  \
+      e = hipFuncSetAttribute((const void*)xk::tridiag_eigh_big_kernel<T, 12>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+      if (e != hipSuccess) return (int)e;                                                                     \
+      hipLaunchKernelGGL((xk::tridiag_eigh_big_kernel<T, 12>), dim3(B), dim3(512), (size_t)lds,              \
+                         (hipStream_t)stream, Tin, ws, lam, Y, info, k, p, pb, uppest, ldt, sT);              \
+    }                                                                                                         \
+    XK_LAUNCH_CHECK();                                                                                        \
+    return XK_OK;                                                                                             \
+  }
+
+XK_DEFINE_EIGH_BIG(f64, double)
+XK_DEFINE_EIGH_BIG(f32, float)
+
+}  // extern "C"

@@ -243,6 +243,36 @@ def small_eigh_tri_ok(k, p, dtype):
     return fn("xk_small_eigh_tri_lds_bytes")(k, p, esize) <= 160 * 1024
 
 
+SMALL_EIGH_BIG_MAX_K = 768
+
+
+def small_eigh_big_ok(k, p, dtype):
+    """does the global-memory tridiagonalisation kernel (K3g) serve order k with p wanted pairs?"""
+    if k < 2 or k > SMALL_EIGH_BIG_MAX_K or p > SMALL_EIGH_MAX_P or p > k:
+        return False
+    return fn("xk_small_eigh_big_batch")(k, p, 8 if dtype == torch.float64 else 4) > 0
+
+
+def small_eigh_big(T, k, p, uppest=False):
+    """K3g: lowest / uppermost p eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower triangle read) for
+    orders beyond the LDS-resident kernels (129 .. 768): lam (B, p) ascending, Y (B, p, k), failure flags (B,) int32
+    (nonzero -> redo with the library).  Replaces torch.linalg.eigh + _take_eigpairs (symeig.py:174-175) on the large
+    bases of an un-restarted run."""
+    require_device(T, "projected matrix")
+    B = T.shape[0]
+    if T.stride(2) != 1:
+        raise _capi.NativeLibraryError("T must have unit stride along its last dim")
+    lam = torch.empty((B, p), dtype=T.dtype, device=T.device)
+    Y = torch.empty((B, p, k), dtype=T.dtype, device=T.device)
+    info = torch.empty((B,), dtype=torch.int32, device=T.device)
+    nws = fn("xk_small_eigh_big_workspace_elems")(B, k)
+    ws = _workspace(nws, T.dtype, T.device)
+    rc = fn("xk_small_eigh_big_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(ws), nws, ptr(info), B, k, p,
+                                                     1 if uppest else 0, T.stride(1), T.stride(0), stream_ptr())
+    check(rc, "xk_small_eigh_big")
+    return lam, Y, info
+
+
 def small_eigh(T, k, p, uppest=False, max_sweeps=16, method="jacobi"):
     """Lowest / uppermost `p` eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower
     triangle is read).  Returns lam (B, p) ascending, Y (B, p, k) with Y[b, c] the c-th eigenvector, and an int32

@@ -245,8 +245,21 @@ class _Group:
                 sl = slice(0, p) if self.mode == "lowest" else slice(pk - p, pk)
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
+        elif self.small_eigh in ("native", "tri") and not force_jacobi and k > K.SMALL_EIGH_MAX_K and \
+                K.small_eigh_big_ok(k, pk, self.dtype):
+            # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra): the same
+            # tridiagonalisation route with the matrix in global memory; a flagged result is redone on the library
+            # (the driver's force_jacobi re-run lands in the branch below)
+            end = self._mark("k3")
+            lam, Yt, tri_flag = K.small_eigh_big(self.T, k, pk, uppest=(self.mode != "lowest"))
+            end()
+            if due:
+                self._compress = (Yt, lam)
+                sl = slice(0, p) if self.mode == "lowest" else slice(pk - p, pk)
+                lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
+            Y = Yt.transpose(1, 2)
         else:
-            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # large bases: library eigh
+            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 16 pairs, > 768
             if due:
                 lk, Yk = take_eigpairs(lam_all, Y_all, pk, self.mode)
                 self._compress = (Yk.transpose(1, 2).contiguous(), lk.contiguous())
@@ -419,11 +432,12 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         reference's CPU path bit for bit; ``"device"``: drawn on the operator's device, which is what
         the reference does for a GPU-resident operator
     small_eigh: str
-        (extension) ``"native"`` (default): while the basis has <= 128 vectors the wanted eigenpairs of the
-        Rayleigh–Ritz matrix come from the LDS-resident kernels — Householder tridiagonalisation + bisection +
-        inverse iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's
-        self-check flags a result; ``"jacobi"`` / ``"tri"`` force one of them; ``"library"``: always
-        ``torch.linalg.eigh``
+        (extension) ``"native"`` (default): the wanted eigenpairs of the Rayleigh–Ritz matrix come from native
+        kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
+        iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
+        flags a result; from 129 to 768 vectors the same route with the matrix in global memory (K3g, fallback:
+        the library); ``torch.linalg.eigh`` beyond that and for more than 16 wanted pairs; ``"jacobi"`` / ``"tri"``
+        force one of the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
         products of both groups run back to back on one stream whose CU mask leaves ``reserve_cus`` compute
