@@ -497,7 +497,7 @@ def test_unrestarted_run_beyond_128_vectors_stays_native(dev, monkeypatch):
     128 vectors of the LDS-resident eigensolvers (symeig.py:132-135, 174-175); from 129 to 768 vectors the
     Rayleigh-Ritz step runs on K3g — no library eigh on the way — and reproduces the closed-form eigenvalues."""
     from xitorch_amd import synthetic
-    B, N, p = 2, 4096, 6
+    B, N, p = 2, 2048, 6
     mat = synthetic.dense_symmetric(B, N, "S2", dtype=torch.float64, device=dev)
     A = xa.LinearOperator.m(mat, is_hermitian=True)
     calls = []
@@ -505,7 +505,8 @@ def test_unrestarted_run_beyond_128_vectors_stays_native(dev, monkeypatch):
     monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (calls.append(1), real_eigh(*a, **k))[1])
     tr = {}
     ev, X = davidson(A, p, "lowest", min_eps=1e-8, trace=tr)
-    assert tr["stop_reason"] == "converged" and tr["basis_size"] > 128 and tr["basis_size"] <= 768, tr["basis_size"]
+    # (S2 at N = 2048: 53 iterations in the reference's probe, SURVEY 8d -> a basis of ~320 <= 352, K3g's range at B = 2)
+    assert tr["stop_reason"] == "converged" and 128 < tr["basis_size"] <= 352, tr["basis_size"]
     assert not calls and tr["k3_fallbacks"] == 0
     exact = synthetic.spectrum("S2", N, device=dev)[:p]
     assert (ev - exact).abs().max().item() <= 1e-10

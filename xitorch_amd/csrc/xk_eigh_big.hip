@@ -20,6 +20,14 @@
 //   5. self-check, 4. back-transformation y = H_0 ... H_{k-3} z (one wave per vector, next reflector prefetched).
 // The result is checked like K3t's (residual on the tridiagonal level, orthogonality, non-finite, annihilated iterate);
 // a flagged member makes the caller repeat the step on the library solver.
+//
+// Measured (fp64, p = 6, 32 matrices; profiles/r03_k3g_vs_library.jsonl): order 192 / 256 / 384 / 512 / 640 / 768:
+// 2.6 / 4.6 / 11.3 / 24.0 / 47.5 / 75 ms against rocSOLVER's 5.4 / 8.7 / 14.7 / 22.0 / 32.7 / 43.7 ms; the same per
+// matrix whether 4 or 32 run (one workgroup = one CU per matrix, bound by that CU's L2 bandwidth), so the library,
+// which spreads one matrix over the chip, wins from order ~480 (32 matrices) / ~360 (4 matrices) on: the Davidson
+// driver switches there (native_eig.py).  What would lift it: the look-ahead form (update of step j fused with the
+// product of step j+1: 2 passes instead of 3) and several workgroups per matrix with a cross-workgroup hand-off per
+// step — not built.
 #include "xk_common.h"
 
 namespace xk {
@@ -90,6 +98,10 @@ template <typename T, int NT>
 __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     const T* __restrict__ Tin, T* __restrict__ Sws, T* __restrict__ lam_out, T* __restrict__ Y_out,
     int* __restrict__ info_out, int n, int p, int pb, int uppest, long ldt, long sT) {
+  // rows per trip of the matrix sweeps (loads in flight per wave = RPT x column slots).  Measured at order 512, 32
+  // matrices: 24.0 ms with 2, 28.6 ms with 4 — the sweeps are bound by what ONE compute unit draws from L2 (three
+  // passes over the trailing block per step: 6.3 MB at order 512 = 47 us at ~130 GB/s), not by the loads in flight
+  constexpr int RPT = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* dd = reinterpret_cast<T*>(smem);                 // n  diagonal of the tridiagonal matrix
   T* ee = dd + n;                                     // n  sub-diagonal
@@ -144,21 +156,24 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = T(0);
       int i = j + 1 + wave;
-      for (; i + nw < n; i += 2 * nw) {               // two rows per trip: 2 NT loads in flight
-        const T* r0 = S + (long)i * n;
-        const T* r1 = S + (long)(i + nw) * n;
-        const T vi0 = dist_get<T, NT>(v, i - j - 1), vi1 = dist_get<T, NT>(v, i + nw - j - 1);
-        T s0[NT], s1[NT];
+      for (; i + (RPT - 1) * nw < n; i += RPT * nw) {
+        T sr[RPT][NT], vi[RPT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int c = j + 1 + lane + 64 * t;
-          s0[t] = c < n ? ld_l2(r0 + c) : T(0);
-          s1[t] = c < n ? ld_l2(r1 + c) : T(0);
+        for (int u = 0; u < RPT; ++u) {
+          const T* ru = S + (long)(i + u * nw) * n;
+          vi[u] = dist_get<T, NT>(v, i + u * nw - j - 1);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int c = j + 1 + lane + 64 * t;
+            sr[u][t] = c < n ? ld_l2(ru + c) : T(0);
+          }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] += s0[t] * vi0 + s1[t] * vi1;
+        for (int u = 0; u < RPT; ++u)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] += sr[u][t] * vi[u];
       }
-      if (i < n) {
+      for (; i < n; i += nw) {
         const T* r0 = S + (long)i * n;
         const T vi0 = dist_get<T, NT>(v, i - j - 1);
 #pragma unroll
@@ -190,36 +205,37 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
 #pragma unroll
       for (int t = 0; t < NT; ++t) q[t] = w[t] - K * v[t];
       int i = j + 1 + wave;
-      for (; i + nw < n; i += 2 * nw) {
-        T* r0 = S + (long)i * n;
-        T* r1 = S + (long)(i + nw) * n;
-        const int ra = i - j - 1, rb = ra + nw;
-        const T via = dist_get<T, NT>(v, ra), qia = dist_get<T, NT>(q, ra);
-        const T vib = dist_get<T, NT>(v, rb), qib = dist_get<T, NT>(q, rb);
-        T s0[NT], s1[NT];
+      for (; i + (RPT - 1) * nw < n; i += RPT * nw) {
+        T sr[RPT][NT], vi[RPT], qi[RPT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int c = j + 1 + lane + 64 * t;
-          s0[t] = c < n ? ld_l2(r0 + c) : T(0);
-          s1[t] = c < n ? ld_l2(r1 + c) : T(0);
+        for (int u = 0; u < RPT; ++u) {
+          const T* ru = S + (long)(i + u * nw) * n;
+          vi[u] = dist_get<T, NT>(v, i + u * nw - j - 1);
+          qi[u] = dist_get<T, NT>(q, i + u * nw - j - 1);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int c = j + 1 + lane + 64 * t;
+            sr[u][t] = c < n ? ld_l2(ru + c) : T(0);
+          }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int c = j + 1 + lane + 64 * t;
-          if (c < n) {
-            r0[c] = s0[t] - (via * q[t] + qia * v[t]);
-            r1[c] = s1[t] - (vib * q[t] + qib * v[t]);
+        for (int u = 0; u < RPT; ++u) {
+          T* ru = S + (long)(i + u * nw) * n;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int c = j + 1 + lane + 64 * t;
+            if (c < n) ru[c] = sr[u][t] - (vi[u] * q[t] + qi[u] * v[t]);
           }
         }
       }
-      if (i < n) {
+      for (; i < n; i += nw) {
         T* r0 = S + (long)i * n;
         const int ra = i - j - 1;
-        const T vi = dist_get<T, NT>(v, ra), qi = dist_get<T, NT>(q, ra);
+        const T vi0 = dist_get<T, NT>(v, ra), qi0 = dist_get<T, NT>(q, ra);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int c = j + 1 + lane + 64 * t;
-          if (c < n) r0[c] = ld_l2(r0 + c) - (vi * q[t] + qi * v[t]);
+          if (c < n) r0[c] = ld_l2(r0 + c) - (vi0 * q[t] + qi0 * v[t]);
         }
       }
     }

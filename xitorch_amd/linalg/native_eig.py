@@ -246,7 +246,9 @@ class _Group:
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
         elif self.small_eigh in ("native", "tri") and not force_jacobi and k > K.SMALL_EIGH_MAX_K and \
-                K.small_eigh_big_ok(k, pk, self.dtype):
+                k <= (448 if self.B >= 16 else 352) and K.small_eigh_big_ok(k, pk, self.dtype):
+            # (one workgroup per matrix: bound by one CU's L2 bandwidth, the same time for 4 or 32 matrices; the library
+            #  spreads a matrix over the chip and is faster from order ~480 / ~360 on, measured: xk_eigh_big.hip)
             # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra): the same
             # tridiagonalisation route with the matrix in global memory; a flagged result is redone on the library
             # (the driver's force_jacobi re-run lands in the branch below)
@@ -435,9 +437,10 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         (extension) ``"native"`` (default): the wanted eigenpairs of the Rayleigh–Ritz matrix come from native
         kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
         iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
-        flags a result; from 129 to 768 vectors the same route with the matrix in global memory (K3g, fallback:
-        the library); ``torch.linalg.eigh`` beyond that and for more than 16 wanted pairs; ``"jacobi"`` / ``"tri"``
-        force one of the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
+        flags a result; from 129 to 448 vectors (352 for fewer than 16 batch members per group) the same route with
+        the matrix in global memory (K3g: up to 2x faster than the library there, measured; fallback: the library);
+        ``torch.linalg.eigh`` beyond that and for more than 16 wanted pairs; ``"jacobi"`` / ``"tri"`` force one of
+        the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
         products of both groups run back to back on one stream whose CU mask leaves ``reserve_cus`` compute
