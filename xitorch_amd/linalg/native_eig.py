@@ -36,6 +36,10 @@ __all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend"]
 
 import os as _os
 _PRELAUNCH = _os.environ.get("XITORCH_AMD_PRELAUNCH", "1") != "0"     # A/B: enqueue the next group's chain early
+# largest basis the global-memory Rayleigh-Ritz kernel (K3g) serves before the library takes over: one workgroup (one
+# CU's L2 bandwidth) per matrix, so its time does not depend on the batch, while the library spreads a matrix over the
+# chip.  (>= 16 matrices per group, fewer) — measured cross-over, xk_eigh_big.hip
+K3G_MAX_K = [448, 352]
 
 
 def take_eigpairs(evals, evecs, neig, mode):
@@ -246,7 +250,7 @@ class _Group:
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
         elif self.small_eigh in ("native", "tri") and not force_jacobi and k > K.SMALL_EIGH_MAX_K and \
-                k <= (448 if self.B >= 16 else 352) and K.small_eigh_big_ok(k, pk, self.dtype):
+                k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
             # (one workgroup per matrix: bound by one CU's L2 bandwidth, the same time for 4 or 32 matrices; the library
             #  spreads a matrix over the chip and is faster from order ~480 / ~360 on, measured: xk_eigh_big.hip)
             # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra): the same
