@@ -505,8 +505,8 @@ def test_unrestarted_run_beyond_128_vectors_stays_native(dev, monkeypatch):
     monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (calls.append(1), real_eigh(*a, **k))[1])
     tr = {}
     ev, X = davidson(A, p, "lowest", min_eps=1e-8, trace=tr)
-    # (S2 at N = 2048: 53 iterations in the reference's probe, SURVEY 8d -> a basis of ~320 <= 352, K3g's range at B = 2)
-    assert tr["stop_reason"] == "converged" and 128 < tr["basis_size"] <= 352, tr["basis_size"]
+    # (S2 at N = 2048: 53 iterations in the reference's probe, SURVEY 8d -> a basis of ~320 <= 448, K3g's range at B = 2)
+    assert tr["stop_reason"] == "converged" and 128 < tr["basis_size"] <= 448, tr["basis_size"]
     assert not calls and tr["k3_fallbacks"] == 0
     exact = synthetic.spectrum("S2", N, device=dev)[:p]
     assert (ev - exact).abs().max().item() <= 1e-10

@@ -11,11 +11,9 @@
 // Same route as K3t (LAPACK's dsyevx: dsytd2 / dstebz / dstein / dormtr):
 //   0. copy:             the lower triangle of T (eigh's UPLO = 'L') mirrored into a full symmetric work copy S
 //   1. tridiagonalise:   Householder, k-2 steps, 2 barriers each.  Every wave recomputes the reflector from row j
-//                        (lane <-> columns j+1+lane+64t).  Only the UPPER triangle of the trailing block is kept
-//                        current: a wave sweeps ITS rows i (columns c >= i), adds S[i][c] v_i into the lane's column
-//                        accumulators and the row sum (one DPP wave reduction per row) into the accumulator of w_i;
-//                        partials of the 8 waves meet in LDS; rank-2 update of the same triangle; the reflector is
-//                        parked in row j (contiguous: the back-transformation reads it coalesced).
+//                        (lane <-> columns j+1+lane+64t), accumulates the column form of S v over ITS rows (no
+//                        cross-lane reduction per row), partials meet in LDS; rank-2 update of the rows; the reflector
+//                        is parked in row j (contiguous: the back-transformation reads it coalesced).
 //                        S is read with sc1 loads (L2-served: another wave's stores are never seen through this CU's
 //                        L1) and every step ends with vmcnt(0) before its barrier (the stores have reached L2).
 //   2. bisection, 3. inverse iteration (in batches of pb shifts: the LU factors of 5 n pb elements are what limits LDS),
@@ -27,9 +25,13 @@
 // 2.6 / 4.6 / 11.3 / 24.0 / 47.5 / 75 ms against rocSOLVER's 5.4 / 8.7 / 14.7 / 22.0 / 32.7 / 43.7 ms; the same per
 // matrix whether 4 or 32 run (one workgroup = one CU per matrix, bound by that CU's L2 bandwidth), so the library,
 // which spreads one matrix over the chip, wins from order ~480 (32 matrices) / ~360 (4 matrices) on: the Davidson
-// driver switches there (native_eig.py).  What would lift it: the look-ahead form (update of step j fused with the
-// product of step j+1: 2 passes instead of 3) and several workgroups per matrix with a cross-workgroup hand-off per
-// step — not built.
+// driver switches near there (native_eig.py: the library's calls cost more inside the solver than in isolation, so
+// the switch sits a little later).  Also built and measured: sweeping only the upper triangle of the trailing block
+// (half the L2 traffic; per-row wave reductions and masks instead): 31.2 ms at order 512, 4.4 at 192 — slower, so the
+// sweeps are not bound by bytes either but by the dependent issue of 8-byte sc1 loads (scripts/_ab history; r03i).
+// What would lift it: 16-byte loads through an absolute column <-> lane map, the look-ahead form (update of step j
+// fused with the product of step j+1), several workgroups per matrix with a cross-workgroup hand-off per step —
+// not built.
 #include "xk_common.h"
 
 namespace xk {
@@ -157,39 +159,31 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       T acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = T(0);
-      // Only the UPPER triangle of the trailing block is kept current and read (half the traffic of a full
-      // symmetric sweep): element (i, c), c >= i, serves row i of the product through a per-row wave reduction and,
-      // for c > i, column c through the lane's accumulator.
-      for (int i = j + 1 + wave; i < n; i += RPT * nw) {
+      int i = j + 1 + wave;
+      for (; i + (RPT - 1) * nw < n; i += RPT * nw) {
         T sr[RPT][NT], vi[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-          const int iu = i + u * nw;
-          const T* ru = S + (long)(iu < n ? iu : j + 1) * n;
-          vi[u] = iu < n ? dist_get<T, NT>(v, iu - j - 1) : T(0);
+          const T* ru = S + (long)(i + u * nw) * n;
+          vi[u] = dist_get<T, NT>(v, i + u * nw - j - 1);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const int c = j + 1 + lane + 64 * t;
-            sr[u][t] = (iu < n && c < n && c >= iu) ? ld_l2(ru + c) : T(0);
+            sr[u][t] = c < n ? ld_l2(ru + c) : T(0);
           }
         }
 #pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-          const int iu = i + u * nw;
-          T rs = T(0);
+        for (int u = 0; u < RPT; ++u)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int c = j + 1 + lane + 64 * t;
-            rs += sr[u][t] * v[t];                               // row part (diagonal included)
-            if (c > iu) acc[t] += sr[u][t] * vi[u];              // column part
-          }
-          rs = wave_sum_dpp(rs);
-          if (iu < n) {
-            const int r = iu - j - 1;                            // owner of w_i: lane r & 63, slot r >> 6
+          for (int t = 0; t < NT; ++t) acc[t] += sr[u][t] * vi[u];
+      }
+      for (; i < n; i += nw) {
+        const T* r0 = S + (long)i * n;
+        const T vi0 = dist_get<T, NT>(v, i - j - 1);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-              if (t == (r >> 6) && lane == (r & 63)) acc[t] += rs;
-          }
+        for (int t = 0; t < NT; ++t) {
+          const int c = j + 1 + lane + 64 * t;
+          acc[t] += (c < n ? ld_l2(r0 + c) : T(0)) * vi0;
         }
       }
 #pragma unroll
@@ -214,29 +208,38 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       const T K = T(0.5) * tj * wave_sum_dpp(wv);
 #pragma unroll
       for (int t = 0; t < NT; ++t) q[t] = w[t] - K * v[t];
-      for (int i = j + 1 + wave; i < n; i += RPT * nw) {
+      int i = j + 1 + wave;
+      for (; i + (RPT - 1) * nw < n; i += RPT * nw) {
         T sr[RPT][NT], vi[RPT], qi[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-          const int iu = i + u * nw;
-          const T* ru = S + (long)(iu < n ? iu : j + 1) * n;
-          vi[u] = iu < n ? dist_get<T, NT>(v, iu - j - 1) : T(0);
-          qi[u] = iu < n ? dist_get<T, NT>(q, iu - j - 1) : T(0);
+          const T* ru = S + (long)(i + u * nw) * n;
+          vi[u] = dist_get<T, NT>(v, i + u * nw - j - 1);
+          qi[u] = dist_get<T, NT>(q, i + u * nw - j - 1);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const int c = j + 1 + lane + 64 * t;
-            sr[u][t] = (iu < n && c < n && c >= iu) ? ld_l2(ru + c) : T(0);
+            sr[u][t] = c < n ? ld_l2(ru + c) : T(0);
           }
         }
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-          const int iu = i + u * nw;
-          T* ru = S + (long)(iu < n ? iu : j + 1) * n;
+          T* ru = S + (long)(i + u * nw) * n;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const int c = j + 1 + lane + 64 * t;
-            if (iu < n && c < n && c >= iu) ru[c] = sr[u][t] - (vi[u] * q[t] + qi[u] * v[t]);
+            if (c < n) ru[c] = sr[u][t] - (vi[u] * q[t] + qi[u] * v[t]);
           }
+        }
+      }
+      for (; i < n; i += nw) {
+        T* r0 = S + (long)i * n;
+        const int ra = i - j - 1;
+        const T vi0 = dist_get<T, NT>(v, ra), qi0 = dist_get<T, NT>(q, ra);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = j + 1 + lane + 64 * t;
+          if (c < n) r0[c] = ld_l2(r0 + c) - (vi0 * q[t] + qi0 * v[t]);
         }
       }
     }

@@ -39,7 +39,7 @@ _PRELAUNCH = _os.environ.get("XITORCH_AMD_PRELAUNCH", "1") != "0"     # A/B: enq
 # largest basis the global-memory Rayleigh-Ritz kernel (K3g) serves before the library takes over: one workgroup (one
 # CU's L2 bandwidth) per matrix, so its time does not depend on the batch, while the library spreads a matrix over the
 # chip.  (>= 16 matrices per group, fewer) — measured cross-over, xk_eigh_big.hip
-K3G_MAX_K = [448, 352]
+K3G_MAX_K = [640, 448]
 
 
 def take_eigpairs(evals, evecs, neig, mode):
@@ -441,8 +441,9 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         (extension) ``"native"`` (default): the wanted eigenpairs of the Rayleigh–Ritz matrix come from native
         kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
         iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
-        flags a result; from 129 to 448 vectors (352 for fewer than 16 batch members per group) the same route with
-        the matrix in global memory (K3g: up to 2x faster than the library there, measured; fallback: the library);
+        flags a result; from 129 to 640 vectors (448 for fewer than 16 batch members per group) the same route with
+        the matrix in global memory (K3g: 2x faster than the library at order 192-256, level with it around 500,
+        measured; fallback: the library);
         ``torch.linalg.eigh`` beyond that and for more than 16 wanted pairs; ``"jacobi"`` / ``"tri"`` force one of
         the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
