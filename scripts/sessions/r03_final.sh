@@ -26,7 +26,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof8 -- python bench
 F=$(find $O/prof8 -name "*kernel_stats.csv" | head -1)
 [ -n "$F" ] && python scripts/summarize_rocprof.py $F $O/r03_b8_kernel_stats_summary.csv 30
 rm -rf $O/prof8
-timeout 900 python scripts/bench_configs.py c3 c3g c4 c5 c5w c2:S2:96 c2:S2:0 2>$O/configs.err > $O/r03_secondary_configs.jsonl
+timeout 900 python scripts/bench_configs.py c3 c3g c4 c5 c5w 2>$O/configs.err > $O/r03_secondary_configs.jsonl
+# (the hard-spectrum runs each in a process of their own: 137 GB of operators + growing work buffers)
+timeout 300 python scripts/bench_configs.py c2:S2:96 2>>$O/configs.err >> $O/r03_secondary_configs.jsonl
+timeout 300 python scripts/bench_configs.py c2:S2:0 2>>$O/configs.err >> $O/r03_secondary_configs.jsonl
 cut -c1-400 $O/r03_secondary_configs.jsonl
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-general-extra 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('torchrun n=1', round(d['ms_per_step'],2), d['n_gpus'], d['config'].get('comm_backend'))"
 XITORCH_BENCH_FORCE_PG=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-general-extra 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('force_pg', round(d['ms_per_step'],2), d['config'].get('comm_backend'), d['config'].get('comm_world_size'))"
