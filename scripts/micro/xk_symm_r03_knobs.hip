@@ -56,7 +56,8 @@ constexpr int SYMM_R = 8;        // rows per chunk == ring depth
 #ifndef XK_SYMM_REFILL
 #define XK_SYMM_REFILL 0
 #endif
-// measurement only (-DXK_SYMM_NOBAR): drop the phase barriers — the accumulation order is then no longer fixed;
+// measurement only: -DXK_SYMM_NOROW / -DXK_SYMM_NOCOL drop the row / column part of the arithmetic (wrong results:
+// what is left is the kernel's memory skeleton); -DXK_SYMM_NOBAR: drop the phase barriers — the accumulation order is then no longer fixed;
 // tells what the barriers cost
 #ifdef XK_SYMM_NOBAR
 #define XK_SYMM_PHASE_BARRIER() ((void)0)
@@ -177,8 +178,14 @@ __device__ __forceinline__ void symm_chunk8(
           for (int c = 0; c < P; ++c)
 #pragma unroll
             for (int v = 0; v < VN; ++v) {
+#ifndef XK_SYMM_NOCOL
               acc_col[u][c][v] += ac[v] * xi[c][q];
+#else
+              if (c == 0) acc_col[u][0][v] += ac[v];          /* measurement: keep the load alive, no column part */
+#endif
+#ifndef XK_SYMM_NOROW
               s[q][c] += ar[v] * xJ[u][c][v];
+#endif
             }
 #if XK_SYMM_REFILL == 2
           // the products of this vector are issued: pin them above the re-issue of its ring slot
@@ -257,7 +264,11 @@ __device__ __forceinline__ void symm_chunk8(
       L4[w] += lane_partner<2>(L4[w]);
       L4[w] += lane_partner<1>(L4[w]);
     }
+#ifdef XK_SYMM_NORED
+    if (lane == 77 && rowok) {                         /* measurement: the reduction tree keeps one (never taken) consumer */
+#else
     if ((lane & 3) == 0 && rowok) {
+#endif
 #pragma unroll
       for (int w = 0; w < P / 2; ++w)
         __hip_atomic_fetch_add(&rowacc[lrow * P + 2 * w + (hi ? 1 : 0)], L4[w], __ATOMIC_RELAXED,
