@@ -53,6 +53,12 @@ constexpr int SYMM_R = 8;        // rows per chunk == ring depth
 // build knob (A/B, scripts/k1s_build_ab.sh): when a consumed ring slot is re-issued — 0: per row pair (round 2),
 // 1: per row, 2: per 16 B vector.  A slot is idle from the arrival of its data until its re-issue; the finer the
 // re-issue, the shorter that is (the wave spends ~100 cycles of FMAs per vector, ~400 per row pair).
+// measurement: -DXK_SYMM_NOSUPP fetches the strictly-lower lanes of the diagonal blocks too (they are masked anyway)
+#ifdef XK_SYMM_NOSUPP
+#define XK_SUPP(c) true
+#else
+#define XK_SUPP(c) (c)
+#endif
 #ifndef XK_SYMM_REFILL
 #define XK_SYMM_REFILL 0
 #endif
@@ -191,7 +197,7 @@ __device__ __forceinline__ void symm_chunk8(
           // the products of this vector are issued: pin them above the re-issue of its ring slot
 #pragma unroll
           for (int c = 0; c < P; ++c) { asm volatile("" : "+v"(acc_col[u][c])); asm volatile("" : "+v"(s[q][c])); }
-          a[r][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
+          a[r][u] = ld_tile<VT>(Ab, XK_SUPP(!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
           __builtin_amdgcn_sched_barrier(0);
 #endif
         }
@@ -202,7 +208,7 @@ __device__ __forceinline__ void symm_chunk8(
           for (int c = 0; c < P; ++c) { asm volatile("" : "+v"(acc_col[u][c])); asm volatile("" : "+v"(s[q][c])); }
 #pragma unroll
         for (int u = 0; u < NU; ++u)
-          a[r][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
+          a[r][u] = ld_tile<VT>(Ab, XK_SUPP(!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
         __builtin_amdgcn_sched_barrier(0);
 #endif
       }
@@ -227,7 +233,7 @@ __device__ __forceinline__ void symm_chunk8(
         const int thr = nx.diag ? row - nx.col0 - (VN - 1) + col0 : -0x40000000;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
-          a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, (!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
+          a[4 * g + 2 * h + q][u] = ld_tile<VT>(Ab, XK_SUPP(!DIAG || jj[u] >= thr) ? nloff[u] : SYMM_OOR, soff);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);      // keep the row pairs in program order (bounded live ranges)
