@@ -290,6 +290,10 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  * factorised at a time (> 0) when the problem fits the 160 KiB of LDS, 0 when it does not.  p <= 16. */
 int xk_small_eigh_big_batch(int k, int p, int elem_size);
 long xk_small_eigh_big_workspace_elems(int B, int k);
+/* measurement hook (no reference counterpart): what 0 = workgroups per matrix of the tridiagonalisation's step kernels
+ * (0 automatic, -1 = the one-workgroup kernel does everything), what 1 = their threads per workgroup (256 / 512);
+ * returns the previous value.  Changes what xk_small_eigh_big_workspace_elems returns. */
+int xk_small_eigh_big_tune(int what, int value);
 int xk_small_eigh_big_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* info, int B, int k,
                           int p, int uppest, long ldt, long sT, void* stream);
 int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long ws_elems, int* info, int B, int k,

@@ -98,10 +98,11 @@ __device__ __forceinline__ unsigned big_hash(unsigned x) {
   return x;
 }
 
-template <typename T, int NT>
+template <typename T, int NT, bool PRE>
 __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
-    const T* __restrict__ Tin, T* __restrict__ Sws, T* __restrict__ lam_out, T* __restrict__ Y_out,
-    int* __restrict__ info_out, int n, int p, int pb, int uppest, long ldt, long sT) {
+    const T* __restrict__ Tin, T* __restrict__ Sws, const T* __restrict__ aux, long aux_stride,
+    T* __restrict__ lam_out, T* __restrict__ Y_out,
+    int* __restrict__ info_out, int n, int p, int pb, int uppest, long ldt, long sT, int stop_after) {
   // rows per trip of the matrix sweeps (loads in flight per wave = RPT x column slots).  Measured at order 512, 32
   // matrices: 24.0 ms with 2, 28.6 ms with 4 — the sweeps are bound by what ONE compute unit draws from L2 (three
   // passes over the trailing block per step: 6.3 MB at order 512 = 47 us at ~130 GB/s), not by the loads in flight
@@ -124,6 +125,18 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   T* S = Sws + (long)b * n * n;
   const T eps = BigEps<T>::eps;
 
+  if (PRE) {
+    // the tridiagonalisation was done by the step kernels (tridiag_step_kernel): (d, e, tau) wait in the aux block,
+    // the reflectors are parked in the rows of S exactly as phase 1 below would have left them
+    const T* ab = aux + (long)b * aux_stride;
+    for (int i = tid; i < n; i += nt) {
+      T d = ab[i], e = ab[n + i], tv = ab[2 * n + i];
+      if (i == n - 1) { d = S[(long)(n - 1) * n + (n - 1)]; e = T(0); tv = T(0); }
+      if (i == n - 2) { e = ab[3 * n + (long)((n - 2) & 1) * n + (n - 1)]; tv = T(0); }
+      dd[i] = d; ee[i] = e; tau[i] = tv; e2[i] = e * e;
+    }
+    __syncthreads();
+  } else {
   // ---- 0. work copy: lower triangle mirrored ----------------------------------------------------------
   for (int idx = tid; idx < n * n; idx += nt) {
     const int i = idx / n, j = idx - i * n;
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   __syncthreads();
   for (int i = tid; i < n; i += nt) e2[i] = ee[i] * ee[i];
   __syncthreads();
+  }
 
   // ---- 2. bisection: wave w -> wanted eigenvalue number w (ascending) ---------------------------------
   T gl = T(INFINITY), gu = T(-INFINITY), emax = T(0);
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   }
   if (tid == 0) red[15] = T(0);                       // "an iterate was annihilated / non-finite" flag of step 3
   __syncthreads();
+  if (stop_after == 2) return;                        // (measurement hook: results are wrong by construction)
 
   // ---- 3. inverse iteration (dstein), vectors in order, pb shifts factorised at a time -----------------
   const T pfloor = eps * tnorm + pivmin;
@@ -416,6 +431,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     }
   }
 #undef AT
+  if (stop_after == 3) return;
 
   // ---- 5. checks on the tridiagonal level ----------------------------------------------------------------
   if (wave == 0) {
@@ -453,6 +469,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   }
   __syncthreads();
 
+  if (stop_after == 5) return;
   // ---- 4. back-transformation y = H_0 ... H_{n-3} z, one wave per vector, next reflector prefetched -------
   for (int j = wave; j < p; j += nw) {
     const T* zj = Z + (long)j * n;
@@ -503,12 +520,311 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   }
 }
 
+
+// ---- K3m: the tridiagonalisation spread over W workgroups per matrix, ONE KERNEL PER HOUSEHOLDER STEP ----------
+// (the kernel boundary is the only cross-workgroup hand-off: no spinning, safe beside CU-masked streams).
+// Look-ahead form: launch j applies the rank-2 update of step j to the trailing block and, in the same pass over it,
+// accumulates the product of the UPDATED block with the reflector of step j + 1 — one read and one write of the
+// trailing block per step instead of two reads and a write.  Every workgroup recomputes the small pieces (reflector j
+// from row j, the sum of the partial products of the previous launch, row j + 1 and reflector j + 1) in the same
+// order, so all of them hold bit-identical values; rows j + 2 .. n - 1 are dealt round-robin over the W x nw waves.
+// Only the upper triangle of the trailing block is read and written: a row contributes the column form of the product
+// for c >= i and, through one wave reduction, its own element of the row form for c > i.
+// aux block per matrix: d[n], e[n], tau[n], X[2][n] (row j + 1 after update j, double-buffered: launch j reads X[j & 1]
+// and writes X[(j + 1) & 1]), R[2][n] (row-form sums), P[2][W][n] (column-form partials), same double buffering.
+// FIRST (j = -1): no update, the rows come from the lower triangle of T (eigh's UPLO = 'L') and are stored to S.
+
+// rows i0, i0 + GW, ... (RPT of them) of the trailing block, columns j2 + lane + 64 t >= the row, into registers
+template <typename T, int NT, int RPT, bool FIRST>
+__device__ __forceinline__ void step_load_rows(T (&sr)[RPT][NT], const T* __restrict__ S, const T* __restrict__ Tb,
+                                               long ldt, int n, int j2, int i0, int GW, int lane) {
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int i = i0 + u * GW;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = j2 + lane + 64 * t;
+      T val = T(0);
+      if (c >= i && c < n) {                          // (upper triangle of the trailing block only; i < n follows)
+        if (FIRST) val = Tb[(long)c * ldt + i];       // element (i, c) = (c, i) of eigh's lower triangle
+        else val = S[(long)i * n + c];
+      }
+      sr[u][t] = val;
+    }
+  }
+}
+
+template <typename T, int NT, bool FIRST>
+__global__ __launch_bounds__(512) void tridiag_step_kernel(
+    const T* __restrict__ Tin, T* __restrict__ Sws, T* __restrict__ aux, long aux_stride, int n, int j, int W,
+    long ldt, long sT) {
+  constexpr int RPT = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* wL = reinterpret_cast<T*>(smem);                 // n  A v_j (sum of the partial products of launch j - 1, unscaled)
+  T* vL = wL + n;                                     // n  reflector j by absolute column
+  T* red = vL + n;                                    // 8  scalars
+  T* partL = red + 8;                                 // nw x n
+  const int b = blockIdx.y, wg = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, nw = nt >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* Tb = Tin + (long)b * sT;
+  T* S = Sws + (long)b * n * n;
+  T* ab = aux + (long)b * aux_stride;
+  T* dd = ab; T* ee = ab + n; T* tau = ab + 2 * n;
+  const T* Xcur = ab + 3 * n + (long)(j & 1) * n;
+  T* Xnext = ab + 3 * n + (long)((j + 1) & 1) * n;
+  const T* Rcur = ab + 5 * n + (long)(j & 1) * n;
+  T* Rnext = ab + 5 * n + (long)((j + 1) & 1) * n;
+  const T* Pcur = ab + 7 * n + (long)(j & 1) * W * n;
+  T* Pnext = ab + 7 * n + (long)((j + 1) & 1) * W * n;
+  const int j1 = j + 1, j2 = j + 2;                   // row handled redundantly, first row / column of the next block
+
+  // every global load that does not depend on this launch's reflector is issued before anything else: row j + 1 and
+  // the first rows of this wave (one trip to the Infinity Cache is what a small step costs)
+  const int GW = W * nw;
+  int i0 = j2 + wg * nw + wave;
+  T s1[NT], sr[RPT][NT];
+  T sdiag = T(0);
+  if (!FIRST) {
+    sdiag = S[(long)j1 * n + j1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = j2 + lane + 64 * t;
+      s1[t] = c < n ? S[(long)j1 * n + c] : T(0);
+    }
+  }
+  step_load_rows<T, NT, RPT, FIRST>(sr, S, Tb, ldt, n, j2, i0, GW, lane);
+
+  T tj = T(0), K = T(0);
+  if (!FIRST) {
+    // ---- A. reflector j (wave 0) and the summed partial products (all threads) --------------------------------
+    for (int c = j1 + tid; c < n; c += nt) {
+      T sacc = Rcur[c];
+      for (int g = 0; g < W; ++g) sacc += Pcur[(long)g * n + c];
+      wL[c] = sacc;
+    }
+    if (wave == 0) {
+      T ss = T(0);
+      T x[NT + 1];
+#pragma unroll
+      for (int t = 0; t < NT + 1; ++t) {
+        const int c = j1 + lane + 64 * t;
+        x[t] = c < n ? Xcur[c] : T(0);
+        if (!(t == 0 && lane == 0)) ss += x[t] * x[t];
+      }
+      const T sigma = wave_sum_dpp(ss);
+      const T alpha = big_readlane(x[0], 0);
+      T tjw = T(0), scale = T(0), beta = alpha;
+      if (!(sigma == T(0))) {                         // (a NaN row must poison the result, not be skipped)
+        const T nrm = sqrt(alpha * alpha + sigma);
+        beta = alpha >= T(0) ? -nrm : nrm;
+        tjw = (beta - alpha) * big_rcp(beta);
+        scale = big_rcp(alpha - beta);
+      }
+#pragma unroll
+      for (int t = 0; t < NT + 1; ++t) {
+        const int c = j1 + lane + 64 * t;
+        const T vv = (t == 0 && lane == 0) ? T(1) : x[t] * scale;
+        if (c < n) {
+          vL[c] = vv;
+          if (wg == 0 && c > j1) S[(long)j * n + c] = vv;      // parked: nobody reads row j of S any more
+        }
+      }
+      if (lane == 0) {
+        red[0] = tjw;
+        if (wg == 0) { tau[j] = tjw; ee[j] = beta; }
+      }
+    }
+    __syncthreads();
+    tj = red[0];
+    T wv = T(0);
+    for (int c = j1 + lane; c < n; c += 64) wv += wL[c] * vL[c];
+    K = T(0.5) * tj * tj * wave_sum_dpp(wv);          // w = tj A v;  K = tj/2 w.v
+  }
+
+  // ---- B. row j + 1 after update j, reflector j + 1 (every wave, identical) -------------------------------------
+  T q2[NT], v2[NT], vN[NT];
+  T q0 = T(0);
+  {
+    T a[NT];
+    T dnext;
+    if (FIRST) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = j2 + lane + 64 * t;
+        a[t] = c < n ? Tb[(long)c * ldt] : T(0);
+        q2[t] = T(0); v2[t] = T(0);
+      }
+      dnext = Tb[0];
+    } else {
+      q0 = tj * wL[j1] - K;                           // v_j(j + 1) = 1
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = j2 + lane + 64 * t;
+        const T vv = c < n ? vL[c] : T(0);
+        const T ww = c < n ? wL[c] : T(0);
+        v2[t] = vv;
+        q2[t] = tj * ww - K * vv;
+        a[t] = s1[t] - (q2[t] + q0 * vv);
+      }
+      dnext = sdiag - T(2) * q0;
+    }
+    T ss = T(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (!(t == 0 && lane == 0)) ss += a[t] * a[t];
+    const T sigma = wave_sum_dpp(ss);
+    const T alpha = big_readlane(a[0], 0);
+    T scale = T(0);
+    if (!(sigma == T(0))) {
+      const T nrm = sqrt(alpha * alpha + sigma);
+      const T beta = alpha >= T(0) ? -nrm : nrm;
+      scale = big_rcp(alpha - beta);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) vN[t] = (t == 0 && lane == 0) ? T(1) : a[t] * scale;
+    if (wg == 0 && wave == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = j2 + lane + 64 * t;
+        if (c < n) Xnext[c] = a[t];
+      }
+      if (lane == 0) dd[j1] = dnext;
+    }
+  }
+
+  // ---- C. rows j + 2 .. n - 1: update, store, accumulate the product with reflector j + 1 ------------------------
+  T acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = T(0);
+  for (; i0 < n; i0 += RPT * GW) {
+    T nx[RPT][NT];
+    step_load_rows<T, NT, RPT, FIRST>(nx, S, Tb, ldt, n, j2, i0 + RPT * GW, GW, lane);     // next trip, before the stores
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int i = i0 + u * GW;
+      if (i < n) {
+        const T vNi = dist_get<T, NT>(vN, i - j2);
+        T vi = T(0), qi = T(0);
+        if (!FIRST) { vi = vL[i]; qi = tj * wL[i] - K * vi; }
+        const int tmin = (i - j2) >> 6;               // first column slot that reaches the diagonal (wave-uniform)
+        T rs = T(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t >= tmin) {
+            const int c = j2 + lane + 64 * t;
+            const bool on = c >= i && c < n;
+            T an = FIRST ? sr[u][t] : sr[u][t] - (vi * q2[t] + qi * v2[t]);
+            an = on ? an : T(0);
+            if (on) S[(long)i * n + c] = an;
+            acc[t] += an * vNi;                       // column form: (A v)(c) += a(i, c) v(i), c >= i
+            rs += c > i ? an * vN[t] : T(0);          // row form:    (A v)(i) += a(i, c) v(c), c > i
+          }
+        }
+        rs = wave_sum_dpp(rs);
+        if (lane == 0) Rnext[i] = rs;                 // row i belongs to exactly one wave of the grid: complete
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) sr[u][t] = nx[u][t];
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = j2 + lane + 64 * t;
+    if (c < n) partL[wave * n + c] = acc[t];
+  }
+  __syncthreads();
+  for (int c = j2 + tid; c < n; c += nt) {
+    T sacc = T(0);
+    for (int ww_ = 0; ww_ < nw; ++ww_) sacc += partL[ww_ * n + c];
+    Pnext[(long)wg * n + c] = sacc;
+  }
+}
+
+static long step_lds_elems(long n, long nw) { return 2 * n + 8 + nw * n; }
+
 // LDS elements for order n, p wanted pairs, LU batches of pb shifts, nw waves
 static long big_lds_elems(long n, long p, long pb, long nw) {
   const long scratch = 5L * n * pb > nw * n ? 5L * n * pb : nw * n;
   return 4 * n + 16 + BIG_MAXP + p * n + scratch;
 }
 
+}  // namespace xk
+
+extern "C" int xk_small_eigh_big_batch(int k, int p, int elem_size);
+
+// measurement hooks: workgroups per matrix of the step kernels (0 = automatic, -1 = the one-workgroup kernel for
+// everything), threads per workgroup of the step kernels, "stop after phase" of the final kernel
+static int g_big_w = 0;
+static int g_big_threads = 512;
+static int g_big_stop = 0;
+
+namespace xk {
+static int big_pick_w(int B, int k) {
+  if (g_big_w < 0 || k < 8) return 0;
+  if (g_big_w > 0) return g_big_w;
+  int w = 1;                                              // measured (scripts/k3m_sweep.py): one workgroup per CU across
+  while (w < 8 && (long)B * (w * 2) <= 256) w *= 2;       // the batch, at most 8 per matrix (4 up to order 256)
+  if (k <= 256 && w > 4) w = 4;
+  return w;
+}
+
+template <typename T, int NT>
+static void big_launch_step(const T* Tin, T* S, T* aux, long aux_stride, int B, int k, int j, int W, long ldt, long sT,
+                            hipStream_t st) {
+  const int nt = g_big_threads;
+  const size_t lds = (size_t)step_lds_elems(k, nt / 64) * sizeof(T);
+  if (j < 0)
+    hipLaunchKernelGGL((tridiag_step_kernel<T, NT, true>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k, j,
+                       W, ldt, sT);
+  else
+    hipLaunchKernelGGL((tridiag_step_kernel<T, NT, false>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k,
+                       j, W, ldt, sT);
+}
+
+template <typename T, int NT, bool PRE>
+static int big_launch_final(const T* Tin, T* ws, const T* aux, long aux_stride, T* lam, T* Y, int* info, int B, int k,
+                            int p, int pb, int uppest, long ldt, long sT, long lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute((const void*)tridiag_eigh_big_kernel<T, NT, PRE>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((tridiag_eigh_big_kernel<T, NT, PRE>), dim3(B), dim3(512), (size_t)lds, st, Tin, ws, aux,
+                     aux_stride, lam, Y, info, k, p, pb, uppest, ldt, sT, g_big_stop);
+  return XK_OK;
+}
+
+template <typename T>
+static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k, int p, int uppest,
+                   long ldt, long sT, hipStream_t st) {
+  const int pb = xk_small_eigh_big_batch(k, p, (int)sizeof(T));
+  if (pb == 0) return XK_ERR_UNSUPPORTED;
+  const long lds = big_lds_elems(k, p, pb, 8) * (long)sizeof(T) + 64;
+  const int W = big_pick_w(B, k);
+  const long aux_stride = W > 0 ? (long)k * (7 + 2 * W) : 0;
+  if (ws == nullptr || ws_elems < (long)B * k * k + (long)B * aux_stride) return XK_ERR_ARG;
+  T* aux = ws + (long)B * k * k;
+  int rc;
+  if (W > 0) {
+    for (int j = -1; j <= k - 3; ++j) {
+      const int m2 = k - (j + 2);
+      if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+      else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+      else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+      else big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+    }
+    rc = k <= 512 ? big_launch_final<T, 8, true>(Tin, ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st)
+                  : big_launch_final<T, 12, true>(Tin, ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st);
+  } else {
+    rc = k <= 512 ? big_launch_final<T, 8, false>(Tin, ws, nullptr, 0L, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st)
+                  : big_launch_final<T, 12, false>(Tin, ws, nullptr, 0L, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st);
+  }
+  if (rc != XK_OK) return rc;
+  XK_LAUNCH_CHECK();
+  return XK_OK;
+}
 }  // namespace xk
 
 extern "C" {
@@ -522,33 +838,28 @@ int xk_small_eigh_big_batch(int k, int p, int elem_size) {
   return 0;
 }
 
-long xk_small_eigh_big_workspace_elems(int B, int k) { return (long)B * k * k; }
+long xk_small_eigh_big_workspace_elems(int B, int k) {
+  const int W = xk::big_pick_w(B, k);
+  return (long)B * k * k + (W > 0 ? (long)B * k * (7 + 2 * W) : 0L);
+}
+
+/* measurement hook: what 0 = workgroups per matrix of the step kernels (0 automatic, -1 one-workgroup kernel only),
+ * what 1 = threads per workgroup of the step kernels (256 / 512), what 2 = leave the final kernel after phase 2 / 3 / 5
+ * (wrong results by construction).  Returns the previous value. */
+int xk_small_eigh_big_tune(int what, int value) {
+  int old = -1000;
+  if (what == 0) { old = g_big_w; if (value >= -1 && value <= 32) g_big_w = value; }
+  if (what == 1) { old = g_big_threads; if (value == 256 || value == 512) g_big_threads = value; }
+  if (what == 2) { old = g_big_stop; g_big_stop = value; }
+  return old;
+}
 
 #define XK_DEFINE_EIGH_BIG(SUF, T)                                                                            \
   int xk_small_eigh_big_##SUF(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k,      \
                               int p, int uppest, long ldt, long sT, void* stream) {                           \
     if (B < 0 || k < 2 || k > 768 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                   \
     if (B == 0) return XK_OK;                                                                                 \
-    if (ws == nullptr || ws_elems < (long)B * k * k) return XK_ERR_ARG;                                       \
-    const int pb = xk_small_eigh_big_batch(k, p, (int)sizeof(T));                                             \
-    if (pb == 0) return XK_ERR_UNSUPPORTED;                                                                   \
-    const long lds = xk::big_lds_elems(k, p, pb, 8) * (long)sizeof(T) + 64;                                  \
-    hipError_t e;                                                                                             \
-    if (k <= 512) {                                                                                           \
-      e = hipFuncSetAttribute((const void*)xk::tridiag_eigh_big_kernel<T, 8>,                                 \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-      if (e != hipSuccess) return (int)e;                                                                     \
-      hipLaunchKernelGGL((xk::tridiag_eigh_big_kernel<T, 8>), dim3(B), dim3(512), (size_t)lds,               \
-                         (hipStream_t)stream, Tin, ws, lam, Y, info, k, p, pb, uppest, ldt, sT);              \
-    } else {                                                                                                  \
-      e = hipFuncSetAttribute((const void*)xk::tridiag_eigh_big_kernel<T, 12>,                                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-      if (e != hipSuccess) return (int)e;                                                                     \
-      hipLaunchKernelGGL((xk::tridiag_eigh_big_kernel<T, 12>), dim3(B), dim3(512), (size_t)lds,              \
-                         (hipStream_t)stream, Tin, ws, lam, Y, info, k, p, pb, uppest, ldt, sT);              \
-    }                                                                                                         \
-    XK_LAUNCH_CHECK();                                                                                        \
-    return XK_OK;                                                                                             \
+    return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, (hipStream_t)stream);    \
   }
 
 XK_DEFINE_EIGH_BIG(f64, double)

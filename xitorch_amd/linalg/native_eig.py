@@ -39,7 +39,7 @@ _PRELAUNCH = _os.environ.get("XITORCH_AMD_PRELAUNCH", "1") != "0"     # A/B: enq
 # largest basis the global-memory Rayleigh-Ritz kernel (K3g) serves before the library takes over: one workgroup (one
 # CU's L2 bandwidth) per matrix, so its time does not depend on the batch, while the library spreads a matrix over the
 # chip.  (>= 16 matrices per group, fewer) — measured cross-over, xk_eigh_big.hip
-K3G_MAX_K = [640, 448]
+K3G_MAX_K = [768, 768]
 
 
 def take_eigpairs(evals, evecs, neig, mode):
