@@ -129,19 +129,24 @@ def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000):
     syn.dense_symmetric(B, N, spectrum, device=dev, out=mat)
     A = xa.LinearOperator.m(mat, is_hermitian=True)
     exact = syn.spectrum(spectrum, N, device=dev)[:p]
-    ev = []
-    tr = {"k1_events": ev}
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    with torch.no_grad(), warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        evals, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, rng_device="device",
-                          max_niter=max_niter, restart=restart, trace=tr)
-    torch.cuda.synchronize(); t = time.perf_counter() - t0
+    first_ms = None
+    for rep in range(2):                                  # the first call of a process also pays for ~20 GB of fresh
+        ev = []                                           # hipMallocs (basis / workspace growth): reported separately
+        tr = {"k1_events": ev}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            evals, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, rng_device="device",
+                              max_niter=max_niter, restart=restart, trace=tr)
+        torch.cuda.synchronize(); t = time.perf_counter() - t0
+        if first_ms is None:
+            first_ms = t * 1e3
     k1 = sum(a.elapsed_time(b) for (a, b, pc, nb) in ev) * 1e-3
     nbl = ev[0][3]
     per = sum(a.elapsed_time(b) for (a, b, pc, nb) in ev if pc == p) / max(1, len([1 for e in ev if e[2] == p]))
     tri_bytes = nbl * N * (N + 1) // 2 * 8 + 2 * nbl * N * p * 8
     return {"config": "c2 symeig davidson, spectrum %s, restart=%s (64 x 16384^2 fp64)" % (spectrum, restart), "ms": t * 1e3,
+            "first_call_of_the_process_ms": first_ms,
             "niter": tr["niter"], "restarts": tr.get("restarts"), "basis_size": tr["basis_size"], "stop": tr["stop_reason"],
             "best_resid": tr["best_resid"], "max_eval_err_vs_closed_form": (evals - exact).abs().max().item(),
             "eigpairs_per_s": B * p / t, "panel_product_share_of_call": k1 / t, "k1_ms_per_launch": per,

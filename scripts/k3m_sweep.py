@@ -17,7 +17,7 @@ def t_of(f, n=3):
     return sorted(ts)[n // 2] * 1e3
 
 
-for dtype in (torch.float64,) if quick else (torch.float64, torch.float32):
+for dtype in (torch.float64, torch.float32) if quick else (torch.float64, torch.float32):
     for B in (32, 4):
         for k in ((192, 384, 582) if quick else (130, 192, 256, 384, 512, 582, 640, 768)):
             g = torch.Generator().manual_seed(k)

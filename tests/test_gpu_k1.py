@@ -2,7 +2,7 @@
 import pytest
 import torch
 from oracle import ops as oops
-from xitorch_amd import kernels as K
+from xitorch_amd import kernels as K, _capi
 from xitorch_amd import LinearOperator
 
 pytestmark = pytest.mark.gpu
@@ -388,16 +388,28 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
         lam_ref = torch.linalg.eigvalsh(Tm)
         buf = torch.full((B, cap, cap), float("nan"), dtype=dtype)
         buf[:, :k, :k] = torch.tril(Tm).to(dtype) + torch.triu(torch.full((k, k), float("nan"), dtype=dtype), 1)
-        lam, Y, info = K.small_eigh_big(buf.to(dev), k, p, uppest=uppest)
-        assert int(info.max()) == 0
-        lam, Y = lam.cpu().double(), Y.cpu().double()
-        sl = slice(k - p, k) if uppest else slice(0, p)
-        tol = 1e-12 if dtype == torch.float64 else 3e-5
-        scale = lam_ref.abs().max().item()
-        assert (lam - lam_ref[:, sl]).abs().max().item() < tol * scale * 10, kind
-        assert torch.all(lam[:, 1:] >= lam[:, :-1])
-        Yc = Y.transpose(-2, -1)
-        res = torch.matmul(Tm, Yc) - Yc * lam.unsqueeze(-2)
-        assert res.abs().max().item() < tol * scale * 100, kind
-        G = torch.matmul(Yc.transpose(-2, -1), Yc)
-        assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, kind
+        # the tridiagonalisation spread over W workgroups per matrix, one launch per Householder step (K3m: automatic W,
+        # an odd W, 8 with 256-thread workgroups) and the one-workgroup kernel (W = -1): same answers, each reproducible
+        tune = _capi.fn("xk_small_eigh_big_tune")
+        try:
+            for W, threads in ((0, 512), (3, 512), (8, 256), (-1, 512)):
+                tune(0, W); tune(1, threads)
+                tag = (kind, W, threads)
+                dbuf = buf.to(dev)
+                lam, Y, info = K.small_eigh_big(dbuf, k, p, uppest=uppest)
+                lam2, Y2, _ = K.small_eigh_big(dbuf, k, p, uppest=uppest)
+                assert torch.equal(lam, lam2) and torch.equal(Y, Y2), tag
+                assert int(info.max()) == 0, tag
+                lam, Y = lam.cpu().double(), Y.cpu().double()
+                sl = slice(k - p, k) if uppest else slice(0, p)
+                tol = 1e-12 if dtype == torch.float64 else 3e-5
+                scale = lam_ref.abs().max().item()
+                assert (lam - lam_ref[:, sl]).abs().max().item() < tol * scale * 10, tag
+                assert torch.all(lam[:, 1:] >= lam[:, :-1])
+                Yc = Y.transpose(-2, -1)
+                res = torch.matmul(Tm, Yc) - Yc * lam.unsqueeze(-2)
+                assert res.abs().max().item() < tol * scale * 100, tag
+                G = torch.matmul(Yc.transpose(-2, -1), Yc)
+                assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
+        finally:
+            tune(0, 0); tune(1, 512)

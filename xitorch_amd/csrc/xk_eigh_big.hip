@@ -316,8 +316,12 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   if (stop_after == 2) return;                        // (measurement hook: results are wrong by construction)
 
   // ---- 3. inverse iteration (dstein), vectors in order, pb shifts factorised at a time -----------------
+  // One thread per shift runs the sequential recurrences; what they cost is LDS round trips, so (a) the LU streams:
+  // row i of the factorisation lives in registers and only the never-modified (d, e) are read, (b) the two solve
+  // sweeps fetch 8 steps' operands before their dependent chain, (c) scaling / orthogonalisation are wave-parallel.
   const T pfloor = eps * tnorm + pivmin;
 #define AT(arr, i) (arr)[(long)(i) * pb]
+  constexpr int SU = 8;
   for (int j0 = 0; j0 < p; j0 += pb) {
     const int nb = p - j0 < pb ? p - j0 : pb;
     if (tid < nb) {
@@ -326,47 +330,33 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       for (int q = j - 1; q >= 0; --q) {
         if (lamv[j] - lamv[q] < T(10) * eps * tnorm) shift += T(10) * eps * tnorm; else break;
       }
-      T* dl = lu + ((long)0 * n) * pb + jl;
-      T* dg = lu + ((long)1 * n) * pb + jl;
+      T* dl = lu + ((long)0 * n) * pb + jl;           // multipliers
+      T* dg = lu + ((long)1 * n) * pb + jl;           // RECIPROCAL pivots
       T* du = lu + ((long)2 * n) * pb + jl;
       T* du2 = lu + ((long)3 * n) * pb + jl;
-      T* sw = lu + ((long)4 * n) * pb + jl;
-      for (int i = 0; i < n; ++i) {
-        AT(dg, i) = dd[i] - shift;
-        AT(dl, i) = (i < n - 1) ? ee[i] : T(0);
-        AT(du, i) = (i < n - 1) ? ee[i] : T(0);
-        AT(du2, i) = T(0);
-        AT(sw, i) = T(0);
-      }
-      for (int i = 0; i + 1 < n; ++i) {               // LU with partial pivoting (dgttrf)
-        T di = AT(dg, i);
-        const T li = AT(dl, i);
-        if (fabs(di) >= fabs(li)) {
-          if (fabs(di) < pfloor) { di = di < T(0) ? -pfloor : pfloor; AT(dg, i) = di; }
-          const T fact = li * big_rcp(di);
-          AT(dl, i) = fact;
-          AT(dg, i + 1) -= fact * AT(du, i);
+      T* sw = lu + ((long)4 * n) * pb + jl;           // 1 = rows i, i + 1 were swapped
+      T dcur = dd[0] - shift, ucur = n > 1 ? ee[0] : T(0);
+      for (int i = 0; i + 1 < n; ++i) {               // LU with partial pivoting (dgttrf), row i in (dcur, ucur)
+        const T li = ee[i];
+        const T dn = dd[i + 1] - shift;
+        const T un = (i + 2 < n) ? ee[i + 1] : T(0);
+        if (fabs(dcur) >= fabs(li)) {
+          if (fabs(dcur) < pfloor) dcur = dcur < T(0) ? -pfloor : pfloor;
+          const T inv = big_rcp(dcur);
+          const T fact = li * inv;
+          AT(dl, i) = fact; AT(dg, i) = inv; AT(du, i) = ucur; AT(du2, i) = T(0); AT(sw, i) = T(0);
+          dcur = dn - fact * ucur;
+          ucur = un;
         } else {
-          const T fact = di * big_rcp(li);
-          AT(dg, i) = li;
-          AT(dl, i) = fact;
-          const T tmp = AT(du, i);
-          const T dn = AT(dg, i + 1);
-          AT(du, i) = dn;
-          AT(dg, i + 1) = tmp - fact * dn;
-          if (i + 2 < n) {
-            const T un = AT(du, i + 1);
-            AT(du2, i) = un;
-            AT(du, i + 1) = -fact * un;
-          }
-          AT(sw, i) = T(1);
+          const T inv = big_rcp(li);
+          const T fact = dcur * inv;
+          AT(dl, i) = fact; AT(dg, i) = inv; AT(du, i) = dn; AT(du2, i) = un; AT(sw, i) = T(1);
+          dcur = ucur - fact * dn;
+          ucur = -fact * un;
         }
       }
-      {
-        T dl_ = AT(dg, n - 1);
-        if (fabs(dl_) < pfloor) AT(dg, n - 1) = dl_ < T(0) ? -pfloor : pfloor;
-      }
-      for (int i = 0; i < n; ++i) AT(dg, i) = big_rcp(AT(dg, i));
+      if (fabs(dcur) < pfloor) dcur = dcur < T(0) ? -pfloor : pfloor;
+      AT(dg, n - 1) = big_rcp(dcur);
       T* z = Z + (long)j * n;
       for (int i = 0; i < n; ++i) {
         const unsigned h = big_hash((unsigned)(i * 131 + j * 7919 + 12345));
@@ -377,41 +367,70 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     for (int it = 0; it < 3; ++it) {
       if (tid < nb) {
         const int jl = tid, j = j0 + tid;
-        T* dl = lu + ((long)0 * n) * pb + jl;
-        T* dg = lu + ((long)1 * n) * pb + jl;
-        T* du = lu + ((long)2 * n) * pb + jl;
-        T* du2 = lu + ((long)3 * n) * pb + jl;
-        T* sw = lu + ((long)4 * n) * pb + jl;
+        const T* dl = lu + ((long)0 * n) * pb + jl;
+        const T* dg = lu + ((long)1 * n) * pb + jl;
+        const T* du = lu + ((long)2 * n) * pb + jl;
+        const T* du2 = lu + ((long)3 * n) * pb + jl;
+        const T* sw = lu + ((long)4 * n) * pb + jl;
         T* z = Z + (long)j * n;
         T cur = z[0];
-        for (int i = 0; i + 1 < n; ++i) {
+        int i = 0;
+        for (; i + SU <= n - 1; i += SU) {            // forward: L^-1 with the row interchanges
+          T nx[SU], l[SU], s_[SU], out[SU];
+#pragma unroll
+          for (int u = 0; u < SU; ++u) { nx[u] = z[i + 1 + u]; l[u] = AT(dl, i + u); s_[u] = AT(sw, i + u); }
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            if (s_[u] == T(0)) { out[u] = cur; cur = nx[u] - l[u] * cur; }
+            else { out[u] = nx[u]; cur = cur - l[u] * nx[u]; }
+          }
+#pragma unroll
+          for (int u = 0; u < SU; ++u) z[i + u] = out[u];
+        }
+        for (; i + 1 < n; ++i) {
           const T nxt = z[i + 1];
           const T l = AT(dl, i);
           if (AT(sw, i) == T(0)) { z[i] = cur; cur = nxt - l * cur; }
           else { z[i] = nxt; cur = cur - l * nxt; }
         }
-        T zp1 = cur * AT(dg, n - 1), zp2 = T(0);
+        T zp1 = cur * AT(dg, n - 1), zp2 = T(0);      // backward: U^-1 (two super-diagonals)
         z[n - 1] = zp1;
         if (n > 1) {
           const T t = (z[n - 2] - AT(du, n - 2) * zp1) * AT(dg, n - 2);
           z[n - 2] = t;
           zp2 = zp1; zp1 = t;
         }
-        for (int i = n - 3; i >= 0; --i) {
+        i = n - 3;
+        for (; i - (SU - 1) >= 0; i -= SU) {
+          T zz[SU], a_[SU], b_[SU], g_[SU];
+#pragma unroll
+          for (int u = 0; u < SU; ++u) { zz[u] = z[i - u]; a_[u] = AT(du, i - u); b_[u] = AT(du2, i - u); g_[u] = AT(dg, i - u); }
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const T t = (zz[u] - a_[u] * zp1 - b_[u] * zp2) * g_[u];
+            zz[u] = t;
+            zp2 = zp1; zp1 = t;
+          }
+#pragma unroll
+          for (int u = 0; u < SU; ++u) z[i - u] = zz[u];
+        }
+        for (; i >= 0; --i) {
           const T t = (z[i] - AT(du, i) * zp1 - AT(du2, i) * zp2) * AT(dg, i);
           z[i] = t;
           zp2 = zp1; zp1 = t;
         }
-        T mx = T(0);
-        for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(z[i]));
-        const T inv = mx > T(0) ? T(1) / mx : T(1);
-        for (int i = 0; i < n; ++i) z[i] *= inv;
       }
       __syncthreads();
-      // modified Gram–Schmidt against ALL earlier vectors (finished batches and this batch) + normalisation
+      // scaling by the largest entry, modified Gram–Schmidt against ALL earlier vectors (finished batches and this
+      // batch) and normalisation: wave 0, vectors in order
       if (wave == 0) {
         for (int j = j0; j < j0 + nb; ++j) {
           T* zj = Z + (long)j * n;
+          T mx = T(0);
+          for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(zj[i]));
+          mx = wave_max(mx);
+          const T sc = (mx > T(0) && mx < T(INFINITY)) ? T(1) / mx : T(1);
+          for (int i = lane; i < n; i += 64) zj[i] *= sc;
           for (int q = j - 1; q >= 0; --q) {
             const T* zq = Z + (long)q * n;
             T dp = T(0);
@@ -557,7 +576,7 @@ __device__ __forceinline__ void step_load_rows(T (&sr)[RPT][NT], const T* __rest
 template <typename T, int NT, bool FIRST>
 __global__ __launch_bounds__(512) void tridiag_step_kernel(
     const T* __restrict__ Tin, T* __restrict__ Sws, T* __restrict__ aux, long aux_stride, int n, int j, int W,
-    long ldt, long sT) {
+    long ldt, long sT, int skip) {
   constexpr int RPT = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* wL = reinterpret_cast<T*>(smem);                 // n  A v_j (sum of the partial products of launch j - 1, unscaled)
@@ -584,6 +603,7 @@ __global__ __launch_bounds__(512) void tridiag_step_kernel(
   // the first rows of this wave (one trip to the Infinity Cache is what a small step costs)
   const int GW = W * nw;
   int i0 = j2 + wg * nw + wave;
+  if (skip & 1) i0 = n;                               // (measurement hook: no row sweep)
   T s1[NT], sr[RPT][NT];
   T sdiag = T(0);
   if (!FIRST) {
@@ -597,11 +617,17 @@ __global__ __launch_bounds__(512) void tridiag_step_kernel(
   step_load_rows<T, NT, RPT, FIRST>(sr, S, Tb, ldt, n, j2, i0, GW, lane);
 
   T tj = T(0), K = T(0);
-  if (!FIRST) {
+  if (!FIRST && !(skip & 2)) {
     // ---- A. reflector j (wave 0) and the summed partial products (all threads) --------------------------------
-    for (int c = j1 + tid; c < n; c += nt) {
-      T sacc = Rcur[c];
-      for (int g = 0; g < W; ++g) sacc += Pcur[(long)g * n + c];
+    for (int c = j1 + tid; c < n; c += nt) {          // (all W + 1 loads in flight at once: a dependent loop over g
+      T sacc = Rcur[c];                               //  costs W round trips to the Infinity Cache per step)
+      for (int g0 = 0; g0 < W; g0 += 8) {
+        T pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = g0 + u < W ? Pcur[(long)(g0 + u) * n + c] : T(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += pv[u];
+      }
       wL[c] = sacc;
     }
     if (wave == 0) {
@@ -736,6 +762,7 @@ __global__ __launch_bounds__(512) void tridiag_step_kernel(
     const int c = j2 + lane + 64 * t;
     if (c < n) partL[wave * n + c] = acc[t];
   }
+  if (skip & 4) return;
   __syncthreads();
   for (int c = j2 + tid; c < n; c += nt) {
     T sacc = T(0);
@@ -761,13 +788,17 @@ extern "C" int xk_small_eigh_big_batch(int k, int p, int elem_size);
 static int g_big_w = 0;
 static int g_big_threads = 512;
 static int g_big_stop = 0;
+static int g_big_skip = 0;
 
 namespace xk {
 static int big_pick_w(int B, int k) {
   if (g_big_w < 0 || k < 8) return 0;
   if (g_big_w > 0) return g_big_w;
-  int w = 1;                                              // measured (scripts/k3m_sweep.py): one workgroup per CU across
-  while (w < 8 && (long)B * (w * 2) <= 256) w *= 2;       // the batch, at most 8 per matrix (4 up to order 256)
+  // measured (scripts/k3m_sweep.py, s2_k3_variants.py): alone on the chip 8 workgroups per matrix are fastest for 32
+  // matrices; beside the panel stream of the Davidson pipeline, which leaves 64 CUs to everything else, 4 are (128
+  // workgroups = two rounds on those CUs instead of four) — the pipeline is where this kernel runs
+  int w = 1;
+  while (w < 8 && (long)B * (w * 2) <= 128) w *= 2;
   if (k <= 256 && w > 4) w = 4;
   return w;
 }
@@ -779,10 +810,10 @@ static void big_launch_step(const T* Tin, T* S, T* aux, long aux_stride, int B, 
   const size_t lds = (size_t)step_lds_elems(k, nt / 64) * sizeof(T);
   if (j < 0)
     hipLaunchKernelGGL((tridiag_step_kernel<T, NT, true>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k, j,
-                       W, ldt, sT);
+                       W, ldt, sT, g_big_skip);
   else
     hipLaunchKernelGGL((tridiag_step_kernel<T, NT, false>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k,
-                       j, W, ldt, sT);
+                       j, W, ldt, sT, g_big_skip);
 }
 
 template <typename T, int NT, bool PRE>
@@ -851,6 +882,7 @@ int xk_small_eigh_big_tune(int what, int value) {
   if (what == 0) { old = g_big_w; if (value >= -1 && value <= 32) g_big_w = value; }
   if (what == 1) { old = g_big_threads; if (value == 256 || value == 512) g_big_threads = value; }
   if (what == 2) { old = g_big_stop; g_big_stop = value; }
+  if (what == 3) { old = g_big_skip; g_big_skip = value; }
   return old;
 }
 

@@ -28,7 +28,12 @@ def _workspace(nelem, dtype, device):
     key = (dtype, device, torch.cuda.current_stream().cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nelem:
-        w = torch.empty(max(nelem, 1), dtype=dtype, device=device)
+        # geometric growth: the Rayleigh-Ritz workspace of an un-restarted run grows with every iteration, and each
+        # new size would be a fresh hipMalloc (milliseconds, and a device-wide stall) in a process that has not cached it
+        grown = 0 if w is None else w.numel() + w.numel() // 2
+        w = None
+        _ws_cache.pop(key, None)
+        w = torch.empty(max(nelem, grown, 1), dtype=dtype, device=device)
         _ws_cache[key] = w
     return w
 

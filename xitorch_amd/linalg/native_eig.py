@@ -34,11 +34,9 @@ from xitorch_amd.dist import allreduce_max_
 
 __all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend"]
 
-import os as _os
-_PRELAUNCH = _os.environ.get("XITORCH_AMD_PRELAUNCH", "1") != "0"     # A/B: enqueue the next group's chain early
-# largest basis the global-memory Rayleigh-Ritz kernel (K3g) serves before the library takes over: one workgroup (one
-# CU's L2 bandwidth) per matrix, so its time does not depend on the batch, while the library spreads a matrix over the
-# chip.  (>= 16 matrices per group, fewer) — measured cross-over, xk_eigh_big.hip
+_PRELAUNCH = True          # enqueue the next group's chain early (module attribute: measurement scripts flip it for A/B)
+# largest basis the global-memory Rayleigh-Ritz solver (K3g, tridiagonalisation spread over several workgroups per
+# matrix: xk_eigh_big.hip) serves before the library takes over (>= 16 matrices per group, fewer): its limit of 768
 K3G_MAX_K = [768, 768]
 
 
@@ -251,11 +249,10 @@ class _Group:
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
         elif self.small_eigh in ("native", "tri") and not force_jacobi and k > K.SMALL_EIGH_MAX_K and \
                 k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
-            # (one workgroup per matrix: bound by one CU's L2 bandwidth, the same time for 4 or 32 matrices; the library
-            #  spreads a matrix over the chip and is faster from order ~480 / ~360 on, measured: xk_eigh_big.hip)
             # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra): the same
-            # tridiagonalisation route with the matrix in global memory; a flagged result is redone on the library
-            # (the driver's force_jacobi re-run lands in the branch below)
+            # tridiagonalisation route with the matrix in global memory, one launch per Householder step over several
+            # workgroups per matrix (2.4x rocSOLVER at order 582, 32 matrices; xk_eigh_big.hip); a flagged result is
+            # redone on the library (the driver's force_jacobi re-run lands in the branch below)
             end = self._mark("k3")
             lam, Yt, tri_flag = K.small_eigh_big(self.T, k, pk, uppest=(self.mode != "lowest"))
             end()
