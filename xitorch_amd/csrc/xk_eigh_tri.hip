@@ -249,44 +249,31 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
     T* du2 = lu + ((long)3 * n) * p + j;
     T* sw = lu + ((long)4 * n) * p + j;
 #define AT(arr, i) (arr)[(long)(i) * p]
-    for (int i = 0; i < n; ++i) {
-      AT(dg, i) = dd[i] - shift;
-      AT(dl, i) = (i < n - 1) ? ee[i] : T(0);
-      AT(du, i) = (i < n - 1) ? ee[i] : T(0);
-      AT(du2, i) = T(0);
-      AT(sw, i) = T(0);
-    }
-    // LU with partial pivoting (dgttrf)
+    // LU with partial pivoting (dgttrf), streamed: row i of the factorisation lives in (dcur, ucur), only the
+    // never-modified (d, e) are read, every factor is written once (the sequential loops of this phase cost LDS round
+    // trips, not arithmetic); dg holds the RECIPROCAL pivots (one reciprocal here instead of three divisions later)
+    T dcur = dd[0] - shift, ucur = n > 1 ? ee[0] : T(0);
     for (int i = 0; i + 1 < n; ++i) {
-      T di = AT(dg, i);
-      const T li = AT(dl, i);
-      if (fabs(di) >= fabs(li)) {
-        if (fabs(di) < pfloor) { di = di < T(0) ? -pfloor : pfloor; AT(dg, i) = di; }
-        const T fact = li * fast_rcp(di);
-        AT(dl, i) = fact;
-        AT(dg, i + 1) -= fact * AT(du, i);
+      const T li = ee[i];
+      const T dn = dd[i + 1] - shift;
+      const T un = (i + 2 < n) ? ee[i + 1] : T(0);
+      if (fabs(dcur) >= fabs(li)) {
+        if (fabs(dcur) < pfloor) dcur = dcur < T(0) ? -pfloor : pfloor;
+        const T inv = fast_rcp(dcur);
+        const T fact = li * inv;
+        AT(dl, i) = fact; AT(dg, i) = inv; AT(du, i) = ucur; AT(du2, i) = T(0); AT(sw, i) = T(0);
+        dcur = dn - fact * ucur;
+        ucur = un;
       } else {
-        const T fact = di * fast_rcp(li);
-        AT(dg, i) = li;
-        AT(dl, i) = fact;
-        const T tmp = AT(du, i);
-        const T dn = AT(dg, i + 1);
-        AT(du, i) = dn;
-        AT(dg, i + 1) = tmp - fact * dn;
-        if (i + 2 < n) {
-          const T un = AT(du, i + 1);
-          AT(du2, i) = un;
-          AT(du, i + 1) = -fact * un;
-        }
-        AT(sw, i) = T(1);
+        const T inv = fast_rcp(li);
+        const T fact = dcur * inv;
+        AT(dl, i) = fact; AT(dg, i) = inv; AT(du, i) = dn; AT(du2, i) = un; AT(sw, i) = T(1);
+        dcur = ucur - fact * dn;
+        ucur = -fact * un;
       }
     }
-    {
-      T dl_ = AT(dg, n - 1);
-      if (fabs(dl_) < pfloor) AT(dg, n - 1) = dl_ < T(0) ? -pfloor : pfloor;
-    }
-    // the triangular solves multiply by the reciprocal pivots (one reciprocal here instead of three divisions later)
-    for (int i = 0; i < n; ++i) AT(dg, i) = fast_rcp(AT(dg, i));
+    if (fabs(dcur) < pfloor) dcur = dcur < T(0) ? -pfloor : pfloor;
+    AT(dg, n - 1) = fast_rcp(dcur);
     // start vector: deterministic pseudo-random in (-1, 1)
     T* z = Z + (long)j * n;
     for (int i = 0; i < n; ++i) {
@@ -304,9 +291,24 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
       T* du2 = lu + ((long)3 * n) * p + j;
       T* sw = lu + ((long)4 * n) * p + j;
       T* z = Z + (long)j * n;
-      // forward substitution with the recorded row interchanges (running value carried in a register)
+      // forward substitution with the recorded row interchanges (running value carried in a register); the operands
+      // of 8 steps are fetched before their dependent chain
+      constexpr int SU = 8;
       T cur = z[0];
-      for (int i = 0; i + 1 < n; ++i) {
+      int i = 0;
+      for (; i + SU <= n - 1; i += SU) {
+        T nx[SU], l[SU], s_[SU], out[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { nx[u] = z[i + 1 + u]; l[u] = AT(dl, i + u); s_[u] = AT(sw, i + u); }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          if (s_[u] == T(0)) { out[u] = cur; cur = nx[u] - l[u] * cur; }
+          else { out[u] = nx[u]; cur = cur - l[u] * nx[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) z[i + u] = out[u];
+      }
+      for (; i + 1 < n; ++i) {
         const T nxt = z[i + 1];
         const T l = AT(dl, i);
         if (AT(sw, i) == T(0)) { z[i] = cur; cur = nxt - l * cur; }
@@ -320,16 +322,25 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
         z[n - 2] = t;
         zp2 = zp1; zp1 = t;
       }
-      for (int i = n - 3; i >= 0; --i) {
+      i = n - 3;
+      for (; i - (SU - 1) >= 0; i -= SU) {
+        T zz[SU], a_[SU], b_[SU], g_[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { zz[u] = z[i - u]; a_[u] = AT(du, i - u); b_[u] = AT(du2, i - u); g_[u] = AT(dg, i - u); }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const T t = (zz[u] - a_[u] * zp1 - b_[u] * zp2) * g_[u];
+          zz[u] = t;
+          zp2 = zp1; zp1 = t;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) z[i - u] = zz[u];
+      }
+      for (; i >= 0; --i) {
         const T t = (z[i] - AT(du, i) * zp1 - AT(du2, i) * zp2) * AT(dg, i);
         z[i] = t;
         zp2 = zp1; zp1 = t;
       }
-      // scale to unit max-norm (keeps the next solve in range)
-      T mx = T(0);
-      for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(z[i]));
-      const T inv = mx > T(0) ? T(1) / mx : T(1);
-      for (int i = 0; i < n; ++i) z[i] *= inv;
     }
 #undef AT
     __syncthreads();
@@ -337,6 +348,12 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
     if (wave == 0) {
       for (int j = 0; j < p; ++j) {
         T* zj = Z + (long)j * n;
+        // scale to unit max-norm first (keeps the sums below and the next solve in range)
+        T mx = T(0);
+        for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(zj[i]));
+        mx = wave_max(mx);
+        const T sc = (mx > T(0) && mx < T(INFINITY)) ? T(1) / mx : T(1);
+        for (int i = lane; i < n; i += 64) zj[i] *= sc;
         // (dstein re-orthogonalises inside clusters only; with p <= 16 vectors orthogonalising against ALL
         // previous ones costs nothing and removes the eps |T| / gap cross-talk of nearby eigenvalues as well)
         for (int q = j - 1; q >= 0; --q) {
