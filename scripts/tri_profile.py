@@ -1,6 +1,6 @@
 """cycle stamps of the phases of the K3t kernel (block 0)"""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from xitorch_amd import kernels as K, synthetic
 from xitorch_amd._capi import fn, ptr
