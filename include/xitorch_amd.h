@@ -282,17 +282,21 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
                       void* stream);
 
 /* ---- K3g: the same p wanted eigenpairs for Rayleigh-Ritz matrices of order 129 .. 768 (xk_eigh_big.hip) ---------
- * torch.linalg.eigh + _take_eigpairs (symeig.py:174-175, 255-264) once the un-restarted basis has outgrown the
- * LDS-resident kernels: Householder tridiagonalisation on a work copy in global memory (L2 / Infinity-Cache resident;
- * ws: xk_small_eigh_big_workspace_elems(B, k) elements), bisection / inverse iteration / self-check in LDS like K3t,
- * back-transformation from the reflectors parked in the work copy.  lam (B, p) ascending, Y (B, p, k) eigenvectors,
- * info[b] != 0 -> redo that call on the library solver.  xk_small_eigh_big_batch(k, p, elem_size): shifts
- * factorised at a time (> 0) when the problem fits the 160 KiB of LDS, 0 when it does not.  p <= 16. */
+ * torch.linalg.eigh + _take_eigpairs (symeig.py:174-175, 255-264) once the un-restarted basis (symeig.py:132-135) has
+ * outgrown the LDS-resident kernels: Householder tridiagonalisation of the upper triangle of a work copy in global
+ * memory, k - 1 launches (one per step, look-ahead form) over several workgroups per matrix; then bisection / inverse
+ * iteration / self-check in LDS like K3t and the back-transformation from the reflectors parked in the work copy, one
+ * workgroup per matrix.  The whole sequence is enqueued on `stream` by one call.  Only the lower triangle of T is read.
+ * ws: xk_small_eigh_big_workspace_elems(B, k) elements (work copies + the steps' hand-over blocks).
+ * lam (B, p) ascending, Y (B, p, k) eigenvectors, info[b] != 0 -> redo that call on the library solver.
+ * xk_small_eigh_big_batch(k, p, elem_size): shifts factorised at a time (> 0) when the problem fits the 160 KiB of
+ * LDS, 0 when it does not.  8 <= k <= 768, p <= 16. */
 int xk_small_eigh_big_batch(int k, int p, int elem_size);
 long xk_small_eigh_big_workspace_elems(int B, int k);
-/* measurement hook (no reference counterpart): what 0 = workgroups per matrix of the tridiagonalisation's step kernels
- * (0 automatic, -1 = the one-workgroup kernel does everything), what 1 = their threads per workgroup (256 / 512);
- * returns the previous value.  Changes what xk_small_eigh_big_workspace_elems returns. */
+/* measurement hook (no reference counterpart): what 0 = workgroups per matrix of the step kernels (0 automatic, 1 .. 32;
+ * changes what xk_small_eigh_big_workspace_elems returns), what 1 = their threads per workgroup (256 / 512), what 2 / 3
+ * = leave the final kernel after a phase / skip parts of the step kernel (timing only: wrong results by construction);
+ * returns the previous value. */
 int xk_small_eigh_big_tune(int what, int value);
 int xk_small_eigh_big_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* info, int B, int k,
                           int p, int uppest, long ldt, long sT, void* stream);

@@ -29,7 +29,7 @@ for dtype in (torch.float64, torch.float32) if quick else (torch.float64, torch.
                 rec["library_eigh_ms"] = round(t_of(lambda: torch.linalg.eigh(T)), 3)
             for threads in (512, 256):
                 tune(1, threads)
-                for W in ((-1, 0, 4, 8, 16, 32) if threads == 512 else (8, 16, 32)):
+                for W in ((0, 2, 4, 8, 16, 32) if threads == 512 else (8, 16, 32)):
                     if B * max(W, 1) > 1024:
                         continue
                     tune(0, W)

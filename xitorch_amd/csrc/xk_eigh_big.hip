@@ -1,37 +1,34 @@
-// xitorch_amd :: K3g — the p wanted eigenpairs of Rayleigh–Ritz matrices of order 129 .. 768, one workgroup per batch
-// member, the MATRIX in global memory (L2 / Infinity-Cache resident: 2 MB at order 512), everything else in LDS.
+// xitorch_amd :: K3g — the p wanted eigenpairs of Rayleigh–Ritz matrices of order 129 .. 768, the MATRIX in global
+// memory, the tridiagonalisation spread over several workgroups per matrix with one launch per Householder step.
 //
 // The un-restarted Davidson iteration of the reference (xitorch/_impls/linalg/symeig.py:132-135: the basis grows by
 // neig vectors per iteration until convergence, :174-175: torch.linalg.eigh of the full T every iteration) reaches
 // bases of 300-800 vectors on slowly converging spectra.  The LDS-resident kernels (xk_eigh.hip, xk_eigh_tri.hip)
 // stop at order 128; beyond that round 2 fell back to torch.linalg.eigh -> rocSOLVER: 8.7 / 14.7 / 22 ms for the 32
 // matrices of a batch group at order 256 / 384 / 512, against 6.4 ms of operator-panel product to hide under, i.e.
-// two thirds of the call on the S2 spectrum (profiles/r03_secondary_configs.jsonl).
+// two thirds of the call on the S2 spectrum.
 //
 // Same route as K3t (LAPACK's dsyevx: dsytd2 / dstebz / dstein / dormtr):
-//   0. copy:             the lower triangle of T (eigh's UPLO = 'L') mirrored into a full symmetric work copy S
-//   1. tridiagonalise:   Householder, k-2 steps, 2 barriers each.  Every wave recomputes the reflector from row j
-//                        (lane <-> columns j+1+lane+64t), accumulates the column form of S v over ITS rows (no
-//                        cross-lane reduction per row), partials meet in LDS; rank-2 update of the rows; the reflector
-//                        is parked in row j (contiguous: the back-transformation reads it coalesced).
-//                        S is read with sc1 loads (L2-served: another wave's stores are never seen through this CU's
-//                        L1) and every step ends with vmcnt(0) before its barrier (the stores have reached L2).
-//   2. bisection, 3. inverse iteration (in batches of pb shifts: the LU factors of 5 n pb elements are what limits LDS),
-//   5. self-check, 4. back-transformation y = H_0 ... H_{k-3} z (one wave per vector, next reflector prefetched).
+//   1. tridiagonalise:   tridiag_step_kernel, k - 1 launches over W workgroups per matrix (look-ahead Householder on
+//                        the upper triangle of a work copy; described at the kernel)
+//   then ONE workgroup per matrix (tridiag_eigh_big_kernel), everything in LDS:
+//   2. bisection (64 shifts per round and wave), 3. inverse iteration (in batches of pb shifts: the LU factors of
+//   5 n pb elements are what limits LDS), 5. self-check, 4. back-transformation y = H_0 ... H_{k-3} z from the reflectors
+//   parked in the rows of the work copy (one wave per vector, next reflector prefetched).
 // The result is checked like K3t's (residual on the tridiagonal level, orthogonality, non-finite, annihilated iterate);
 // a flagged member makes the caller repeat the step on the library solver.
 //
-// Measured (fp64, p = 6, 32 matrices; profiles/r03_k3g_vs_library.jsonl): order 192 / 256 / 384 / 512 / 640 / 768:
-// 2.6 / 4.6 / 11.3 / 24.0 / 47.5 / 75 ms against rocSOLVER's 5.4 / 8.7 / 14.7 / 22.0 / 32.7 / 43.7 ms; the same per
-// matrix whether 4 or 32 run (one workgroup = one CU per matrix, bound by that CU's L2 bandwidth), so the library,
-// which spreads one matrix over the chip, wins from order ~480 (32 matrices) / ~360 (4 matrices) on: the Davidson
-// driver switches near there (native_eig.py: the library's calls cost more inside the solver than in isolation, so
-// the switch sits a little later).  Also built and measured: sweeping only the upper triangle of the trailing block
-// (half the L2 traffic; per-row wave reductions and masks instead): 31.2 ms at order 512, 4.4 at 192 — slower, so the
-// sweeps are not bound by bytes either but by the dependent issue of 8-byte sc1 loads (scripts/_ab history; r03i).
-// What would lift it: 16-byte loads through an absolute column <-> lane map, the look-ahead form (update of step j
-// fused with the product of step j+1), several workgroups per matrix with a cross-workgroup hand-off per step —
-// not built.
+// Measured (fp64, p = 6; profiles/r03_k3m_sweep.jsonl), order 192 / 256 / 384 / 512 / 582 / 640 / 768:
+//   32 matrices:  1.7 / 2.5 / 5.1 / 8.5 / 11.0 / 13.2 / 18.6 ms   (rocSOLVER eigh: 5.4 / 8.6 / 14.6 / 22.1 / 27.2 / 32.7 / 43.8)
+//    4 matrices:  1.7 / 2.4 / 3.9 / 6.1 /  7.9 /  9.3 / 12.7 ms   (rocSOLVER eigh: 4.3 / 6.5 /  9.6 / 12.7 / 14.1 / 16.2 / 20.2)
+// at order 582, 32 matrices: step launches 8.4 ms (5.4 / 8.8 / 15.8 / 25.3 us each while 2 / 4 / 8 / 12 column slots of
+// 64 are live: ~4.6 us of launch + row j + 1 + reflector, ~3 us of partial sums and reflector j, the rest the row sweep,
+// which waits one trip to the Infinity Cache per two rows of a wave), bisection 0.4, inverse iteration 0.6, back-
+// transformation 0.4.  Round 3's first version did all of it in one workgroup per matrix (three passes over the
+// trailing block per step through ONE CU's L2 path): 3.0 / 5.4 / 13.6 / 28.7 / 44.8 / 56.8 / 91 ms, whatever the batch;
+// sweeping only the upper triangle in that form was slower (latency-, not byte-bound), here it is what the launches need
+// (8 -> 7.4 ms at 582).  Inside the Davidson pipeline the step kernels share the chip with the panel stream (64 CUs
+// left): 15.6 ms at order 582 there (scripts/s2_timeline.py).
 #include "xk_common.h"
 
 namespace xk {
@@ -98,15 +95,10 @@ __device__ __forceinline__ unsigned big_hash(unsigned x) {
   return x;
 }
 
-template <typename T, int NT, bool PRE>
+template <typename T, int NT>
 __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
-    const T* __restrict__ Tin, T* __restrict__ Sws, const T* __restrict__ aux, long aux_stride,
-    T* __restrict__ lam_out, T* __restrict__ Y_out,
-    int* __restrict__ info_out, int n, int p, int pb, int uppest, long ldt, long sT, int stop_after) {
-  // rows per trip of the matrix sweeps (loads in flight per wave = RPT x column slots).  Measured at order 512, 32
-  // matrices: 24.0 ms with 2, 28.6 ms with 4 — the sweeps are bound by what ONE compute unit draws from L2 (three
-  // passes over the trailing block per step: 6.3 MB at order 512 = 47 us at ~130 GB/s), not by the loads in flight
-  constexpr int RPT = 2;
+    T* __restrict__ Sws, const T* __restrict__ aux, long aux_stride, T* __restrict__ lam_out, T* __restrict__ Y_out,
+    int* __restrict__ info_out, int n, int p, int pb, int uppest, int stop_after) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* dd = reinterpret_cast<T*>(smem);                 // n  diagonal of the tridiagonal matrix
   T* ee = dd + n;                                     // n  sub-diagonal
@@ -115,19 +107,17 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   T* red = tau + n;                                   // 16 scratch scalars
   T* lamv = red + 16;                                 // BIG_MAXP eigenvalues
   T* Z = lamv + BIG_MAXP;                             // p x n eigenvectors of (d, e)
-  T* lu = Z + (long)p * n;                            // max(nw x n partial products, 5 x n x pb LU factors); nw = 8 waves (512 threads:
-                                                      // 2 waves per SIMD, 256 VGPRs each for the NT-slot vectors)
+  T* lu = Z + (long)p * n;                            // 5 x n x pb LU factors
   const int b = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, nw = nt >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const T* Tb = Tin + (long)b * sT;
   T* S = Sws + (long)b * n * n;
   const T eps = BigEps<T>::eps;
 
-  if (PRE) {
-    // the tridiagonalisation was done by the step kernels (tridiag_step_kernel): (d, e, tau) wait in the aux block,
-    // the reflectors are parked in the rows of S exactly as phase 1 below would have left them
+  {
+    // the tridiagonalisation was done by the step kernels (tridiag_step_kernel below): (d, e, tau) wait in the aux block,
+    // the reflectors are parked in the rows of S (row j, columns > j + 1)
     const T* ab = aux + (long)b * aux_stride;
     for (int i = tid; i < n; i += nt) {
       T d = ab[i], e = ab[n + i], tv = ab[2 * n + i];
@@ -136,146 +126,6 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       dd[i] = d; ee[i] = e; tau[i] = tv; e2[i] = e * e;
     }
     __syncthreads();
-  } else {
-  // ---- 0. work copy: lower triangle mirrored ----------------------------------------------------------
-  for (int idx = tid; idx < n * n; idx += nt) {
-    const int i = idx / n, j = idx - i * n;
-    S[idx] = (i >= j) ? Tb[(long)i * ldt + j] : Tb[(long)j * ldt + i];
-  }
-  vm_drain();
-  __syncthreads();
-
-  // ---- 1. Householder tridiagonalisation on the global copy ---------------------------------------------
-  T* part = lu;                                       // nw x n
-  for (int j = 0; j + 2 < n; ++j) {
-    const T* rowj = S + (long)j * n;
-    T x[NT], v[NT];
-    T ss = T(0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int c = j + 1 + lane + 64 * t;
-      x[t] = c < n ? ld_l2(rowj + c) : T(0);
-      if (!(t == 0 && lane == 0)) ss += x[t] * x[t];
-    }
-    const T sigma = wave_sum_dpp(ss);
-    const T alpha = big_readlane(x[0], 0);
-    T tj = T(0), scale = T(0), beta = alpha;
-    if (!(sigma == T(0))) {                           // (a NaN row must poison the result, not be skipped)
-      const T nrm = sqrt(alpha * alpha + sigma);
-      beta = alpha >= T(0) ? -nrm : nrm;
-      tj = (beta - alpha) * big_rcp(beta);
-      scale = big_rcp(alpha - beta);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) v[t] = (t == 0 && lane == 0) ? T(1) : x[t] * scale;
-    if (tj != T(0)) {                                 // (wave-uniform and identical in every wave)
-      T acc[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = T(0);
-      int i = j + 1 + wave;
-      for (; i + (RPT - 1) * nw < n; i += RPT * nw) {
-        T sr[RPT][NT], vi[RPT];
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-          const T* ru = S + (long)(i + u * nw) * n;
-          vi[u] = dist_get<T, NT>(v, i + u * nw - j - 1);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int c = j + 1 + lane + 64 * t;
-            sr[u][t] = c < n ? ld_l2(ru + c) : T(0);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < RPT; ++u)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] += sr[u][t] * vi[u];
-      }
-      for (; i < n; i += nw) {
-        const T* r0 = S + (long)i * n;
-        const T vi0 = dist_get<T, NT>(v, i - j - 1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int c = j + 1 + lane + 64 * t;
-          acc[t] += (c < n ? ld_l2(r0 + c) : T(0)) * vi0;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int c = j + 1 + lane + 64 * t;
-        if (c < n) part[wave * n + c] = acc[t];
-      }
-    }
-    __syncthreads();
-    if (tj != T(0)) {
-      T w[NT], q[NT];
-      T wv = T(0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int c = j + 1 + lane + 64 * t;
-        T sw_ = T(0);
-        if (c < n)
-          for (int ww_ = 0; ww_ < nw; ++ww_) sw_ += part[ww_ * n + c];
-        w[t] = sw_ * tj;
-        wv += w[t] * v[t];
-      }
-      const T K = T(0.5) * tj * wave_sum_dpp(wv);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) q[t] = w[t] - K * v[t];
-      int i = j + 1 + wave;
-      for (; i + (RPT - 1) * nw < n; i += RPT * nw) {
-        T sr[RPT][NT], vi[RPT], qi[RPT];
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-          const T* ru = S + (long)(i + u * nw) * n;
-          vi[u] = dist_get<T, NT>(v, i + u * nw - j - 1);
-          qi[u] = dist_get<T, NT>(q, i + u * nw - j - 1);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int c = j + 1 + lane + 64 * t;
-            sr[u][t] = c < n ? ld_l2(ru + c) : T(0);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-          T* ru = S + (long)(i + u * nw) * n;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int c = j + 1 + lane + 64 * t;
-            if (c < n) ru[c] = sr[u][t] - (vi[u] * q[t] + qi[u] * v[t]);
-          }
-        }
-      }
-      for (; i < n; i += nw) {
-        T* r0 = S + (long)i * n;
-        const int ra = i - j - 1;
-        const T vi0 = dist_get<T, NT>(v, ra), qi0 = dist_get<T, NT>(q, ra);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int c = j + 1 + lane + 64 * t;
-          if (c < n) r0[c] = ld_l2(r0 + c) - (vi0 * q[t] + qi0 * v[t]);
-        }
-      }
-    }
-    if (wave == 0) {
-      // row j (right of the diagonal) is no longer read by anybody: park the reflector there
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int c = j + 1 + lane + 64 * t;
-        if (c < n && c > j + 1) S[(long)j * n + c] = v[t];
-      }
-      if (lane == 0) { tau[j] = tj; ee[j] = beta; dd[j] = ld_l2(S + (long)j * n + j); }
-    }
-    vm_drain();
-    __syncthreads();
-  }
-  if (tid == 0) {
-    if (n >= 2) { dd[n - 2] = ld_l2(S + (long)(n - 2) * n + (n - 2)); ee[n - 2] = ld_l2(S + (long)(n - 2) * n + (n - 1)); }
-    dd[n - 1] = ld_l2(S + (long)(n - 1) * n + (n - 1));
-    if (n >= 1) ee[n - 1] = T(0);
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += nt) e2[i] = ee[i] * ee[i];
-  __syncthreads();
   }
 
   // ---- 2. bisection: wave w -> wanted eigenvalue number w (ascending) ---------------------------------
@@ -773,18 +623,15 @@ __global__ __launch_bounds__(512) void tridiag_step_kernel(
 
 static long step_lds_elems(long n, long nw) { return 2 * n + 8 + nw * n; }
 
-// LDS elements for order n, p wanted pairs, LU batches of pb shifts, nw waves
-static long big_lds_elems(long n, long p, long pb, long nw) {
-  const long scratch = 5L * n * pb > nw * n ? 5L * n * pb : nw * n;
-  return 4 * n + 16 + BIG_MAXP + p * n + scratch;
-}
+// LDS elements of the final kernel for order n, p wanted pairs, LU batches of pb shifts
+static long big_lds_elems(long n, long p, long pb) { return 4 * n + 16 + BIG_MAXP + p * n + 5L * n * pb; }
 
 }  // namespace xk
 
 extern "C" int xk_small_eigh_big_batch(int k, int p, int elem_size);
 
-// measurement hooks: workgroups per matrix of the step kernels (0 = automatic, -1 = the one-workgroup kernel for
-// everything), threads per workgroup of the step kernels, "stop after phase" of the final kernel
+// measurement hooks: workgroups per matrix of the step kernels (0 = automatic), their threads per workgroup, "leave the
+// final kernel after phase", "skip parts of the step kernel" (the last two give wrong results by construction)
 static int g_big_w = 0;
 static int g_big_threads = 512;
 static int g_big_stop = 0;
@@ -792,7 +639,6 @@ static int g_big_skip = 0;
 
 namespace xk {
 static int big_pick_w(int B, int k) {
-  if (g_big_w < 0 || k < 8) return 0;
   if (g_big_w > 0) return g_big_w;
   // measured (scripts/k3m_sweep.py, s2_k3_variants.py): alone on the chip 8 workgroups per matrix are fastest for 32
   // matrices; beside the panel stream of the Davidson pipeline, which leaves 64 CUs to everything else, 4 are (128
@@ -816,14 +662,14 @@ static void big_launch_step(const T* Tin, T* S, T* aux, long aux_stride, int B, 
                        j, W, ldt, sT, g_big_skip);
 }
 
-template <typename T, int NT, bool PRE>
-static int big_launch_final(const T* Tin, T* ws, const T* aux, long aux_stride, T* lam, T* Y, int* info, int B, int k,
-                            int p, int pb, int uppest, long ldt, long sT, long lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute((const void*)tridiag_eigh_big_kernel<T, NT, PRE>,
+template <typename T, int NT>
+static int big_launch_final(T* ws, const T* aux, long aux_stride, T* lam, T* Y, int* info, int B, int k, int p, int pb,
+                            int uppest, long lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute((const void*)tridiag_eigh_big_kernel<T, NT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((tridiag_eigh_big_kernel<T, NT, PRE>), dim3(B), dim3(512), (size_t)lds, st, Tin, ws, aux,
-                     aux_stride, lam, Y, info, k, p, pb, uppest, ldt, sT, g_big_stop);
+  hipLaunchKernelGGL((tridiag_eigh_big_kernel<T, NT>), dim3(B), dim3(512), (size_t)lds, st, ws, aux, aux_stride, lam, Y,
+                     info, k, p, pb, uppest, g_big_stop);
   return XK_OK;
 }
 
@@ -832,26 +678,20 @@ static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, 
                    long ldt, long sT, hipStream_t st) {
   const int pb = xk_small_eigh_big_batch(k, p, (int)sizeof(T));
   if (pb == 0) return XK_ERR_UNSUPPORTED;
-  const long lds = big_lds_elems(k, p, pb, 8) * (long)sizeof(T) + 64;
+  const long lds = big_lds_elems(k, p, pb) * (long)sizeof(T) + 64;
   const int W = big_pick_w(B, k);
-  const long aux_stride = W > 0 ? (long)k * (7 + 2 * W) : 0;
+  const long aux_stride = (long)k * (7 + 2 * W);
   if (ws == nullptr || ws_elems < (long)B * k * k + (long)B * aux_stride) return XK_ERR_ARG;
   T* aux = ws + (long)B * k * k;
-  int rc;
-  if (W > 0) {
-    for (int j = -1; j <= k - 3; ++j) {
-      const int m2 = k - (j + 2);
-      if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
-      else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
-      else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
-      else big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
-    }
-    rc = k <= 512 ? big_launch_final<T, 8, true>(Tin, ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st)
-                  : big_launch_final<T, 12, true>(Tin, ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st);
-  } else {
-    rc = k <= 512 ? big_launch_final<T, 8, false>(Tin, ws, nullptr, 0L, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st)
-                  : big_launch_final<T, 12, false>(Tin, ws, nullptr, 0L, lam, Y, info, B, k, p, pb, uppest, ldt, sT, lds, st);
+  for (int j = -1; j <= k - 3; ++j) {                     // (column slots of 64 that are still live: 2 / 4 / 8 / 12)
+    const int m2 = k - (j + 2);
+    if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+    else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+    else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+    else big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
   }
+  const int rc = k <= 512 ? big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, st)
+                          : big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, st);
   if (rc != XK_OK) return rc;
   XK_LAUNCH_CHECK();
   return XK_OK;
@@ -863,23 +703,24 @@ extern "C" {
 /* the LU batch size (shifts factorised at a time) the kernel would use for order k, p pairs, or 0 when it does not
  * fit the 160 KiB of LDS at all (elem_size 8 / 4) */
 int xk_small_eigh_big_batch(int k, int p, int elem_size) {
-  if (k < 2 || k > 768 || p < 1 || p > xk::BIG_MAXP || p > k) return 0;
+  if (k < 8 || k > 768 || p < 1 || p > xk::BIG_MAXP || p > k) return 0;
   for (int pb = p; pb >= 1; --pb)
-    if (xk::big_lds_elems(k, p, pb, 8) * elem_size + 64 <= 160 * 1024) return pb;
+    if (xk::big_lds_elems(k, p, pb) * elem_size + 64 <= 160 * 1024) return pb;
   return 0;
 }
 
 long xk_small_eigh_big_workspace_elems(int B, int k) {
   const int W = xk::big_pick_w(B, k);
-  return (long)B * k * k + (W > 0 ? (long)B * k * (7 + 2 * W) : 0L);
+  return (long)B * k * k + (long)B * k * (7 + 2 * W);
 }
 
-/* measurement hook: what 0 = workgroups per matrix of the step kernels (0 automatic, -1 one-workgroup kernel only),
- * what 1 = threads per workgroup of the step kernels (256 / 512), what 2 = leave the final kernel after phase 2 / 3 / 5
- * (wrong results by construction).  Returns the previous value. */
+/* measurement hook: what 0 = workgroups per matrix of the step kernels (0 automatic, 1 .. 32), what 1 = their threads
+ * per workgroup (256 / 512), what 2 = leave the final kernel after phase 2 / 3 / 5, what 3 = bit mask of step-kernel
+ * parts to skip (1 row sweep, 2 reflector + partial sums, 4 partial flush) — 2 and 3 give wrong results by construction.
+ * Returns the previous value. */
 int xk_small_eigh_big_tune(int what, int value) {
   int old = -1000;
-  if (what == 0) { old = g_big_w; if (value >= -1 && value <= 32) g_big_w = value; }
+  if (what == 0) { old = g_big_w; if (value >= 0 && value <= 32) g_big_w = value; }
   if (what == 1) { old = g_big_threads; if (value == 256 || value == 512) g_big_threads = value; }
   if (what == 2) { old = g_big_stop; g_big_stop = value; }
   if (what == 3) { old = g_big_skip; g_big_skip = value; }
@@ -889,7 +730,7 @@ int xk_small_eigh_big_tune(int what, int value) {
 #define XK_DEFINE_EIGH_BIG(SUF, T)                                                                            \
   int xk_small_eigh_big_##SUF(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k,      \
                               int p, int uppest, long ldt, long sT, void* stream) {                           \
-    if (B < 0 || k < 2 || k > 768 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                   \
+    if (B < 0 || k < 8 || k > 768 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                   \
     if (B == 0) return XK_OK;                                                                                 \
     return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, (hipStream_t)stream);    \
   }

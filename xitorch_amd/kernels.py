@@ -253,7 +253,7 @@ SMALL_EIGH_BIG_MAX_K = 768
 
 def small_eigh_big_ok(k, p, dtype):
     """does the global-memory tridiagonalisation kernel (K3g) serve order k with p wanted pairs?"""
-    if k < 2 or k > SMALL_EIGH_BIG_MAX_K or p > SMALL_EIGH_MAX_P or p > k:
+    if k < 8 or k > SMALL_EIGH_BIG_MAX_K or p > SMALL_EIGH_MAX_P or p > k:
         return False
     return fn("xk_small_eigh_big_batch")(k, p, 8 if dtype == torch.float64 else 4) > 0
 
