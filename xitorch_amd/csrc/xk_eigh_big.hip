@@ -58,14 +58,6 @@ __device__ __forceinline__ float big_rcp(float x) {
   r = fmaf(fmaf(-x, r, 1.0f), r, r);
   return r;
 }
-// L2-served load: bypasses this CU's vector L1, which a store of another wave does not refresh
-template <typename T>
-__device__ __forceinline__ T ld_l2(const T* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// all outstanding vector memory operations of this wave have completed (stores acknowledged by L2)
-__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0f70); }
-
 // value of element r (0-based, wave-uniform) of a vector distributed as slot[t] of lane l <-> element l + 64 t
 template <typename T, int NT>
 __device__ __forceinline__ T dist_get(const T (&v)[NT], int r) {
@@ -353,7 +345,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int i = lane + 64 * t;
-        vn[t] = (i < n && i > r + 1) ? ld_l2(S + (long)r * n + i) : T(0);
+        vn[t] = (i < n && i > r + 1) ? S[(long)r * n + i] : T(0);
       }
     }
     for (; r >= 0; --r) {
@@ -367,7 +359,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int i = lane + 64 * t;
-          vn[t] = (i < n && i > r) ? ld_l2(S + (long)(r - 1) * n + i) : T(0);
+          vn[t] = (i < n && i > r) ? S[(long)(r - 1) * n + i] : T(0);
         }
       }
       const T tr = tau[r];
