@@ -290,7 +290,8 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  * ws: xk_small_eigh_big_workspace_elems(B, k) elements (work copies + the steps' hand-over blocks).
  * lam (B, p) ascending, Y (B, p, k) eigenvectors, info[b] != 0 -> redo that call on the library solver.
  * xk_small_eigh_big_batch(k, p, elem_size): shifts factorised at a time (> 0) when the problem fits the 160 KiB of
- * LDS, 0 when it does not.  8 <= k <= 768, p <= 16. */
+ * LDS, 0 when it does not.  8 <= k <= 768, p <= 64 (also the solver for MORE THAN 16 wanted pairs at any order: wide
+ * eigen-blocks, thick restarts; the batch of vectors in work lives in LDS, finished ones in the rows of Y). */
 int xk_small_eigh_big_batch(int k, int p, int elem_size);
 long xk_small_eigh_big_workspace_elems(int B, int k);
 /* measurement hook (no reference counterpart): what 0 = workgroups per matrix of the step kernels (0 automatic, 1 .. 32;
@@ -308,10 +309,12 @@ int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long 
  * few microseconds of host time instead of an interpreter round trip per launch (what bounds small per-GPU batches).
  * xk_davidson_ritz: xk_ritz_residual + the group status {max_b rmax (NaN-propagating), max_b info, max_b flag} as
  *   three doubles; rmax is left zeroed for the next step (symeig.py:178-197).  flag may be NULL.
- * xk_davidson_orth: rows [k0, k0+q) of the basis V (B, cap, ldv) against rows [0, k0): `passes` rounds of block
- *   Gram-Schmidt (C[b,c,a] = <V_a, t_c>, t_c -= sum_a C V_a), then CholeskyQR of the q rows — for q <= 8 in ONE kernel
- *   (Gram, Cholesky, inverse, transform; one workgroup per batch member) — i.e. tallqr of [V, t] restricted to the new
- *   block (_utils/tensor.py:8-19, symeig.py:207-220).  C: scratch >= B*q*max(k0,q), W: scratch B*q*q, info[b] sticky
+ * xk_davidson_orth: rows [k0, k0+q) of the basis V (B, cap, ldv) against rows [0, k0): block Gram-Schmidt
+ *   (C[b,c,a] = <V_a, t_c>, t_c -= sum_a C V_a) and CholeskyQR of the q rows — for q <= 8 in ONE kernel (Gram,
+ *   Cholesky, inverse, transform; one workgroup per batch member) — i.e. tallqr of [V, t] restricted to the new block
+ *   (_utils/tensor.py:8-19, symeig.py:207-220).  passes = 0: CholeskyQR only; 1: projection, CholeskyQR; >= 2:
+ *   [projection, CholeskyQR] per pass with the FIRST CholeskyQR shifted (Gram + 11 (N q + q (q + 1)) u trace I): the
+ *   order that keeps nearly dependent panels (Gram spectrum over 15 decades) positive definite and orthogonal to V.  C: scratch >= B*q*max(k0,q), W: scratch B*q*q, info[b] sticky
  *   index+1 of a non-positive pivot, ws: xk_dense_mm_workspace_elems(B, cap, N, q, 0).  Any q: panels wider than
  *   32 are taken 32 rows at a time, each chunk against everything before it (twice), then among itself.
  * xk_davidson_extend_t: Tn[b,c,a] = <V_a, (AV)_{k0+c}> for a < k0+q, written to T[b, k0+c, a] and mirrored to

@@ -449,14 +449,21 @@ def _separated_ends_operator(dev, N=1536):
 
 @pytest.mark.parametrize("neig,nguess,mode,restart", [(40, None, "lowest", None), (36, 40, "uppest", None),
                                                       (20, None, "lowest", 100), (10, None, "lowest", 40), (16, None, "lowest", None)])
-def test_wide_blocks_and_restart_beyond_16(dev, neig, nguess, mode, restart):
+def test_wide_blocks_and_restart_beyond_16(dev, neig, nguess, mode, restart, monkeypatch):
     """No width cliff: neig / nguess > 32 go through the chunked panel orthonormalisation
     (the reference has no limit: symeig.py:100-140); thick restart with 16 < neig <= 32 keeps at least the wanted
-    vectors.  Against the dense eigendecomposition."""
+    vectors; more than 16 wanted pairs (up to 64) stay on the native Rayleigh-Ritz solver (K3g) — no library eigh as long
+    as the basis holds at most 768 vectors.  Against the dense eigendecomposition."""
     mat, lam_all = _separated_ends_operator(dev)
     A = xa.LinearOperator.m(mat, is_hermitian=True)
     tr = {}
+    calls = []
+    real_eigh = torch.linalg.eigh
+    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (calls.append(1), real_eigh(*a, **k))[1])
     ev, X = davidson(A, neig, mode, min_eps=1e-8, nguess=nguess, restart=restart, trace=tr)
+    monkeypatch.undo()
+    if tr["basis_size"] <= 768 and (restart is None or 2 * neig <= 64):
+        assert calls == [] and tr["k3_fallbacks"] == 0, (len(calls), tr["k3_fallbacks"], tr["basis_size"])
     assert tr["stop_reason"] == "converged", tr["stop_reason"]
     assert ev.shape == (2, neig) and X.shape == (2, 1536, neig)
     want = lam_all[:, :neig] if mode == "lowest" else lam_all[:, -neig:]

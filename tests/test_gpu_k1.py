@@ -367,7 +367,10 @@ def test_group_status_kernel(dev, dtype, B):
                                                 (2, 333, 4, False, torch.float64), (2, 512, 6, False, torch.float64),
                                                 (1, 600, 6, False, torch.float64), (1, 768, 6, True, torch.float64),
                                                 (2, 300, 12, False, torch.float64), (2, 256, 16, False, torch.float32),
-                                                (2, 400, 6, False, torch.float32), (2, 129, 1, False, torch.float64)])
+                                                (2, 400, 6, False, torch.float32), (2, 129, 1, False, torch.float64),
+                                                (2, 100, 20, False, torch.float64), (2, 300, 40, True, torch.float64),
+                                                (1, 200, 64, False, torch.float64), (2, 24, 17, False, torch.float64),
+                                                (1, 90, 33, False, torch.float32)])
 def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
     """K3g (orders 129 .. 768, matrix in global memory) against LAPACK: eigenvalues, residual, orthonormality, on
     matrices shaped like a Davidson T (a few separated eigenvalues below a dense band) and on random ones; the

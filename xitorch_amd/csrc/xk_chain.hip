@@ -10,7 +10,8 @@
 // The entry points below enqueue a whole stage from C++ (a launch is ~3 us here) on the caller's stream:
 //
 //   xk_davidson_ritz      ritz_residual + group status (which re-zeroes the per-member max for the next round)
-//   xk_davidson_orth      block Gram-Schmidt of the new panel against the basis (passes x [Gram, projection]) +
+//   xk_davidson_orth      block Gram-Schmidt of the new panel against the basis (one pass: Gram, projection, CholeskyQR;
+//                         more: [Gram, projection, CholeskyQR] per pass, the first CholeskyQR shifted), the
 //                         CholeskyQR of the panel in ONE kernel (Gram, Cholesky, inverse, transform; one workgroup per
 //                         batch member, the p x N panel is read twice and written once) — panels up to 8 vectors;
 //                         wider ones take the separate Gram / xk_panel_chol / xk_panel_transform kernels
@@ -128,11 +129,13 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
 // CholeskyQR of a P-row panel in one kernel (tallqr restricted to the new block, _utils/tensor.py:15-18):
 //   G = t t^T (P x P, symmetrised like xk_panel_chol), G = R^T R, W = R^-1, t <- W^T t   (row c <- sum_{a<=c} W[a,c] t_a)
 // One 1024-thread workgroup per batch member; info[b] = index+1 of the first non-positive pivot (sticky, like
-// xk_panel_chol).  P <= 8.
+// xk_panel_chol).  P <= 8.  shift_rel > 0: the first step of shifted CholeskyQR (Fukaya et al.): the Gram matrix gets
+// shift_rel * trace(G) on its diagonal, which makes the factorisation safe for panels whose condition number squared
+// exceeds 1 / eps; the result is then only well-conditioned, not orthonormal — a plain pass follows.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int P>
 __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, int* __restrict__ info, int N,
-                                                            long ldt, long sT) {
+                                                            long ldt, long sT, T shift_rel) {
   // (N here is the panel length rounded up to whole 16 B vectors: the pad elements are zero by the panel contract)
   typedef typename Vec16<T>::type VT;
   constexpr int VN = Vec16<T>::n;
@@ -173,6 +176,11 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
         G[c][d] = s;
         G[d][c] = s;
       }
+    if (shift_rel > T(0)) {                                    // shifted CholeskyQR: G + (shift_rel trace G) I
+      T tr = T(0);
+      for (int c = 0; c < P; ++c) tr += G[c][c];
+      for (int c = 0; c < P; ++c) G[c][c] += shift_rel * tr;
+    }
     int bad = 0;
     for (int r = 0; r < P; ++r)
       for (int c = 0; c < P; ++c) R[r][c] = T(0);
@@ -237,12 +245,24 @@ __global__ __launch_bounds__(256) void t_scatter_kernel(const T* __restrict__ Tn
   if (a < k0) Tb[(long)a * ldt + k0 + c] = v;
 }
 
+// G[b] += shift_rel * trace(G[b]) * I for the (B, q, q) Gram blocks of the wide-panel path
 template <typename T>
-static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT, hipStream_t st) {
+__global__ __launch_bounds__(64) void gram_shift_kernel(T* __restrict__ G, int B, int q, T shift_rel) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  T* Gb = G + (long)b * q * q;
+  T tr = T(0);
+  for (int c = 0; c < q; ++c) tr += Gb[(long)c * q + c];
+  for (int c = 0; c < q; ++c) Gb[(long)c * q + c] += shift_rel * tr;
+}
+
+template <typename T>
+static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT, T shift_rel, hipStream_t st) {
   switch (P) {
 #define XK_CASE(PP)                                                                                        \
   case PP:                                                                                                 \
-    hipLaunchKernelGGL((panel_cholqr_kernel<T, PP>), dim3(B), dim3(1024), 0, st, Tp, info, N, ldt, sT);    \
+    hipLaunchKernelGGL((panel_cholqr_kernel<T, PP>), dim3(B), dim3(1024), 0, st, Tp, info, N, ldt, sT,   \
+                       shift_rel);                                                                         \
     break;
     XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
 #undef XK_CASE
@@ -252,29 +272,54 @@ static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT
   return XK_OK;
 }
 
+// CholeskyQR of panel rows [k0, k0 + q) (q <= 32), optionally shifted
+template <typename T>
+static int panel_cholqr(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
+                        long ws_elems, T shift_rel, void* stream) {
+  constexpr int VN = Vec16<T>::n;
+  T* panel = V + (long)k0 * ldv;
+  if (q <= 8) return cholqr_fused<T>(panel, info, B, q, (N + VN - 1) / VN * VN, ldv, sV, shift_rel, (hipStream_t)stream);
+  // wider panels: Gram on K1, Cholesky + inverse per member, transform
+  T* G = C;                                               // (B, q, q) fits: the caller sizes C for q * max(k0, q)
+  int rc = dense_mm(panel, panel, G, ws, ws_elems, B, q, N, q, ldv, sV, ldv, sV, (long)q, (long)q * q, stream);
+  if (rc != XK_OK) return rc;
+  if (shift_rel > T(0)) {
+    hipLaunchKernelGGL((gram_shift_kernel<T>), dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, G, B, q, shift_rel);
+    XK_LAUNCH_CHECK();
+  }
+  rc = chol_c(G, W, info, B, q, (long)q, (long)q * q, stream);
+  if (rc != XK_OK) return rc;
+  return transform_c(panel, W, B, q, (int)ldv, ldv, sV, stream);
+}
+
+// One pass (the default of the un-restarted iteration: a Ritz residual block is orthogonal to the basis up to
+// rounding and its Gram matrix is benign): projection, CholeskyQR.  Two or more: block Gram-Schmidt with
+// re-orthogonalisation in the order that survives ill-conditioned panels — [projection, CholeskyQR] per pass, the
+// first CholeskyQR shifted: a panel of nearly dependent residuals (wide blocks close to convergence: Gram spectrum
+// over 15 decades measured) otherwise loses (a) positive definiteness of its Gram matrix in floating point and (b)
+// through R^-1 the orthogonality against the basis that the projections before it had established.
 template <typename T>
 static int davidson_orth_block(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
                                long ws_elems, int passes, void* stream) {
-  constexpr int VN = Vec16<T>::n;
   T* panel = V + (long)k0 * ldv;
+  const double u = sizeof(T) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-08;
+  double sh = 11.0 * ((double)N * q + (double)q * (q + 1)) * u;
+  if (sh > 1e-3) sh = 1e-3;
+  const int rounds = passes >= 2 ? passes : 1;
   int rc;
-  if (k0 > 0) {
-    for (int it = 0; it < passes; ++it) {
+  for (int it = 0; it < rounds; ++it) {
+    if (k0 > 0 && passes >= 1) {
       // C[b,c,a] = <V_a, t_c> (a < k0), then t_c -= sum_a C[b,c,a] V_a   (tensor.py:15-18 restricted to the new block)
       rc = dense_mm(V, panel, C, ws, ws_elems, B, k0, N, q, ldv, sV, ldv, sV, (long)k0, (long)q * k0, stream);
       if (rc != XK_OK) return rc;
       rc = lincomb_c(V, C, panel, B, k0, (int)ldv, q, ldv, sV, (long)q * k0, 1L, (long)k0, ldv, sV, -1.0, 1.0, stream);
       if (rc != XK_OK) return rc;
     }
+    const T shift = (rounds >= 2 && it == 0) ? (T)sh : T(0);
+    rc = panel_cholqr<T>(V, B, N, k0, q, ldv, sV, C, W, info, ws, ws_elems, shift, stream);
+    if (rc != XK_OK) return rc;
   }
-  if (q <= 8) return cholqr_fused<T>(panel, info, B, q, (N + VN - 1) / VN * VN, ldv, sV, (hipStream_t)stream);
-  // wider panels: Gram on K1, Cholesky + inverse per member, transform
-  T* G = C;                                               // (B, q, q) fits: the caller sizes C for q * max(k0, q)
-  rc = dense_mm(panel, panel, G, ws, ws_elems, B, q, N, q, ldv, sV, ldv, sV, (long)q, (long)q * q, stream);
-  if (rc != XK_OK) return rc;
-  rc = chol_c(G, W, info, B, q, (long)q, (long)q * q, stream);
-  if (rc != XK_OK) return rc;
-  return transform_c(panel, W, B, q, (int)ldv, ldv, sV, stream);
+  return XK_OK;
 }
 
 // Panels wider than the 32 columns of the per-member Cholesky kernel are taken 32 rows at a time: every chunk is

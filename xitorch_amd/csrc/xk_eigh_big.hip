@@ -37,7 +37,7 @@ template <typename T> struct BigEps;
 template <> struct BigEps<double> { static constexpr double eps = 2.220446049250313e-16; static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct BigEps<float> { static constexpr float eps = 1.1920929e-07f; static constexpr float tiny = 1.17549435e-38f; };
 
-constexpr int BIG_MAXP = 16;
+constexpr int BIG_MAXP = 64;
 
 __device__ __forceinline__ double big_readlane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -98,13 +98,15 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   T* tau = e2 + n;                                    // n
   T* red = tau + n;                                   // 16 scratch scalars
   T* lamv = red + 16;                                 // BIG_MAXP eigenvalues
-  T* Z = lamv + BIG_MAXP;                             // p x n eigenvectors of (d, e)
-  T* lu = Z + (long)p * n;                            // 5 x n x pb LU factors
+  T* Zb = lamv + BIG_MAXP;                            // pb x n: the eigenvectors of (d, e) of the batch in work; finished
+                                                      // batches wait in the rows of Y_out (global), where step 4 turns them
+  T* lu = Zb + (long)pb * n;                          // 5 x n x pb LU factors
   const int b = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, nw = nt >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   T* S = Sws + (long)b * n * n;
+  T* Yg = Y_out + (long)b * p * n;                    // (B, p, n): row j = eigenvector j, first of (d, e), then of T
   const T eps = BigEps<T>::eps;
 
   {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       }
       if (fabs(dcur) < pfloor) dcur = dcur < T(0) ? -pfloor : pfloor;
       AT(dg, n - 1) = big_rcp(dcur);
-      T* z = Z + (long)j * n;
+      T* z = Zb + (long)jl * n;
       for (int i = 0; i < n; ++i) {
         const unsigned h = big_hash((unsigned)(i * 131 + j * 7919 + 12345));
         z[i] = T((int)(h & 0xffffff) - 0x800000) / T(0x800000);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
         const T* du = lu + ((long)2 * n) * pb + jl;
         const T* du2 = lu + ((long)3 * n) * pb + jl;
         const T* sw = lu + ((long)4 * n) * pb + jl;
-        T* z = Z + (long)j * n;
+        T* z = Zb + (long)jl * n;
         T cur = z[0];
         int i = 0;
         for (; i + SU <= n - 1; i += SU) {            // forward: L^-1 with the row interchanges
@@ -267,14 +269,14 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       // batch) and normalisation: wave 0, vectors in order
       if (wave == 0) {
         for (int j = j0; j < j0 + nb; ++j) {
-          T* zj = Z + (long)j * n;
+          T* zj = Zb + (long)(j - j0) * n;
           T mx = T(0);
           for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(zj[i]));
           mx = wave_max(mx);
           const T sc = (mx > T(0) && mx < T(INFINITY)) ? T(1) / mx : T(1);
           for (int i = lane; i < n; i += 64) zj[i] *= sc;
           for (int q = j - 1; q >= 0; --q) {
-            const T* zq = Z + (long)q * n;
+            const T* zq = q >= j0 ? Zb + (long)(q - j0) * n : Yg + (long)q * n;
             T dp = T(0);
             for (int i = lane; i < n; i += 64) dp += zq[i] * zj[i];
             dp = wave_sum_dpp(dp);
@@ -290,6 +292,8 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       }
       __syncthreads();
     }
+    for (int idx = tid; idx < nb * n; idx += nt) Yg[(long)j0 * n + idx] = Zb[idx];     // rows j0 .. j0 + nb - 1
+    __syncthreads();
   }
 #undef AT
   if (stop_after == 3) return;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     T worst = T(0);
     int nonfinite = 0;
     for (int j = 0; j < p; ++j) {
-      const T* zj = Z + (long)j * n;
+      const T* zj = Yg + (long)j * n;
       const T lam = lamv[j];
       T r = T(0);
       for (int i = lane; i < n; i += 64) {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       r = wave_max(r);
       worst = fmax(worst, r);
       if (j > 0) {
-        const T* zq = Z + (long)(j - 1) * n;
+        const T* zq = Yg + (long)(j - 1) * n;
         T dp = T(0);
         for (int i = lane; i < n; i += 64) dp += zq[i] * zj[i];
         dp = fabs(wave_sum_dpp(dp));
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   if (stop_after == 5) return;
   // ---- 4. back-transformation y = H_0 ... H_{n-3} z, one wave per vector, next reflector prefetched -------
   for (int j = wave; j < p; j += nw) {
-    const T* zj = Z + (long)j * n;
+    const T* zj = Yg + (long)j * n;
     T y[NT], vn[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(512) void tridiag_step_kernel(
 static long step_lds_elems(long n, long nw) { return 2 * n + 8 + nw * n; }
 
 // LDS elements of the final kernel for order n, p wanted pairs, LU batches of pb shifts
-static long big_lds_elems(long n, long p, long pb) { return 4 * n + 16 + BIG_MAXP + p * n + 5L * n * pb; }
+static long big_lds_elems(long n, long p, long pb) { (void)p; return 4 * n + 16 + BIG_MAXP + 6L * n * pb; }
 
 }  // namespace xk
 

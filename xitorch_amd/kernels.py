@@ -249,18 +249,19 @@ def small_eigh_tri_ok(k, p, dtype):
 
 
 SMALL_EIGH_BIG_MAX_K = 768
+SMALL_EIGH_BIG_MAX_P = 64
 
 
 def small_eigh_big_ok(k, p, dtype):
     """does the global-memory tridiagonalisation kernel (K3g) serve order k with p wanted pairs?"""
-    if k < 8 or k > SMALL_EIGH_BIG_MAX_K or p > SMALL_EIGH_MAX_P or p > k:
+    if k < 8 or k > SMALL_EIGH_BIG_MAX_K or p > SMALL_EIGH_BIG_MAX_P or p > k:
         return False
     return fn("xk_small_eigh_big_batch")(k, p, 8 if dtype == torch.float64 else 4) > 0
 
 
 def small_eigh_big(T, k, p, uppest=False):
     """K3g: lowest / uppermost p eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower triangle read) for
-    orders beyond the LDS-resident kernels (129 .. 768): lam (B, p) ascending, Y (B, p, k), failure flags (B,) int32
+    orders beyond the LDS-resident kernels (129 .. 768) or more than 16 wanted pairs (p <= 64, k >= 8): lam (B, p) ascending, Y (B, p, k), failure flags (B,) int32
     (nonzero -> redo with the library).  Replaces torch.linalg.eigh + _take_eigpairs (symeig.py:174-175) on the large
     bases of an un-restarted run."""
     require_device(T, "projected matrix")

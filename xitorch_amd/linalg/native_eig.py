@@ -146,10 +146,12 @@ class _Group:
             self._cscratch = torch.empty((n,), dtype=self.dtype, device=self.device)
         return self._cscratch
 
-    def cholqr(self, k0, q):
-        """Orthonormalise basis rows k0..k0+q among themselves (M-inner product if M)."""
+    def cholqr(self, k0, q, shifted=False):
+        """Orthonormalise basis rows k0..k0+q among themselves (M-inner product if M).  shifted: the first step of
+        shifted CholeskyQR (Gram matrix + 11 (N q + q (q + 1)) u trace(G) I, xk_chain.hip): leaves a well-conditioned,
+        not yet orthonormal panel; a plain pass follows."""
         N = self.N
-        if self.opM is None and self.fast:
+        if self.opM is None and self.fast and not shifted:
             K.davidson_orth(self.Vs, N, k0, q, self.scratch(q), self.Wflat, self.info, passes=0)
             return
         panel = self.Vs[:, k0:k0 + q]
@@ -158,6 +160,11 @@ class _Group:
         else:
             self.opM.apply(panel, self.MVs[:, k0:k0 + q])
             G = K.dense_mm(panel[:, :, :N], self.MVs[:, k0:k0 + q, :N])
+        if shifted:
+            u = 1.1102230246251565e-16 if self.dtype == torch.float64 else 5.9604644775390625e-08
+            sh = min(1e-3, 11.0 * (float(N) * q + float(q) * (q + 1)) * u)
+            tr = torch.diagonal(G, dim1=-2, dim2=-1).sum(-1)
+            G = G + (sh * tr)[:, None, None] * torch.eye(q, dtype=G.dtype, device=G.device)
         Wq = self.Wflat[:self.B * q * q].view(self.B, q, q)      # compact (B, q, q), as the C ABI expects
         K.panel_chol(G, Wq, self.info, q)
         K.panel_transform(panel, Wq, q)
@@ -247,9 +254,11 @@ class _Group:
                 sl = slice(0, p) if self.mode == "lowest" else slice(pk - p, pk)
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
-        elif self.small_eigh in ("native", "tri") and not force_jacobi and k > K.SMALL_EIGH_MAX_K and \
+        elif self.small_eigh in ("native", "tri") and not force_jacobi and \
+                (k > K.SMALL_EIGH_MAX_K or pk > K.SMALL_EIGH_MAX_P) and \
                 k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
-            # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra): the same
+            # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
+            # wanted pairs at any order (wide eigen-blocks, thick restarts that keep 2 neig > 16 vectors): the same
             # tridiagonalisation route with the matrix in global memory, one launch per Householder step over several
             # workgroups per matrix (2.4x rocSOLVER at order 582, 32 matrices; xk_eigh_big.hip); a flagged result is
             # redone on the library (the driver's force_jacobi re-run lands in the branch below)
@@ -262,7 +271,7 @@ class _Group:
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)
         else:
-            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 16 pairs, > 768
+            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 64 pairs, > 768
             if due:
                 lk, Yk = take_eigpairs(lam_all, Y_all, pk, self.mode)
                 self._compress = (Yk.transpose(1, 2).contiguous(), lk.contiguous())
@@ -339,9 +348,13 @@ class _Group:
             K.davidson_orth(self.Vs, self.N, k, nadd, self.scratch(nadd), self.Wflat, self.info,
                             passes=max(1, self.orth_passes))
         else:
-            for _ in range(max(1, self.orth_passes)):
+            # (the order of xk_davidson_orth: one pass = projection + CholeskyQR; more = [projection, CholeskyQR] per
+            #  pass with the first CholeskyQR shifted — robust for nearly dependent residual blocks)
+            rounds = max(1, self.orth_passes)
+            for it in range(rounds):
                 self.project_out(k, nadd)
-            self.cholqr(k, nadd)
+                if rounds >= 2 or it == rounds - 1:
+                    self.cholqr(k, nadd, shifted=(rounds >= 2 and it == 0))
         end()
         self._orth_done = True
 
