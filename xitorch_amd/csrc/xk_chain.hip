@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
 // shift_rel * trace(G) on its diagonal, which makes the factorisation safe for panels whose condition number squared
 // exceeds 1 / eps; the result is then only well-conditioned, not orthonormal — a plain pass follows.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int P>
+template <typename T, int P, bool SHIFT>
 __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, int* __restrict__ info, int N,
                                                             long ldt, long sT, T shift_rel) {
   // (N here is the panel length rounded up to whole 16 B vectors: the pad elements are zero by the panel contract)
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
   constexpr int NG = P * (P + 1) / 2;
   __shared__ T part[16][NG];
   __shared__ T Wsh[P][P];
+  __shared__ T G[P][P], R[P][P], col[P];
   const int b = blockIdx.x;
   T* Tb = Tp + (long)b * sT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,27 +167,76 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
     if (lane == 0) part[wave][i] = s;
   }
   __syncthreads();
-  if (tid == 0) {
-    T G[P][P], R[P][P];
+  if (!SHIFT && tid == 0) {
+    // plain CholeskyQR (every iteration of the default path): the 6 x 6 factorisation unrolled in registers
+    T Gr[P][P], Rr[P][P];
     int i = 0;
     for (int c = 0; c < P; ++c)
       for (int d = c; d < P; ++d, ++i) {
         T s = T(0);
+        for (int w = 0; w < 16; ++w) s += part[w][i];          // fixed order
+        Gr[c][d] = s;
+        Gr[d][c] = s;
+      }
+    int bad = 0;
+    for (int r = 0; r < P; ++r)
+      for (int c = 0; c < P; ++c) Rr[r][c] = T(0);
+    for (int j = 0; j < P; ++j)
+      for (int r = 0; r <= j; ++r) {
+        T s = Gr[r][j];
+        for (int m = 0; m < r; ++m) s -= Rr[m][r] * Rr[m][j];
+        if (r == j) {
+          if (!(s > T(0))) { if (!bad) bad = j + 1; s = T(1); }
+          Rr[j][j] = sqrt(s);
+        } else {
+          Rr[r][j] = s / Rr[r][r];
+        }
+      }
+    // W = R^-1 (upper triangular), column by column: R W = I
+    for (int c = 0; c < P; ++c) {
+      T colr[P];
+      for (int r = P - 1; r >= 0; --r) {
+        T s = (r == c) ? T(1) : T(0);
+        for (int m = r + 1; m <= c; ++m) s -= Rr[r][m] * colr[m];
+        colr[r] = (r <= c) ? s / Rr[r][r] : T(0);
+      }
+      for (int r = 0; r < P; ++r) Wsh[r][c] = colr[r];
+    }
+    if (bad) info[b] = bad;
+  }
+  if (SHIFT && tid == 0) {
+    // shifted variant (re-orthogonalised passes only): G, R, col in LDS and rolled loops — with the shift in the
+    // register version above the 1024-thread kernel's 128-VGPR budget spilled 554 registers at P = 6 (35 -> 75 us for
+    // EVERY call); this one costs 58 us where it runs
+    int i = 0;
+#pragma unroll 1
+    for (int c = 0; c < P; ++c)
+#pragma unroll 1
+      for (int d = c; d < P; ++d, ++i) {
+        T s = T(0);
+#pragma unroll 1
         for (int w = 0; w < 16; ++w) s += part[w][i];          // fixed order
         G[c][d] = s;
         G[d][c] = s;
       }
     if (shift_rel > T(0)) {                                    // shifted CholeskyQR: G + (shift_rel trace G) I
       T tr = T(0);
+#pragma unroll 1
       for (int c = 0; c < P; ++c) tr += G[c][c];
+#pragma unroll 1
       for (int c = 0; c < P; ++c) G[c][c] += shift_rel * tr;
     }
     int bad = 0;
+#pragma unroll 1
     for (int r = 0; r < P; ++r)
+#pragma unroll 1
       for (int c = 0; c < P; ++c) R[r][c] = T(0);
+#pragma unroll 1
     for (int j = 0; j < P; ++j)
+#pragma unroll 1
       for (int r = 0; r <= j; ++r) {
         T s = G[r][j];
+#pragma unroll 1
         for (int m = 0; m < r; ++m) s -= R[m][r] * R[m][j];
         if (r == j) {
           if (!(s > T(0))) { if (!bad) bad = j + 1; s = T(1); }
@@ -196,13 +246,16 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
         }
       }
     // W = R^-1 (upper triangular), column by column: R W = I
+#pragma unroll 1
     for (int c = 0; c < P; ++c) {
-      T col[P];
+#pragma unroll 1
       for (int r = P - 1; r >= 0; --r) {
         T s = (r == c) ? T(1) : T(0);
+#pragma unroll 1
         for (int m = r + 1; m <= c; ++m) s -= R[r][m] * col[m];
         col[r] = (r <= c) ? s / R[r][r] : T(0);
       }
+#pragma unroll 1
       for (int r = 0; r < P; ++r) Wsh[r][c] = col[r];
     }
     if (bad) info[b] = bad;
@@ -261,8 +314,12 @@ static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT
   switch (P) {
 #define XK_CASE(PP)                                                                                        \
   case PP:                                                                                                 \
-    hipLaunchKernelGGL((panel_cholqr_kernel<T, PP>), dim3(B), dim3(1024), 0, st, Tp, info, N, ldt, sT,   \
-                       shift_rel);                                                                         \
+    if (shift_rel > T(0))                                                                                  \
+      hipLaunchKernelGGL((panel_cholqr_kernel<T, PP, true>), dim3(B), dim3(1024), 0, st, Tp, info, N, ldt, \
+                         sT, shift_rel);                                                                   \
+    else                                                                                                   \
+      hipLaunchKernelGGL((panel_cholqr_kernel<T, PP, false>), dim3(B), dim3(1024), 0, st, Tp, info, N,     \
+                         ldt, sT, shift_rel);                                                              \
     break;
     XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
 #undef XK_CASE
