@@ -82,6 +82,17 @@ static inline int transform_c(float* Tp, const float* W, int B, int P, int N, lo
   return xk_panel_transform_f32(Tp, W, B, P, N, ldt, sT, st);
 }
 
+// a value every lane of the wave holds identically, moved to scalar registers (the 21 inverse-factor entries of the
+// fused CholeskyQR otherwise sit in VGPRs across its panel loop: with them the fp32 kernel spilled at 128 VGPRs)
+__device__ __forceinline__ float chain_uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ double chain_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b]} as doubles, then rmax <- 0 for the next
 // Rayleigh-Ritz step (the residual kernel folds into it with an order-independent atomic max).  One wave.
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
       for (int v = 0; v < VN; ++v) acc[v] = T(0);
 #pragma unroll
       for (int a = 0; a <= c; ++a) {
-        const T w = Wsh[a][c];
+        const T w = chain_uniform(Wsh[a][c]);                   // the same for every lane: lives in SGPRs
 #pragma unroll
         for (int v = 0; v < VN; ++v) acc[v] += w * t[a][v];
       }
