@@ -31,5 +31,7 @@ timeout 900 python scripts/bench_configs.py c3 c3g c4 c5 c5w 2>$O/configs.err > 
 timeout 300 python scripts/bench_configs.py c2:S2:96 2>>$O/configs.err >> $O/r03_secondary_configs.jsonl
 timeout 300 python scripts/bench_configs.py c2:S2:0 2>>$O/configs.err >> $O/r03_secondary_configs.jsonl
 cut -c1-400 $O/r03_secondary_configs.jsonl
+timeout 300 python scripts/k3m_sweep.py quick 2>/dev/null > $O/r03_k3m_sweep_quick.jsonl
+tail -3 $O/r03_k3m_sweep_quick.jsonl | cut -c1-200
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-general-extra 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('torchrun n=1', round(d['ms_per_step'],2), d['n_gpus'], d['config'].get('comm_backend'))"
 XITORCH_BENCH_FORCE_PG=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-general-extra 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('force_pg', round(d['ms_per_step'],2), d['config'].get('comm_backend'), d['config'].get('comm_world_size'))"
