@@ -308,29 +308,32 @@ int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long 
  * The stages between two operator-panel products are two to eight small launches each; issued from C++ they cost a
  * few microseconds of host time instead of an interpreter round trip per launch (what bounds small per-GPU batches).
  * xk_davidson_ritz: xk_ritz_residual + the group status {max_b rmax (NaN-propagating), max_b info, max_b flag} as
- *   three doubles; rmax is left zeroed for the next step (symeig.py:178-197).  flag may be NULL.
+ *   three doubles (+ a fourth, max_b cond, when cond is given; cond is re-zeroed); rmax is left zeroed for the next
+ *   step (symeig.py:178-197).  flag and cond may be NULL.
  * xk_davidson_orth: rows [k0, k0+q) of the basis V (B, cap, ldv) against rows [0, k0): block Gram-Schmidt
  *   (C[b,c,a] = <V_a, t_c>, t_c -= sum_a C V_a) and CholeskyQR of the q rows — for q <= 8 in ONE kernel (Gram,
  *   Cholesky, inverse, transform; one workgroup per batch member) — i.e. tallqr of [V, t] restricted to the new block
  *   (_utils/tensor.py:8-19, symeig.py:207-220).  passes = 0: CholeskyQR only; 1: projection, CholeskyQR; >= 2:
  *   [projection, CholeskyQR] per pass with the FIRST CholeskyQR shifted (Gram + 11 (N q + q (q + 1)) u trace I): the
- *   order that keeps nearly dependent panels (Gram spectrum over 15 decades) positive definite and orthogonal to V.  C: scratch >= B*q*max(k0,q), W: scratch B*q*q, info[b] sticky
+ *   order that keeps nearly dependent panels (Gram spectrum over 15 decades) positive definite and orthogonal to V.
+ *   cond (B, may be NULL; q <= 8 only): cond[b] = max(cond[b], (largest / smallest pivot)^2 of the raw panel's
+ *   CholeskyQR) — the squared condition estimate by which the Davidson driver decides when ONE pass stops being safe.  C: scratch >= B*q*max(k0,q), W: scratch B*q*q, info[b] sticky
  *   index+1 of a non-positive pivot, ws: xk_dense_mm_workspace_elems(B, cap, N, q, 0).  Any q: panels wider than
  *   32 are taken 32 rows at a time, each chunk against everything before it (twice), then among itself.
  * xk_davidson_extend_t: Tn[b,c,a] = <V_a, (AV)_{k0+c}> for a < k0+q, written to T[b, k0+c, a] and mirrored to
  *   T[b, a, k0+c] (symeig.py:170 restricted to the new rows / columns).  Tn: scratch >= B*q*(k0+q). */
 int xk_davidson_ritz_f64(const double* V, const double* AV, const double* Y, const double* lam, double* X, double* Tn,
-                         double* rmax, const int* info, const int* flag, double* status, int B, int k, int N, int P,
-                         long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam, long ldx,
-                         long sX, long ldt, long sT, void* stream);
+                         double* rmax, const int* info, const int* flag, double* cond, double* status, int B, int k,
+                         int N, int P, long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam,
+                         long ldx, long sX, long ldt, long sT, void* stream);
 int xk_davidson_ritz_f32(const float* V, const float* AV, const float* Y, const float* lam, float* X, float* Tn,
-                         float* rmax, const int* info, const int* flag, double* status, int B, int k, int N, int P,
-                         long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam, long ldx,
+                         float* rmax, const int* info, const int* flag, float* cond, double* status, int B, int k,
+                         int N, int P, long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam, long ldx,
                          long sX, long ldt, long sT, void* stream);
 int xk_davidson_orth_f64(double* V, int B, int N, int k0, int q, long ldv, long sV, double* C, double* W, int* info,
-                         double* ws, long ws_elems, int passes, void* stream);
+                         double* cond, double* ws, long ws_elems, int passes, void* stream);
 int xk_davidson_orth_f32(float* V, int B, int N, int k0, int q, long ldv, long sV, float* C, float* W, int* info,
-                         float* ws, long ws_elems, int passes, void* stream);
+                         float* cond, float* ws, long ws_elems, int passes, void* stream);
 int xk_davidson_extend_t_f64(const double* V, const double* AV, double* T, double* Tn, int B, int N, int k0, int q,
                              long ldv, long sV, long ldav, long sAV, long ldt, long sT, double* ws, long ws_elems,
                              void* stream);

@@ -19,7 +19,7 @@ variants = [dict(extra)]
 if "," in str(extra.get("chain", "")):
     variants = [dict(v, chain=c) for v in variants for c in str(extra["chain"]).split(",")]
 if "," in str(extra.get("orth_passes", "")):
-    variants = [dict(v, orth_passes=int(g)) for v in variants for g in str(extra["orth_passes"]).split(",")]
+    variants = [dict(v, orth_passes=(g if g == "auto" else int(g))) for v in variants for g in str(extra["orth_passes"]).split(",")]
 if "," in str(extra.get("groups", "")):
     variants = [dict(v, groups=int(g)) for v in variants for g in str(extra["groups"]).split(",")]
 N, p = 16384, 6
@@ -46,7 +46,7 @@ for opts in variants:
                 davidson(A, p, "lowest", min_eps=1e-8, rng_device="device", overlap=overlap, **opts)
             torch.cuda.synchronize(); ws.append((time.perf_counter() - t0) * 1e3)
         print(json.dumps({"B": B, "opts": {k: str(v) for k, v in opts.items()}, "overlap": overlap,
-                          "groups": tr["groups"], "niter": tr["niter"], "wall_traced_ms": round(wall, 2),
+                          "groups": tr["groups"], "niter": tr["niter"], "orth_two_pass_from": tr.get("orth_two_pass_from"), "wall_traced_ms": round(wall, 2),
                           "wall_ms": [round(w, 2) for w in ws],
                           "phase_total_ms": {k: round(sum(v), 2) for k, v in tot.items()},
                           "phase_calls": {k: len(v) for k, v in tot.items()},

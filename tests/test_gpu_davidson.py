@@ -1,6 +1,7 @@
 """-m gpu: native HIP Davidson vs (a) the oracle on the same inputs, (b) the reference's golden outputs."""
 import os
 import numpy as np
+import warnings
 import pytest
 import torch
 from oracle import ops as oops, symeig as osym
@@ -381,24 +382,27 @@ def test_chain_calls_match_kernel_by_kernel(dev):
         mat = synthetic.dense_symmetric(B, N, "S1", dtype=dtype, device=dev)
         A = xa.LinearOperator.m(mat, is_hermitian=True)
         eps = 1e-8 if dtype == torch.float64 else 1e-3
-        # default (one projection pass + CholeskyQR) and the re-orthogonalised order ([projection, CholeskyQR] twice,
-        # the first CholeskyQR shifted), which the host loop mirrors with its own Gram shift
-        for extra in ({}, {"orth_passes": 2}):
-            if extra and p > 8:
-                # (the 10-column case is where converged pairs' noise residuals decide the path: 48 iterations with one
-                #  pass, 62-63 with two or three, in every version of the code; any rounding-level difference between
-                #  the two hosts' shift arithmetic — a kernel there, torch here — diverges within 16 iterations)
-                continue
+        # one projection pass + CholeskyQR, and the re-orthogonalised order ([projection, CholeskyQR] twice, the first
+        # CholeskyQR shifted), which the host loop mirrors with its own Gram shift
+        for extra in ({"orth_passes": 1}, {"orth_passes": 2}):
+            if p > 8:
+                # (10 columns: converged pairs' noise residuals decide the path — one pass breaks down after ~30
+                #  iterations, see test_default_orthonormalisation_survives_mixed_convergence, and with two any
+                #  rounding-level difference between the two hosts' shift arithmetic, a kernel there and torch here,
+                #  diverges within 16 iterations: the wide-panel kernels are compared over the first 14)
+                extra = dict(extra, max_niter=14)
             out = {}
             for chain in ("calls", "kernels"):
                 tr = {}
-                ev, X = davidson(A, p, "lowest", min_eps=eps, chain=chain, trace=tr, **extra)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    ev, X = davidson(A, p, "lowest", min_eps=eps, chain=chain, trace=tr, **extra)
                 out[chain] = (ev.double().cpu(), tr)
             (e1, t1), (e2, t2) = out["calls"], out["kernels"]
             # (the shifted pass adds its shift in torch on one side and in the kernel on the other: the rounding-level
             #  difference may move a stopping test that sits at the threshold by one iteration; the residual histories
             #  must agree over the common part)
-            slack = 1 if extra else 0
+            slack = 1 if extra.get("orth_passes") == 2 else 0
             assert abs(t1["niter"] - t2["niter"]) <= slack, (extra, t1["niter"], t2["niter"])
             assert (e1 - e2).abs().max().item() <= tol * max(1.0, e2.abs().max().item())
             m = min(len(t1["resid_history"]), len(t2["resid_history"]))
@@ -536,8 +540,8 @@ def test_wide_blocks_and_restart_beyond_16(dev, neig, nguess, mode, restart, mon
 
 
 def test_one_gram_schmidt_pass_equals_two(dev):
-    """orth_passes='auto' takes ONE pass of the new residual block against the basis (a Ritz residual is orthogonal
-    to it up to rounding); the iteration must be the one two passes give: same count, same eigenvalues, same residual
+    """On short, well-conditioned runs ONE projection pass of the new residual block (orth_passes=1, opt-in since the
+    wide-block failure below) gives the iteration of the default two: same count, same eigenvalues, same residual
     history to rounding, and an orthonormal result — on the clustered and on the slowly converging spectrum, fp64 and
     fp32."""
     from xitorch_amd import synthetic
@@ -578,3 +582,32 @@ def test_unrestarted_run_beyond_128_vectors_stays_native(dev, monkeypatch):
     exact = synthetic.spectrum("S2", N, device=dev)[:p]
     assert (ev - exact).abs().max().item() <= 1e-10
     assert (mat @ X - X * ev.unsqueeze(-2)).abs().max().item() <= 1e-7
+
+
+@pytest.mark.parametrize("N,p", [(900, 8), (900, 10), (2048, 12)])
+def test_default_orthonormalisation_survives_mixed_convergence(dev, N, p):
+    """Regression (round 3): with some wanted pairs long converged and others (inside the dense part of the S1
+    spectrum) still far, the residual block's condition number reaches 1e7 and more; ONE projection + CholeskyQR then
+    lost the basis' orthogonality after ~30 iterations and the run stopped on DUPLICATED eigenpairs (eigenvalue error
+    50, residual < min_eps).  The default ([projection, shifted CholeskyQR] + [projection, CholeskyQR]) must return
+    the exact lowest pairs, orthonormal, in about the reference's number of iterations (oracle on the host)."""
+    from xitorch_amd import synthetic
+    from oracle import ops as oops, symeig as osym
+    B = 2
+    mat = synthetic.dense_symmetric(B, N, "S1", dtype=torch.float64, device=dev)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    exact = torch.linalg.eigvalsh(mat)[:, :p]
+    tr = {}
+    ev, X = davidson(A, p, "lowest", min_eps=1e-8, trace=tr)
+    assert tr["stop_reason"] == "converged"
+    assert tr["orth_adaptive"]
+    if p <= 8:       # blocks of up to 8 start on one pass and must have been moved to two by the condition estimate
+        assert all(t is not None and t < tr["niter"] - 5 for t in tr["orth_two_pass_from"]), tr["orth_two_pass_from"]
+    assert (ev - exact).abs().max().item() <= 1e-10 * exact.abs().max().item()
+    G = X.transpose(1, 2) @ X
+    assert (G - torch.eye(p, dtype=torch.float64, device=dev)).abs().max().item() <= 1e-10
+    assert (mat @ X - X * ev[:, None, :]).abs().max().item() <= 1e-7
+    if N <= 900:
+        tro = {}
+        osym.davidson(oops.DenseOp(mat.cpu(), True), p, "lowest", min_eps=1e-8, trace=tro)
+        assert abs(tr["niter"] - tro["niter"]) <= max(3, tro["niter"] // 10), (tr["niter"], tro["niter"])

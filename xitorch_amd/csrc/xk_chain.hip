@@ -94,20 +94,26 @@ __device__ __forceinline__ double chain_uniform(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b]} as doubles, then rmax <- 0 for the next
+// status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b], max_b cond[b] (only with cond)} as doubles,
+// cond <- 0, then rmax <- 0 for the next
 // Rayleigh-Ritz step (the residual kernel folds into it with an order-independent atomic max).  One wave.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__ rmax, const int* __restrict__ info,
-                                                                 const int* __restrict__ flag,
+                                                                 const int* __restrict__ flag, T* __restrict__ cond,
                                                                  double* __restrict__ status, int B) {
   const int lane = threadIdx.x;
-  double m = 0.0;
+  double m = 0.0, cm = 0.0;
   int nan = 0, i1 = 0, i2 = 0;
   bool first = true;
   for (int b = lane; b < B; b += 64) {
     const double v = (double)rmax[b];
     rmax[b] = T(0);
+    if (cond) {                                              // worst pivot ratio of the panels orthonormalised since the
+      const double cv = (double)cond[b];                     // last status (NaN counts as infinite), re-zeroed
+      cond[b] = T(0);
+      cm = (cv != cv) ? __builtin_inf() : (cv > cm ? cv : cm);
+    }
     nan |= (v != v);
     m = first ? v : (v > m ? v : m);
     const int a = info[b];
@@ -122,9 +128,10 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
   int a1 = first ? -2147483647 - 1 : i1, a2 = first ? -2147483647 - 1 : i2;
 #pragma unroll
   for (int sft = 32; sft >= 1; sft >>= 1) {
-    const double om = __shfl_xor(mm, sft, 64);
+    const double om = __shfl_xor(mm, sft, 64), oc = __shfl_xor(cm, sft, 64);
     const int o1 = __shfl_xor(a1, sft, 64), o2 = __shfl_xor(a2, sft, 64), on = __shfl_xor(nan, sft, 64);
     mm = om > mm ? om : mm;
+    cm = oc > cm ? oc : cm;
     a1 = o1 > a1 ? o1 : a1;
     a2 = o2 > a2 ? o2 : a2;
     nan |= on;
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
     status[0] = nan ? __builtin_nan("") : mm;
     status[1] = (double)a1;
     status[2] = flag ? (double)a2 : 0.0;
+    if (cond) status[3] = cm;
   }
 }
 
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
 // ---------------------------------------------------------------------------------------------
 template <typename T, int P, bool SHIFT>
 __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, int* __restrict__ info, int N,
-                                                            long ldt, long sT, T shift_rel) {
+                                                            long ldt, long sT, T shift_rel, T* __restrict__ cond) {
   // (N here is the panel length rounded up to whole 16 B vectors: the pad elements are zero by the panel contract)
   typedef typename Vec16<T>::type VT;
   constexpr int VN = Vec16<T>::n;
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
         Gr[d][c] = s;
       }
     int bad = 0;
+    T pmax = T(0), pmin = T(0);                                // largest / smallest squared pivot
     for (int r = 0; r < P; ++r)
       for (int c = 0; c < P; ++c) Rr[r][c] = T(0);
     for (int j = 0; j < P; ++j)
@@ -198,6 +207,8 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
         for (int m = 0; m < r; ++m) s -= Rr[m][r] * Rr[m][j];
         if (r == j) {
           if (!(s > T(0))) { if (!bad) bad = j + 1; s = T(1); }
+          pmax = j == 0 ? s : (s > pmax ? s : pmax);
+          pmin = j == 0 ? s : (s < pmin ? s : pmin);
           Rr[j][j] = sqrt(s);
         } else {
           Rr[r][j] = s / Rr[r][r];
@@ -214,6 +225,11 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
       for (int r = 0; r < P; ++r) Wsh[r][c] = colr[r];
     }
     if (bad) info[b] = bad;
+    if (cond) {                                                // (pivot ratio)^2 ~ condition number of the panel, squared
+      const T ratio = bad ? T(INFINITY) : pmax / pmin;
+      const T old = cond[b];
+      cond[b] = (ratio > old || ratio != ratio) ? ratio : old;
+    }
   }
   if (SHIFT && tid == 0) {
     // shifted variant (re-orthogonalised passes only): G, R, col in LDS and rolled loops — with the shift in the
@@ -238,6 +254,7 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
       for (int c = 0; c < P; ++c) G[c][c] += shift_rel * tr;
     }
     int bad = 0;
+    T pmax = T(0), pmin = T(0);
 #pragma unroll 1
     for (int r = 0; r < P; ++r)
 #pragma unroll 1
@@ -251,6 +268,8 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
         for (int m = 0; m < r; ++m) s -= R[m][r] * R[m][j];
         if (r == j) {
           if (!(s > T(0))) { if (!bad) bad = j + 1; s = T(1); }
+          pmax = j == 0 ? s : (s > pmax ? s : pmax);
+          pmin = j == 0 ? s : (s < pmin ? s : pmin);
           R[j][j] = sqrt(s);
         } else {
           R[r][j] = s / R[r][r];
@@ -270,6 +289,11 @@ __global__ __launch_bounds__(1024) void panel_cholqr_kernel(T* __restrict__ Tp, 
       for (int r = 0; r < P; ++r) Wsh[r][c] = col[r];
     }
     if (bad) info[b] = bad;
+    if (cond) {
+      const T ratio = bad ? T(INFINITY) : pmax / pmin;
+      const T old = cond[b];
+      cond[b] = (ratio > old || ratio != ratio) ? ratio : old;
+    }
   }
   __syncthreads();
   for (int j = tid * VN; j < N; j += 1024 * VN) {
@@ -321,16 +345,17 @@ __global__ __launch_bounds__(64) void gram_shift_kernel(T* __restrict__ G, int B
 }
 
 template <typename T>
-static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT, T shift_rel, hipStream_t st) {
+static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT, T shift_rel, T* cond,
+                        hipStream_t st) {
   switch (P) {
 #define XK_CASE(PP)                                                                                        \
   case PP:                                                                                                 \
     if (shift_rel > T(0))                                                                                  \
       hipLaunchKernelGGL((panel_cholqr_kernel<T, PP, true>), dim3(B), dim3(1024), 0, st, Tp, info, N, ldt, \
-                         sT, shift_rel);                                                                   \
+                         sT, shift_rel, cond);                                                             \
     else                                                                                                   \
       hipLaunchKernelGGL((panel_cholqr_kernel<T, PP, false>), dim3(B), dim3(1024), 0, st, Tp, info, N,     \
-                         ldt, sT, shift_rel);                                                              \
+                         ldt, sT, shift_rel, cond);                                                        \
     break;
     XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
 #undef XK_CASE
@@ -343,10 +368,11 @@ static int cholqr_fused(T* Tp, int* info, int B, int P, int N, long ldt, long sT
 // CholeskyQR of panel rows [k0, k0 + q) (q <= 32), optionally shifted
 template <typename T>
 static int panel_cholqr(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
-                        long ws_elems, T shift_rel, void* stream) {
+                        long ws_elems, T shift_rel, T* cond, void* stream) {
   constexpr int VN = Vec16<T>::n;
   T* panel = V + (long)k0 * ldv;
-  if (q <= 8) return cholqr_fused<T>(panel, info, B, q, (N + VN - 1) / VN * VN, ldv, sV, shift_rel, (hipStream_t)stream);
+  if (q <= 8)
+    return cholqr_fused<T>(panel, info, B, q, (N + VN - 1) / VN * VN, ldv, sV, shift_rel, cond, (hipStream_t)stream);
   // wider panels: Gram on K1, Cholesky + inverse per member, transform
   T* G = C;                                               // (B, q, q) fits: the caller sizes C for q * max(k0, q)
   int rc = dense_mm(panel, panel, G, ws, ws_elems, B, q, N, q, ldv, sV, ldv, sV, (long)q, (long)q * q, stream);
@@ -368,7 +394,7 @@ static int panel_cholqr(T* V, int B, int N, int k0, int q, long ldv, long sV, T*
 // through R^-1 the orthogonality against the basis that the projections before it had established.
 template <typename T>
 static int davidson_orth_block(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
-                               long ws_elems, int passes, void* stream) {
+                               long ws_elems, int passes, T* cond, void* stream) {
   T* panel = V + (long)k0 * ldv;
   const double u = sizeof(T) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-08;
   double sh = 11.0 * ((double)N * q + (double)q * (q + 1)) * u;
@@ -384,7 +410,8 @@ static int davidson_orth_block(T* V, int B, int N, int k0, int q, long ldv, long
       if (rc != XK_OK) return rc;
     }
     const T shift = (rounds >= 2 && it == 0) ? (T)sh : T(0);
-    rc = panel_cholqr<T>(V, B, N, k0, q, ldv, sV, C, W, info, ws, ws_elems, shift, stream);
+    // (the pivot ratio is reported for the raw panel only: the first CholeskyQR of the call)
+    rc = panel_cholqr<T>(V, B, N, k0, q, ldv, sV, C, W, info, ws, ws_elems, shift, it == 0 ? cond : (T*)nullptr, stream);
     if (rc != XK_OK) return rc;
   }
   return XK_OK;
@@ -397,13 +424,13 @@ static int davidson_orth_block(T* V, int B, int N, int k0, int q, long ldv, long
 // no width limit (tallqr, _utils/tensor.py:8-19; symeig.py:100-140 for any neig / nguess).
 template <typename T>
 static int davidson_orth(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,
-                         long ws_elems, int passes, void* stream) {
+                         long ws_elems, int passes, T* cond, void* stream) {
   constexpr int VN = Vec16<T>::n;
   if ((ldv % VN) || (sV % VN) || ((uintptr_t)V & 15) || ldv < (long)((N + VN - 1) / VN) * VN) return XK_ERR_UNSUPPORTED;
   for (int off = 0; off < q; off += 32) {
     const int qc = q - off < 32 ? q - off : 32;
     const int np = off == 0 ? passes : (passes > 2 ? passes : 2);
-    const int rc = davidson_orth_block<T>(V, B, N, k0 + off, qc, ldv, sV, C, W, info, ws, ws_elems, np, stream);
+    const int rc = davidson_orth_block<T>(V, B, N, k0 + off, qc, ldv, sV, C, W, info, ws, ws_elems, np, cond, stream);
     if (rc != XK_OK) return rc;
   }
   return XK_OK;
@@ -430,7 +457,8 @@ extern "C" {
 
 #define XK_DEFINE_CHAIN(SUF, T)                                                                                    \
   int xk_davidson_ritz_##SUF(const T* V, const T* AV, const T* Y, const T* lam, T* X, T* Tn, T* rmax,              \
-                             const int* info, const int* flag, double* status, int B, int k, int N, int P,         \
+                             const int* info, const int* flag, T* cond, double* status, int B, int k, int N,       \
+                             int P,                                                                                \
                              long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam,       \
                              long ldx, long sX, long ldt, long sT, void* stream) {                                 \
     if (B <= 0 || k <= 0 || N <= 0 || P <= 0 || !rmax || !info || !status) return XK_ERR_ARG;                      \
@@ -438,15 +466,15 @@ extern "C" {
                         ldt, sT, stream);                                                                          \
     if (rc != XK_OK) return rc;                                                                                    \
     hipLaunchKernelGGL((xk::group_status_rezero_kernel<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, rmax, info,  \
-                       flag, status, B);                                                                           \
+                       flag, cond, status, B);                                                                     \
     XK_LAUNCH_CHECK();                                                                                             \
     return XK_OK;                                                                                                  \
   }                                                                                                                \
-  int xk_davidson_orth_##SUF(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info, T* ws,   \
-                             long ws_elems, int passes, void* stream) {                                            \
+  int xk_davidson_orth_##SUF(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info,          \
+                             T* cond, T* ws, long ws_elems, int passes, void* stream) {                            \
     if (B < 0 || N <= 0 || k0 < 0 || q <= 0 || passes < 0) return XK_ERR_ARG;                            \
     if (B == 0) return XK_OK;                                                                                      \
-    return xk::davidson_orth<T>(V, B, N, k0, q, ldv, sV, C, W, info, ws, ws_elems, passes, stream);                \
+    return xk::davidson_orth<T>(V, B, N, k0, q, ldv, sV, C, W, info, ws, ws_elems, passes, cond, stream);          \
   }                                                                                                                \
   int xk_davidson_extend_t_##SUF(const T* V, const T* AV, T* Tm, T* Tn, int B, int N, int k0, int q, long ldv,     \
                                  long sV, long ldav, long sAV, long ldt, long sT, T* ws, long ws_elems,            \

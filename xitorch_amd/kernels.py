@@ -189,17 +189,17 @@ def panel_transform(Tp, W, P):
 
 
 # --------------------------------------------------------------------------- Davidson chain (one C call per stage)
-def davidson_ritz(V, AV, Y, lam, X, Tn, rmax, info, flag, status, k, P):
+def davidson_ritz(V, AV, Y, lam, X, Tn, rmax, info, flag, status, k, P, cond=None):
     """ritz_residual + group status in one C call (xk_davidson_ritz): X = Y^T V, Tn = -(Y^T AV - lam X),
-    status = {max|resid| (NaN-propagating), max info, max flag}; rmax is left zeroed for the next step
-    (symeig.py:178-197)."""
+    status = {max|resid| (NaN-propagating), max info, max flag[, max cond]}; rmax (and cond) are left zeroed for the
+    next step (symeig.py:178-197)."""
     B, N = V.shape[0], V.shape[2]
     if lam.stride(-1) != 1 and P > 1:
         raise _capi.NativeLibraryError("lam must have unit stride along its last dim")
     _check_ritz_shapes(V, AV, Y, lam, X, Tn, k, P)
     rc = fn("xk_davidson_ritz_" + suffix(V.dtype))(
         ptr(V), ptr(AV), ptr(Y), ptr(lam), ptr(X), ptr(Tn), ptr(rmax), ptr(info), ptr(flag) if flag is not None else None,
-        ptr(status), B, k, N, P, V.stride(1), V.stride(0), AV.stride(1), AV.stride(0), Y.stride(0), Y.stride(1),
+        ptr(cond) if cond is not None else None, ptr(status), B, k, N, P, V.stride(1), V.stride(0), AV.stride(1), AV.stride(0), Y.stride(0), Y.stride(1),
         Y.stride(2), lam.stride(0), X.stride(1), X.stride(0), Tn.stride(1), Tn.stride(0), stream_ptr())
     check(rc, "xk_davidson_ritz")
 
@@ -210,14 +210,17 @@ def davidson_ws(B, cap, N, q, dtype, device):
     return _workspace(max(nws, 1), dtype, device), nws
 
 
-def davidson_orth(V, N, k0, q, C, W, info, passes=2):
+def davidson_orth(V, N, k0, q, C, W, info, passes=2, cond=None):
     """Rows [k0, k0+q) of the basis V (B, cap, ld) are orthogonalised against rows [0, k0) (`passes` rounds of block
     Gram-Schmidt) and orthonormalised among themselves (CholeskyQR) — tallqr of [V, t] restricted to the new block
-    (_utils/tensor.py:8-19, symeig.py:207-220) — in one C call.  C: scratch of >= B*q*max(k0,q) elements, W: B*q*q."""
+    (_utils/tensor.py:8-19, symeig.py:207-220) — in one C call.  C: scratch of >= B*q*max(k0,q) elements, W: B*q*q.
+    passes >= 2: [projection, CholeskyQR] per pass, the first CholeskyQR shifted.  cond (B,), optional, q <= 8: receives
+    max(cond, squared pivot ratio of the raw panel)."""
     B = V.shape[0]
     ws, nws = davidson_ws(B, V.shape[1], N, q, V.dtype, V.device)
     rc = fn("xk_davidson_orth_" + suffix(V.dtype))(ptr(V), B, N, k0, q, V.stride(1), V.stride(0), ptr(C), ptr(W),
-                                                    ptr(info), ptr(ws), nws, int(passes), stream_ptr())
+                                                    ptr(info), ptr(cond) if cond is not None else None, ptr(ws), nws,
+                                                    int(passes), stream_ptr())
     check(rc, "xk_davidson_orth")
 
 

@@ -116,7 +116,12 @@ class _Group:
         self.Wflat = torch.empty((B * 32 * 32,), dtype=dtype, device=device)
         self._cscratch = None                     # coefficient scratch of the one-call chain stages, B * p * cap
         self.info = torch.zeros((B,), dtype=torch.int32, device=device)
-        self.status = torch.zeros((3,), dtype=torch.float64, device=device)   # max|resid|, chol flag, K3t self-check flag
+        # max|resid|, chol flag, K3t self-check flag, squared pivot ratio of the last orthonormalised panel(s)
+        self.status = torch.zeros((4,), dtype=torch.float64, device=device)
+        self.cond = torch.zeros((B,), dtype=dtype, device=device)
+        self.adaptive = False                     # orth_passes="auto": one pass until a panel's condition estimate says no
+        self.passes_now = 2                       # (the first panel is orthonormalised with two)
+        self.two_pass_from = None
         self.rmax = z(B)
         self.Xbuf = [z(B, p, Npad), z(B, p, Npad)]
         self.k = 0
@@ -292,7 +297,7 @@ class _Group:
         if fused_status:
             # rotation + residual + status in one C call; rmax comes back zeroed for the next step
             K.davidson_ritz(self.Vs, self.AVs, Y, lam, X, self.newpanel, self.rmax, self.info, tri_flag, self.status,
-                            k, p)
+                            k, p, cond=self.cond)
         elif self.opM is None:
             K.ritz_residual(self.Vs, self.AVs, Y, lam, X, self.newpanel, self.rmax, k, p)
         else:
@@ -346,17 +351,40 @@ class _Group:
         end = self._mark("orth")
         if self.fast and self.opM is None:
             K.davidson_orth(self.Vs, self.N, k, nadd, self.scratch(nadd), self.Wflat, self.info,
-                            passes=max(1, self.orth_passes))
+                            passes=self.current_passes(nadd), cond=self.cond)
         else:
             # (the order of xk_davidson_orth: one pass = projection + CholeskyQR; more = [projection, CholeskyQR] per
             #  pass with the first CholeskyQR shifted — robust for nearly dependent residual blocks)
-            rounds = max(1, self.orth_passes)
+            rounds = self.current_passes(nadd)
             for it in range(rounds):
                 self.project_out(k, nadd)
                 if rounds >= 2 or it == rounds - 1:
                     self.cholqr(k, nadd, shifted=(rounds >= 2 and it == 0))
         end()
         self._orth_done = True
+
+    # A panel whose squared pivot ratio (xk_davidson_orth's cond) is below this may be followed by ONE-pass panels: the
+    # estimate reaches the host two panels late (the next orthonormalisation is enqueued before the status is read) and
+    # residual norms spread by at most ~10x per iteration, so one pass never meets a condition number above ~1e4, i.e.
+    # an orthogonality loss above ~1e-12 per iteration.  Beyond it the run stays on two passes.
+    ONE_PASS_MAX_COND2 = 1e4
+
+    def current_passes(self, q):
+        """projection passes of the next panel orthonormalisation"""
+        if not self.adaptive:
+            return max(1, self.orth_passes)
+        if q > 8 or not (self.fast and self.opM is None and self.precond is None):
+            return 2                              # (no condition estimate on these paths)
+        return self.passes_now
+
+    def note_condition(self, cond2, it):
+        """the driver hands over status[3] after every status read"""
+        if self.adaptive and self.passes_now == 1 and not (cond2 <= self.ONE_PASS_MAX_COND2):
+            self.passes_now = 2
+            self.two_pass_from = it
+        elif self.adaptive and self.two_pass_from is None and self.passes_now == 2 and cond2 <= self.ONE_PASS_MAX_COND2 \
+                and it >= 1:
+            self.passes_now = 1                   # the start block and the first panel were benign: fast order
 
     def speculate_orth(self):
         """expand_orth ahead of the status read — unless the step is not repeatable afterwards (a pending thick
@@ -492,13 +520,19 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     V0: tensor or None
         (extension) start block ``(*batch, na, nguess)`` replacing the random draw
     orth_passes: int or str
-        (extension) Gram–Schmidt passes of the new panel against the basis.  ``"auto"`` (default): ONE pass when the
-        new directions are the negated residuals (no preconditioner) — a Ritz residual is orthogonal to the basis by
-        construction (``V^T (A X - X lam) = T Y - Y lam = 0``), what one pass removes is the rounding-sized component
-        that forming it left (measured <= 1e-6 of its norm), and "twice is enough" only matters when the first pass
-        cancels most of the vector; the reference does not re-orthogonalise at all (one CholeskyQR of ``[V, t]``,
-        symeig.py:207-220).  Two passes (CGS2) with a preconditioner, whose output has no such property, and with
-        ``restart=``.  An integer forces the number of passes
+        (extension) Gram–Schmidt passes of the new panel against the basis.  The reference re-orthonormalises the
+        WHOLE basis every iteration (one CholeskyQR of ``[V, t]``, symeig.py:207-220); restricted to the new block that
+        is one projection + one CholeskyQR, which is only safe while the residual block is well conditioned: the
+        inverse factor amplifies the rounding-sized basis components the projection left by the block's condition
+        number, and once some pairs have converged and others have not that number reaches 1e7 and more.  Measured
+        with ONE pass throughout (round 3's first default): S1 with neig = 8 .. 16 lost the basis' orthogonality after
+        ~30 iterations and returned duplicated eigenpairs (eigenvalue error 50) with a residual below ``min_eps``.
+        ``"auto"`` (default): two passes in the order [projection, shifted CholeskyQR, projection, CholeskyQR]
+        (xk_chain.hip) — except that blocks of up to 8 vectors take ONE pass while the fused CholeskyQR kernel's
+        condition estimate (squared pivot ratio, read with the iteration's status) stays below 1e4; the first panel
+        that exceeds it puts the rest of the run on two passes (``trace["orth_two_pass_from"]``).  With a
+        preconditioner, ``restart=``, ``M`` or ``chain="kernels"``: always two.  An integer forces the number of passes
+        (1 = one pass throughout; not checked).
     process_group: torch.distributed group or None
         (extension) when given, the batch is sharded over the group's ranks and the stopping test
         uses the all-reduced (MAX) residual, so all ranks iterate in lock step (RCCL over xGMI)
@@ -527,10 +561,9 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     if (nguess > 32 or p > 32) and M is not None:
         raise NativeLibraryError("neig / nguess > 32 with an overlap operator M is not supported by the native "
                                  "davidson (the chunked panel orthonormalisation serves M = None)")
+    adaptive = orth_passes == "auto" and precond is None and restart is None
     if orth_passes == "auto":
-        # (with thick restarts one pass proved marginal — a 20-pair run failed its panel Cholesky where two passes
-        # converge, r03 — so the restarted extension keeps CGS2)
-        orth_passes = 1 if (precond is None and restart is None) else 2
+        orth_passes = 2
     events = trace.get("k1_events") if trace is not None else None
 
     # ---- batch groups: one, or two pipelined on two streams ---------------------------------
@@ -613,6 +646,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
                          precond=_pc_slice(b0, b1), restart=restart)
             grp.k1_stream = k1_stream
+            grp.adaptive = adaptive
             # (panels wider than 32 need the chunked orthonormalisation of xk_davidson_orth)
             grp.fast = (chain != "kernels") or p > 32 or nguess > 32
             if trace is not None and "timeline" in trace:
@@ -625,7 +659,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     stop_reason = "max_niter"
     niter = 0
     distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
-    gstat = torch.zeros((3,), dtype=torch.float64, device=device) if distributed else None
+    gstat = torch.zeros((4,), dtype=torch.float64, device=device) if distributed else None
     n_fallback = [0]
     for it in range(max_niter):
         niter = it + 1
@@ -648,14 +682,15 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                     groups[g].small()
                     groups[g].speculate_orth()
             with torch.cuda.stream(streams[g]):
-                st_g, bad_g, tri_g = groups[g].status.tolist()        # host waits for THIS group's stream only
+                st_g, bad_g, tri_g, cond_g = groups[g].status.tolist()   # host waits for THIS group's stream only
                 if tri_g != 0:
                     # the tridiagonalisation kernel's self-check failed for some member: same step on Jacobi (the
                     # speculative orthonormalisation consumed its output: redo that too, it only touched rows >= k)
                     groups[g].small(force_jacobi=True)
                     groups[g].speculate_orth()
-                    st_g, bad_g, tri_g = groups[g].status.tolist()
+                    st_g, bad_g, tri_g, cond_g = groups[g].status.tolist()
                     n_fallback[0] += 1
+                groups[g].note_condition(cond_g, it)
             if st_g != st_g:
                 st_g = float("inf")
             local_max, bad = max(local_max, st_g), max(bad, bad_g)
@@ -675,7 +710,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                 # device, one all-reduce (MAX) over the ranks, one read
                 torch.amax(torch.stack([grp.status for grp in groups]), dim=0, out=gstat)
                 allreduce_max_(gstat, process_group)
-                max_resid, bad, _ = gstat.tolist()
+                max_resid, bad = gstat.tolist()[:2]
             if max_resid != max_resid:
                 max_resid = float("inf")
         if bad != 0:
@@ -714,7 +749,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     if trace is not None:
         trace.update(niter=niter, napply=sum(op.napply for op in ops) // G, resid_history=history,
                      basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G,
-                     k3_fallbacks=n_fallback[0], restarts=groups[0].nrestart, panel_kernel=ops[0].last_kernel)
+                     k3_fallbacks=n_fallback[0], restarts=groups[0].nrestart, panel_kernel=ops[0].last_kernel,
+                     orth_two_pass_from=[grp.two_pass_from for grp in groups], orth_adaptive=bool(adaptive))
     evals = evals.reshape(*bdims, p)
     evecs = Xall[:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
     return evals, evecs
