@@ -363,11 +363,13 @@ class _Group:
         end()
         self._orth_done = True
 
-    # A panel whose squared pivot ratio (xk_davidson_orth's cond) is below this may be followed by ONE-pass panels: the
-    # estimate reaches the host two panels late (the next orthonormalisation is enqueued before the status is read) and
-    # residual norms spread by at most ~10x per iteration, so one pass never meets a condition number above ~1e4, i.e.
-    # an orthogonality loss above ~1e-12 per iteration.  Beyond it the run stays on two passes.
-    ONE_PASS_MAX_COND2 = 1e4
+    # A panel whose squared pivot ratio (xk_davidson_orth's cond) is below this may be followed by ONE-pass panels.  The
+    # estimate reaches the host two panels late (the next orthonormalisation is enqueued before the status is read);
+    # measured growth where it grows at all (S1, neig = 8: pairs converge one after the other) is ~20x per iteration, so
+    # one pass never meets a squared condition number above ~4e5, i.e. an orthogonality loss above ~1e-13 per
+    # iteration.  Beyond it the run stays on two passes.  (The headline workload stays below 40, S1 at order 2048 below
+    # 800; scripts/orth_passes_scan.py.)
+    ONE_PASS_MAX_COND2 = 1e3
 
     def current_passes(self, q):
         """projection passes of the next panel orthonormalisation"""
@@ -529,7 +531,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         ~30 iterations and returned duplicated eigenpairs (eigenvalue error 50) with a residual below ``min_eps``.
         ``"auto"`` (default): two passes in the order [projection, shifted CholeskyQR, projection, CholeskyQR]
         (xk_chain.hip) — except that blocks of up to 8 vectors take ONE pass while the fused CholeskyQR kernel's
-        condition estimate (squared pivot ratio, read with the iteration's status) stays below 1e4; the first panel
+        condition estimate (squared pivot ratio, read with the iteration's status) stays below 1e3; the first panel
         that exceeds it puts the rest of the run on two passes (``trace["orth_two_pass_from"]``).  With a
         preconditioner, ``restart=``, ``M`` or ``chain="kernels"``: always two.  An integer forces the number of passes
         (1 = one pass throughout; not checked).
@@ -661,6 +663,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
     gstat = torch.zeros((4,), dtype=torch.float64, device=device) if distributed else None
     n_fallback = [0]
+    cond_hist = [[] for _ in range(G)]            # squared pivot ratio of each group's panels (status[3]), as read
     for it in range(max_niter):
         niter = it + 1
         local_max, bad = 0.0, 0.0
@@ -691,6 +694,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                     st_g, bad_g, tri_g, cond_g = groups[g].status.tolist()
                     n_fallback[0] += 1
                 groups[g].note_condition(cond_g, it)
+                cond_hist[g].append(cond_g)
             if st_g != st_g:
                 st_g = float("inf")
             local_max, bad = max(local_max, st_g), max(bad, bad_g)
@@ -750,7 +754,8 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         trace.update(niter=niter, napply=sum(op.napply for op in ops) // G, resid_history=history,
                      basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G,
                      k3_fallbacks=n_fallback[0], restarts=groups[0].nrestart, panel_kernel=ops[0].last_kernel,
-                     orth_two_pass_from=[grp.two_pass_from for grp in groups], orth_adaptive=bool(adaptive))
+                     orth_two_pass_from=[grp.two_pass_from for grp in groups], orth_adaptive=bool(adaptive),
+                     orth_cond2_history=cond_hist)
     evals = evals.reshape(*bdims, p)
     evecs = Xall[:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
     return evals, evecs
