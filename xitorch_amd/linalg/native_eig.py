@@ -416,8 +416,8 @@ def tallqr_extend(V, t, M=None, orth_passes=2):
     block ``t (B, N, p)``, return ``Q (B, N, k+p)`` whose first k columns are V and whose last p columns span
     ``t`` minus its components along V, (M-)orthonormal — what the reference obtains from the full CholeskyQR
     ``tallqr(cat(V, t))`` (xitorch/_utils/tensor.py:8-19, _impls/linalg/symeig.py:207-220), computed here like in
-    the Davidson loop: block Gram–Schmidt (``orth_passes`` times) of the new panel against the basis + CholeskyQR of
-    the panel alone.  In exact arithmetic the two agree column by column, since
+    the Davidson loop: ``orth_passes`` rounds of [block Gram–Schmidt of the new panel against the basis, CholeskyQR of
+    the panel alone] (the first CholeskyQR shifted when there are two or more).  In exact arithmetic the two agree column by column, since
     chol([[I, C], [C^T, G]]) = [[I, C], [0, chol(G - C^T C)]].  Raises RuntimeError when the panel Gram matrix is
     not positive definite (the reference raises from torch.linalg.cholesky)."""
     B, N, k = V.shape
@@ -430,9 +430,11 @@ def tallqr_extend(V, t, M=None, orth_passes=2):
     grp.Vs[:, k:k + p, :N].copy_(t.transpose(-2, -1))
     if opM is not None:
         opM.apply(grp.Vs[:, :k], grp.MVs[:, :k])
-    for _ in range(max(1, orth_passes)):
-        grp.project_out(k, p)
-    grp.cholqr(k, p)
+    rounds = max(1, orth_passes)
+    for it in range(rounds):                 # the order of the Davidson loop: [projection, CholeskyQR] per pass, the first
+        grp.project_out(k, p)                # CholeskyQR shifted when another pass follows
+        if rounds >= 2 or it == rounds - 1:
+            grp.cholqr(k, p, shifted=(rounds >= 2 and it == 0))
     if int(grp.info.max().item()) != 0:
         raise RuntimeError("xitorch_amd tallqr_extend: the panel Gram matrix is not positive definite "
                            "(linearly dependent vectors)")
