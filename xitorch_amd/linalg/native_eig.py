@@ -363,13 +363,15 @@ class _Group:
         end()
         self._orth_done = True
 
-    # A panel whose squared pivot ratio (xk_davidson_orth's cond) is below this may be followed by ONE-pass panels.  The
-    # estimate reaches the host two panels late (the next orthonormalisation is enqueued before the status is read);
-    # measured growth where it grows at all (S1, neig = 8: pairs converge one after the other) is ~20x per iteration, so
-    # one pass never meets a squared condition number above ~4e5, i.e. an orthogonality loss above ~1e-13 per
-    # iteration.  Beyond it the run stays on two passes.  (The headline workload stays below 40, S1 at order 2048 below
-    # 800; scripts/orth_passes_scan.py.)
-    ONE_PASS_MAX_COND2 = 1e3
+    # A panel whose squared pivot ratio (xk_davidson_orth's cond) is below this may be followed by ONE-pass panels.  Two
+    # regimes were measured (scripts/orth_passes_scan.py, the headline workload): a benign plateau — the 64 operators of
+    # BASELINE configs[1] settle at 1e3 .. 2e3 from iteration 7 on, S1 at order 2048 at 8e2 — where one pass loses
+    # ~5e-15 of orthogonality per iteration, and exponential growth (~20x per iteration: S1 with neig = 8, pairs
+    # converging one after the other) that ends at 1e11 and in duplicated eigenpairs.  The estimate reaches the host two
+    # panels late (the next orthonormalisation is enqueued before the status is read), so with the threshold between
+    # the two regimes one pass never meets a squared condition number above ~4e6: an orthogonality loss of ~2e-13 per
+    # iteration at worst.  Beyond the threshold the run stays on two passes.
+    ONE_PASS_MAX_COND2 = 1e4
 
     def current_passes(self, q):
         """projection passes of the next panel orthonormalisation"""
@@ -533,7 +535,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         ~30 iterations and returned duplicated eigenpairs (eigenvalue error 50) with a residual below ``min_eps``.
         ``"auto"`` (default): two passes in the order [projection, shifted CholeskyQR, projection, CholeskyQR]
         (xk_chain.hip) — except that blocks of up to 8 vectors take ONE pass while the fused CholeskyQR kernel's
-        condition estimate (squared pivot ratio, read with the iteration's status) stays below 1e3; the first panel
+        condition estimate (squared pivot ratio, read with the iteration's status) stays below 1e4; the first panel
         that exceeds it puts the rest of the run on two passes (``trace["orth_two_pass_from"]``).  With a
         preconditioner, ``restart=``, ``M`` or ``chain="kernels"``: always two.  An integer forces the number of passes
         (1 = one pass throughout; not checked).
