@@ -371,7 +371,7 @@ class _Group:
     # panels late (the next orthonormalisation is enqueued before the status is read), so with the threshold between
     # the two regimes one pass never meets a squared condition number above ~4e6: an orthogonality loss of ~2e-13 per
     # iteration at worst.  Beyond the threshold the run stays on two passes.
-    ONE_PASS_MAX_COND2 = 1e4
+    ONE_PASS_MAX_COND2 = 1e4                     # fp64; fp32 runs use 1e2 (the loss per iteration is eps * condition)
 
     def current_passes(self, q):
         """projection passes of the next panel orthonormalisation"""
@@ -383,11 +383,11 @@ class _Group:
 
     def note_condition(self, cond2, it):
         """the driver hands over status[3] after every status read"""
-        if self.adaptive and self.passes_now == 1 and not (cond2 <= self.ONE_PASS_MAX_COND2):
+        limit = self.ONE_PASS_MAX_COND2 if self.dtype == torch.float64 else min(self.ONE_PASS_MAX_COND2, 1e2)
+        if self.adaptive and self.passes_now == 1 and not (cond2 <= limit):
             self.passes_now = 2
             self.two_pass_from = it
-        elif self.adaptive and self.two_pass_from is None and self.passes_now == 2 and cond2 <= self.ONE_PASS_MAX_COND2 \
-                and it >= 1:
+        elif self.adaptive and self.two_pass_from is None and self.passes_now == 2 and cond2 <= limit and it >= 1:
             self.passes_now = 1                   # the start block and the first panel were benign: fast order
 
     def speculate_orth(self):
