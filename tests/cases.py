@@ -27,6 +27,11 @@ DAVIDSON_CASES = [
     dict(name="s1_512_b2_lowest6", kind="S1", n=512, batch=(2,), neig=6, mode="lowest", min_eps=1e-8),
     dict(name="s2_256_b3_uppest4", kind="S2", n=256, batch=(3,), neig=4, mode="uppest", min_eps=1e-8),
     dict(name="s1_1024_b1_lowest6", kind="S1", n=1024, batch=(1,), neig=6, mode="lowest", min_eps=1e-8),
+    # mixed convergence (r03): six separated eigenvalues converge within ~20 iterations, the rest of the wanted pairs
+    # sit in the dense part of S1 and take 60-75 — the regime in which restricting the reference's full-basis
+    # CholeskyQR to the new block needs a second orthonormalisation pass
+    dict(name="s1_900_b2_lowest10", kind="S1", n=900, batch=(2,), neig=10, mode="lowest", min_eps=1e-8),
+    dict(name="s1_900_b2_lowest8", kind="S1", n=900, batch=(2,), neig=8, mode="lowest", min_eps=1e-8),
     # config 1 of BASELINE.json: benchmarks_solve.py shape family, N=512, lowest 6
     dict(name="c1_rand512_lowest6", kind="randsym", n=512, batch=(), neig=6, mode="lowest", min_eps=1e-8),
     # generalised problem A x = lam M x (M-orthonormal basis, symeig.py:183-185,216-218).  (v_init="eye" is not
