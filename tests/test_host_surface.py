@@ -464,3 +464,39 @@ def test_extra_methods_match_reference_goldens_on_cpu():
         y, nfev = _run_extra(case, "cpu")
         assert nfev == int(gold["nfev"]), (case["name"], nfev, int(gold["nfev"]))
         assert np.abs(y.detach().numpy() - gold["y"]).max() <= 1e-12, case["name"]
+
+
+def test_davidson_orthonormalisation_pass_policy():
+    """The adaptive choice of projection passes (native_eig._Group.current_passes / note_condition), without a device:
+    two passes for the first two panels, one while the reported squared condition estimate stays below the limit, two
+    for the rest of the run from the first panel above it; fixed counts, wide panels and the non-fused paths ignore the
+    estimate."""
+    from types import SimpleNamespace
+    from xitorch_amd.linalg.native_eig import _Group
+
+    def group(**kw):
+        g = SimpleNamespace(adaptive=True, passes_now=2, two_pass_from=None, orth_passes=2, fast=True, opM=None,
+                            precond=None, dtype=torch.float64, ONE_PASS_MAX_COND2=_Group.ONE_PASS_MAX_COND2)
+        g.__dict__.update(kw)
+        return g
+    g = group()
+    seen = []
+    for it, cond2 in enumerate([0.0, 1.0, 30.0, 2e3, 8e3, 3e5, 10.0, 1.0]):
+        seen.append(_Group.current_passes(g, 6))          # the panel enqueued before this iteration's status is read
+        _Group.note_condition(g, cond2, it)
+    assert seen == [2, 2, 1, 1, 1, 1, 2, 2] and g.two_pass_from == 5
+    # fp32: the limit is 1e2
+    g = group(dtype=torch.float32)
+    for it, cond2 in enumerate([0.0, 1.0, 5e2]):
+        _Group.note_condition(g, cond2, it)
+    assert g.passes_now == 2 and g.two_pass_from == 2
+    # NaN counts as "above"
+    g = group(passes_now=1)
+    _Group.note_condition(g, float("nan"), 4)
+    assert g.passes_now == 2
+    # wide panels, an overlap operator, a fixed count
+    g = group(passes_now=1)
+    assert _Group.current_passes(g, 10) == 2
+    assert _Group.current_passes(group(passes_now=1, opM=object()), 6) == 2
+    assert _Group.current_passes(group(adaptive=False, orth_passes=1), 6) == 1
+    assert _Group.current_passes(group(adaptive=False, orth_passes=3), 6) == 3
