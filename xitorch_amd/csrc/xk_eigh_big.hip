@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     __syncthreads();
     for (int it = 0; it < 3; ++it) {
       if (tid < nb) {
-        const int jl = tid, j = j0 + tid;
+        const int jl = tid;
         const T* dl = lu + ((long)0 * n) * pb + jl;
         const T* dg = lu + ((long)1 * n) * pb + jl;
         const T* du = lu + ((long)2 * n) * pb + jl;
