@@ -167,9 +167,13 @@ int xk_diag_precond_f32(float* t, const float* d, const float* m, const float* l
 
 /* ---- group status of a Davidson step in one launch (native_eig._Group.small; the reference reads
  * `resid.abs().max()` on the host, symeig.py:190-197): status[0] = max_b rmax[b] (NaN if any is NaN),
- * status[1] = max_b info[b] (panel Cholesky flags), status[2] = max_b flag[b] (K3t self-check; flag may be NULL) */
-int xk_group_status_f64(const double* rmax, const int* info, const int* flag, double* status, int B, void* stream);
-int xk_group_status_f32(const float* rmax, const int* info, const int* flag, double* status, int B, void* stream);
+ * status[1] = max_b info[b] (panel Cholesky flags), status[2] = max_b flag[b] (K3t self-check; flag may be NULL);
+ * orth (B, may be NULL): the a-posteriori guard values left by xk_ritz_guard: status[4] = max_b orth[b] (NaN counts as
+ * infinite), orth is re-zeroed; status then has 5 doubles (status[3], the chain's condition estimate, is not written) */
+int xk_group_status_f64(const double* rmax, const int* info, const int* flag, double* orth, double* status, int B,
+                        void* stream);
+int xk_group_status_f32(const float* rmax, const int* info, const int* flag, float* orth, double* status, int B,
+                        void* stream);
 
 /* ---- K3: batched small symmetric eigensolver (LDS-resident parallel Jacobi) -----------------
  * Lowest (uppest=0) / uppermost (uppest=1) p eigenpairs of B symmetric k x k matrices (lower
@@ -308,8 +312,16 @@ int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long 
  * The stages between two operator-panel products are two to eight small launches each; issued from C++ they cost a
  * few microseconds of host time instead of an interpreter round trip per launch (what bounds small per-GPU batches).
  * xk_davidson_ritz: xk_ritz_residual + the group status {max_b rmax (NaN-propagating), max_b info, max_b flag} as
- *   three doubles (+ a fourth, max_b cond, when cond is given; cond is re-zeroed); rmax is left zeroed for the next
- *   step (symeig.py:178-197).  flag and cond may be NULL.
+ *   three doubles (+ a fourth, max_b cond, when cond is given; cond is re-zeroed; + a fifth, max_b orth, when orth is
+ *   given: xk_ritz_guard of the Ritz block X just formed, folded and re-zeroed); rmax is left zeroed for the next
+ *   step (symeig.py:178-197).  flag, cond and orth may be NULL.  Gs: scratch >= B*P*P and ws:
+ *   xk_dense_mm_workspace_elems(B, P, N, P, 0), both only read when orth is given and P > 8.
+ * xk_ritz_guard: the a-posteriori check that stands where the reference's whole-basis CholeskyQR makes a wrong
+ *   answer impossible (tallqr of [V, t] every iteration, _utils/tensor.py:8-19, symeig.py:207-223): orth[b] =
+ *   max(orth[b], max_{c,d} |<X_c, (M X)_d> - delta_cd|) over the P rows of the Ritz block X (B, P, ldx) and M X
+ *   (B, P, ldm; NULL: X itself).  Two copies of one eigenpair in a block give 1, a healthy block rounding level; the
+ *   Davidson driver never returns (and never restarts from) a block above its threshold.  P <= 8: one kernel, the
+ *   panels are read once; wider: Gram on K1 into Gs (>= B*P*P) + one wave per member.
  * xk_davidson_orth: rows [k0, k0+q) of the basis V (B, cap, ldv) against rows [0, k0): block Gram-Schmidt
  *   (C[b,c,a] = <V_a, t_c>, t_c -= sum_a C V_a) and CholeskyQR of the q rows — for q <= 8 in ONE kernel (Gram,
  *   Cholesky, inverse, transform; one workgroup per batch member) — i.e. tallqr of [V, t] restricted to the new block
@@ -323,13 +335,19 @@ int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long 
  * xk_davidson_extend_t: Tn[b,c,a] = <V_a, (AV)_{k0+c}> for a < k0+q, written to T[b, k0+c, a] and mirrored to
  *   T[b, a, k0+c] (symeig.py:170 restricted to the new rows / columns).  Tn: scratch >= B*q*(k0+q). */
 int xk_davidson_ritz_f64(const double* V, const double* AV, const double* Y, const double* lam, double* X, double* Tn,
-                         double* rmax, const int* info, const int* flag, double* cond, double* status, int B, int k,
-                         int N, int P, long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam,
-                         long ldx, long sX, long ldt, long sT, void* stream);
+                         double* rmax, const int* info, const int* flag, double* cond, double* orth, double* status,
+                         int B, int k, int N, int P, long ldv, long sV, long ldav, long sAV, long sY, long sYa,
+                         long sYc, long sLam, long ldx, long sX, long ldt, long sT, double* Gs, long gs_elems,
+                         double* ws, long ws_elems, void* stream);
 int xk_davidson_ritz_f32(const float* V, const float* AV, const float* Y, const float* lam, float* X, float* Tn,
-                         float* rmax, const int* info, const int* flag, float* cond, double* status, int B, int k,
-                         int N, int P, long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam, long ldx,
-                         long sX, long ldt, long sT, void* stream);
+                         float* rmax, const int* info, const int* flag, float* cond, float* orth, double* status, int B,
+                         int k, int N, int P, long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc,
+                         long sLam, long ldx, long sX, long ldt, long sT, float* Gs, long gs_elems, float* ws,
+                         long ws_elems, void* stream);
+int xk_ritz_guard_f64(const double* X, const double* MX, double* orth, int B, int N, int P, long ldx, long sX,
+                      long ldm, long sM, double* Gs, long gs_elems, double* ws, long ws_elems, void* stream);
+int xk_ritz_guard_f32(const float* X, const float* MX, float* orth, int B, int N, int P, long ldx, long sX, long ldm,
+                      long sM, float* Gs, long gs_elems, float* ws, long ws_elems, void* stream);
 int xk_davidson_orth_f64(double* V, int B, int N, int k0, int q, long ldv, long sV, double* C, double* W, int* info,
                          double* cond, double* ws, long ws_elems, int passes, void* stream);
 int xk_davidson_orth_f32(float* V, int B, int N, int k0, int q, long ldv, long sV, float* C, float* W, int* info,

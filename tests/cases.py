@@ -42,6 +42,16 @@ DAVIDSON_CASES = [
 ]
 
 
+# fp32, mixed convergence (r04): the six separated eigenvalues of S1 converge early, the two wanted pairs inside the
+# dense part late (43 reference iterations) — the regime of the r03 duplicate-eigenpair defect, in the precision of
+# BASELINE configs[4].  (The reference's own fp32 run needs torch.set_num_threads(1), which make_golden.py sets: with
+# several MKL threads its torch.inverse stalls in SLASWP at a basis of 152 vectors in this image.)
+DAVIDSON_CASES_F32 = [
+    dict(name="s1_900_b2_lowest8_f32", kind="S1", n=900, batch=(2,), neig=8, mode="lowest", min_eps=2e-3,
+         dtype="float32"),
+]
+
+
 def random_symmetric(n, min_eival, max_eival, seed):
     """Prescribed linspace spectrum in a seeded random orthogonal basis — restates what
     xitorch/_utils/tensor.py:46-76 (create_random_square_matrix, hermitian branch) computes."""
@@ -53,6 +63,8 @@ def random_symmetric(n, min_eival, max_eival, seed):
 
 
 def davidson_matrix(case):
+    if case.get("dtype") == "float32":
+        return davidson_matrix({k: v for k, v in case.items() if k != "dtype"}).to(torch.float32)
     n, kind, batch = case["n"], case["kind"], tuple(case["batch"])
     if kind == "alarge":
         nb = 1

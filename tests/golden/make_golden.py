@@ -90,9 +90,11 @@ def save(name, **arrs):
 
 
 # --------------------------------------------------------------------------- symeig / davidson
-def gen_davidson():
-    for case in cases.DAVIDSON_CASES:
+def gen_davidson(only=None):
+    for case in cases.DAVIDSON_CASES + cases.DAVIDSON_CASES_F32:
         name = case["name"]
+        if only and name not in only:
+            continue
         mat = cases.davidson_matrix(case)
         Mmat = cases.davidson_M(case)
         with warnings.catch_warnings():
@@ -108,7 +110,11 @@ def gen_davidson():
         exact(ev_r, ev_o, name + " evals")
         exact(X_r, X_o, name + " evecs")
         assert tr["napply"] == rop.n, (tr["napply"], rop.n)
-        ev_x, _ = ref_symeig.exacteig(xitorch.LinearOperator.m(mat, is_hermitian=True), case["neig"], case["mode"], rM)
+        if mat.dtype == torch.float32:       # the exact spectrum of the fp32 operator, in double
+            ev_all = torch.linalg.eigvalsh(mat.double())
+            ev_x = ev_all[..., :case["neig"]] if case["mode"] == "lowest" else ev_all[..., -case["neig"]:]
+        else:
+            ev_x, _ = ref_symeig.exacteig(xitorch.LinearOperator.m(mat, is_hermitian=True), case["neig"], case["mode"], rM)
         MX = torch.matmul(Mmat, X_r) if Mmat is not None else X_r
         resid = (torch.matmul(mat, X_r) - MX * ev_r.unsqueeze(-2)).abs().max()
         # store evecs only through a sign-free, small summary: |X|^T at a few probe rows
@@ -241,8 +247,9 @@ def gen_extra():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["davidson", "solve", "root", "extra"]
-    if "davidson" in which:
-        gen_davidson()
+    only = [w.split(":", 1)[1] for w in which if w.startswith("davidson:")]      # e.g. davidson:s1_900_b2_lowest8_f32
+    if "davidson" in which or only:
+        gen_davidson(only or None)
     if "solve" in which:
         gen_solve()
     if "root" in which:

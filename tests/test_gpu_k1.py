@@ -170,7 +170,13 @@ def test_dense_symm_is_bit_reproducible(dev, B, N, P, dtype):
 @pytest.mark.parametrize("B,M,N,P,dtype", [(2, 512, 256, 32, torch.float32), (1, 300, 128, 17, torch.float32),
                                            (2, 256, 384, 12, torch.float32), (2, 512, 64, 16, torch.float64),
                                            (1, 130, 96, 32, torch.float64), (2, 77, 32, 25, torch.float64),
-                                           (1, 256, 256, 50, torch.float64), (1, 1024, 1024, 50, torch.float32)])
+                                           (1, 256, 256, 50, torch.float64), (1, 1024, 1024, 50, torch.float32),
+                                           # r04: fp32 panels of 9 .. 16 columns take the 16-wide MFMA tile
+                                           # (v_mfma_f32_16x16x4_f32): no padded output columns at P = 16
+                                           (2, 512, 256, 9, torch.float32), (2, 512, 256, 16, torch.float32),
+                                           (3, 1030, 384, 16, torch.float32), (2, 256, 128, 17, torch.float32),
+                                           (2, 256, 64, 9, torch.float64), (2, 256, 64, 17, torch.float64),
+                                           (1, 2048, 2048, 16, torch.float32), (1, 2048, 2048, 40, torch.float32)])
 def test_dense_wide_mfma_vs_oracle(dev, B, M, N, P, dtype):
     # K1w: Y = A^T X for many panel columns on the matrix cores (asymmetric A catches transposed fragments)
     g = torch.Generator().manual_seed(M + N + P)
@@ -185,7 +191,13 @@ def test_dense_wide_mfma_vs_oracle(dev, B, M, N, P, dtype):
     assert (Yv - ref).abs().max().item() / scale < tol * M ** 0.5
     if P <= 32:
         Yw = K.dense_wide(A.to(dev), X.to(dev)).cpu().double()
-        assert torch.equal(Yw, Y)
+        if P >= K.WIDE_MIN_P:
+            assert torch.equal(Yw, Y)                   # (the dispatcher took this very kernel)
+        else:
+            assert (Yw - ref).abs().max().item() / scale < tol * M ** 0.5
+        assert torch.equal(K.dense_wide(A.to(dev), X.to(dev)).cpu().double(), Yw)
+    # fixed accumulation order: bit-identical from launch to launch
+    assert torch.equal(K.dense_mm(A.to(dev), X.to(dev), trans=True).cpu().double(), Y)
 
 
 def test_exact_symmetry_detection_large_batched(dev):

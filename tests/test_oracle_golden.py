@@ -32,6 +32,27 @@ def test_oracle_davidson(case):
     assert (torch.matmul(mat, X) - MX * ev.unsqueeze(-2)).abs().max().item() <= 10 * case["min_eps"]
 
 
+@pytest.mark.parametrize("case", cases.DAVIDSON_CASES_F32, ids=[c["name"] for c in cases.DAVIDSON_CASES_F32])
+def test_oracle_davidson_fp32_mixed_convergence(case):
+    # fp32 reference golden (r04): on the generating machine the oracle is bit-equal to the reference (make_golden.py
+    # asserts torch.equal); here, with whatever BLAS threading the box has, within fp32 rounding of it
+    gold = np.load(os.path.join(GOLD, "davidson_%s.npz" % case["name"]))
+    mat = cases.davidson_matrix(case)
+    assert mat.dtype == torch.float32
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)          # (several MKL threads: the fp32 torch.inverse of the reference's tallqr stalls)
+    try:
+        tr = {}
+        ev, X = osym.davidson(oops.DenseOp(mat, True), case["neig"], case["mode"], None, min_eps=case["min_eps"], trace=tr)
+    finally:
+        torch.set_num_threads(nthreads)
+    assert ev.dtype == torch.float32
+    assert np.abs(ev.numpy() - gold["evals"]).max() <= 2e-4           # fp32: eps * |A| ~ 1e-5, resid^2 / gap ~ 1e-4
+    assert np.abs(ev.numpy().astype(np.float64) - gold["evals_exact"]).max() <= 5e-4
+    assert abs(tr["niter"] - int(gold["niter"])) <= 2
+    assert (torch.matmul(mat, X) - X * ev.unsqueeze(-2)).abs().max().item() <= 10 * case["min_eps"]
+
+
 @pytest.mark.parametrize("case", cases.SOLVE_CASES, ids=[c["name"] for c in cases.SOLVE_CASES])
 def test_oracle_solve(case):
     gold = np.load(os.path.join(GOLD, "solve_%s.npz" % case["name"]))

@@ -64,7 +64,8 @@ def _declare(L):
         sigs["xk_diag_precond_" + sfx] = (I, [P, P, P, P, I, I, I, Lg, Lg, Lg, Lg, Lg, D, P])
         sigs["xk_small_eigh_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, I, Lg, Lg, P])
     for sfx in ("f64", "f32"):
-        sigs["xk_davidson_ritz_" + sfx] = (I, [P] * 11 + [I, I, I, I] + [Lg] * 12 + [P])
+        sigs["xk_davidson_ritz_" + sfx] = (I, [P] * 12 + [I, I, I, I] + [Lg] * 12 + [P, Lg, P, Lg, P])
+        sigs["xk_ritz_guard_" + sfx] = (I, [P, P, P, I, I, I, Lg, Lg, Lg, Lg, P, Lg, P, Lg, P])
         sigs["xk_davidson_orth_" + sfx] = (I, [P, I, I, I, I, Lg, Lg, P, P, P, P, P, Lg, I, P])
         sigs["xk_davidson_extend_t_" + sfx] = (I, [P, P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P, Lg, P])
     sigs["xk_small_eigh_workspace_elems"] = (Lg, [I, I, I])
@@ -89,7 +90,7 @@ def _declare(L):
     for sfx in ("f64", "f32"):
         sigs["xk_dense_wide_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):
-        sigs["xk_group_status_" + sfx] = (I, [P, P, P, P, I, P])
+        sigs["xk_group_status_" + sfx] = (I, [P, P, P, P, P, I, P])
         sigs["xk_dense_symm_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
         sigs["xk_dense_symm_tiles_" + sfx] = (I, [P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, P])
         sigs["xk_dense_symm_fold_" + sfx] = (I, [P, P, Lg, I, I, I, Lg, Lg, P])

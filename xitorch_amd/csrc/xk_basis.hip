@@ -358,16 +358,18 @@ __global__ __launch_bounds__(256) void diag_precond_kernel(T* __restrict__ Tn, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Group status in one launch: status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b]} as doubles.
+// Group status in one launch: status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b]} as doubles;
+// with orth (the a-posteriori guard values of xk_ritz_guard, NaN counts as infinite) also status[4] = max_b orth[b],
+// orth <- 0 (status[3] is the condition estimate of the fused chain, untouched here).
 // Replaces three torch reductions + three converting element copies per Rayleigh-Ritz step (eight tiny launches on
 // the critical chain of a small batch group).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void group_status_kernel(const T* __restrict__ rmax, const int* __restrict__ info,
-                                                          const int* __restrict__ flag, double* __restrict__ status,
-                                                          int B) {
+                                                          const int* __restrict__ flag, T* __restrict__ orth,
+                                                          double* __restrict__ status, int B) {
   const int lane = threadIdx.x;
-  double m = 0.0;
+  double m = 0.0, om_ = 0.0;
   int nan = 0, i1 = 0, i2 = 0;
   bool first = true;
   for (int b = lane; b < B; b += 64) {
@@ -380,6 +382,11 @@ __global__ __launch_bounds__(64) void group_status_kernel(const T* __restrict__ 
       const int f = flag[b];
       i2 = first ? f : (f > i2 ? f : i2);
     }
+    if (orth) {
+      const double ov = (double)orth[b];
+      orth[b] = T(0);
+      om_ = (ov != ov) ? __builtin_inf() : (ov > om_ ? ov : om_);
+    }
     first = false;
   }
   // lanes without an element must not contribute: fold with explicit validity
@@ -387,9 +394,10 @@ __global__ __launch_bounds__(64) void group_status_kernel(const T* __restrict__ 
   int a1 = first ? -2147483647 - 1 : i1, a2 = first ? -2147483647 - 1 : i2;
 #pragma unroll
   for (int sft = 32; sft >= 1; sft >>= 1) {
-    const double om = __shfl_xor(mm, sft, 64);
+    const double om = __shfl_xor(mm, sft, 64), oo = __shfl_xor(om_, sft, 64);
     const int o1 = __shfl_xor(a1, sft, 64), o2 = __shfl_xor(a2, sft, 64), on = __shfl_xor(nan, sft, 64);
     mm = om > mm ? om : mm;
+    om_ = oo > om_ ? oo : om_;
     a1 = o1 > a1 ? o1 : a1;
     a2 = o2 > a2 ? o2 : a2;
     nan |= on;
@@ -398,6 +406,7 @@ __global__ __launch_bounds__(64) void group_status_kernel(const T* __restrict__ 
     status[0] = nan ? __builtin_nan("") : mm;
     status[1] = (double)a1;
     status[2] = flag ? (double)a2 : 0.0;
+    if (orth) status[4] = om_;
   }
 }
 
@@ -448,11 +457,11 @@ XK_DEFINE_BASIS(f64, double)
 XK_DEFINE_BASIS(f32, float)
 
 #define XK_DEFINE_STATUS(SUF, T)                                                                            \
-  int xk_group_status_##SUF(const T* rmax, const int* info, const int* flag, double* status, int B,         \
+  int xk_group_status_##SUF(const T* rmax, const int* info, const int* flag, T* orth, double* status, int B, \
                             void* stream) {                                                                 \
     if (B <= 0 || !rmax || !info || !status) return XK_ERR_ARG;                                             \
     hipLaunchKernelGGL((xk::group_status_kernel<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, rmax, info, \
-                       flag, status, B);                                                                    \
+                       flag, orth, status, B);                                                              \
     XK_LAUNCH_CHECK();                                                                                      \
     return XK_OK;                                                                                           \
   }

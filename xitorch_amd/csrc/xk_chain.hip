@@ -94,16 +94,18 @@ __device__ __forceinline__ double chain_uniform(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b], max_b cond[b] (only with cond)} as doubles,
-// cond <- 0, then rmax <- 0 for the next
+// status = {max_b rmax[b] (NaN if any is NaN), max_b info[b], max_b flag[b], max_b cond[b] (only with cond),
+// max_b orth[b] (only with orth: the a-posteriori guard, NaN counts as infinite)} as doubles, cond <- 0, orth <- 0,
+// then rmax <- 0 for the next
 // Rayleigh-Ritz step (the residual kernel folds into it with an order-independent atomic max).  One wave.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__ rmax, const int* __restrict__ info,
                                                                  const int* __restrict__ flag, T* __restrict__ cond,
-                                                                 double* __restrict__ status, int B) {
+                                                                 T* __restrict__ orth, double* __restrict__ status,
+                                                                 int B) {
   const int lane = threadIdx.x;
-  double m = 0.0, cm = 0.0;
+  double m = 0.0, cm = 0.0, om_ = 0.0;
   int nan = 0, i1 = 0, i2 = 0;
   bool first = true;
   for (int b = lane; b < B; b += 64) {
@@ -113,6 +115,11 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
       const double cv = (double)cond[b];                     // last status (NaN counts as infinite), re-zeroed
       cond[b] = T(0);
       cm = (cv != cv) ? __builtin_inf() : (cv > cm ? cv : cm);
+    }
+    if (orth) {                                              // worst |X^T M X - I| of the Ritz blocks checked since
+      const double ov = (double)orth[b];                     // the last status, re-zeroed
+      orth[b] = T(0);
+      om_ = (ov != ov) ? __builtin_inf() : (ov > om_ ? ov : om_);
     }
     nan |= (v != v);
     m = first ? v : (v > m ? v : m);
@@ -128,10 +135,11 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
   int a1 = first ? -2147483647 - 1 : i1, a2 = first ? -2147483647 - 1 : i2;
 #pragma unroll
   for (int sft = 32; sft >= 1; sft >>= 1) {
-    const double om = __shfl_xor(mm, sft, 64), oc = __shfl_xor(cm, sft, 64);
+    const double om = __shfl_xor(mm, sft, 64), oc = __shfl_xor(cm, sft, 64), oo = __shfl_xor(om_, sft, 64);
     const int o1 = __shfl_xor(a1, sft, 64), o2 = __shfl_xor(a2, sft, 64), on = __shfl_xor(nan, sft, 64);
     mm = om > mm ? om : mm;
     cm = oc > cm ? oc : cm;
+    om_ = oo > om_ ? oo : om_;
     a1 = o1 > a1 ? o1 : a1;
     a2 = o2 > a2 ? o2 : a2;
     nan |= on;
@@ -141,6 +149,98 @@ __global__ __launch_bounds__(64) void group_status_rezero_kernel(T* __restrict__
     status[1] = (double)a1;
     status[2] = flag ? (double)a2 : 0.0;
     if (cond) status[3] = cm;
+    if (orth) status[4] = om_;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-posteriori guard of a Rayleigh-Ritz block: orth[b] = max(orth[b], max_{c,d} |<X_c, (M X)_d> - delta_cd|) for the P
+// rows of the panel X (MX == X when there is no overlap operator).  The reference re-orthonormalises the WHOLE basis
+// every iteration (tallqr of [V, t], _utils/tensor.py:8-19, symeig.py:207-223), so the Ritz vectors V y it returns are
+// orthonormal by construction; this build orthonormalises only the new panel, and a basis that has lost its
+// orthogonality shows up here as a Ritz block whose Gram matrix is not the identity (two copies of one eigenpair: an
+// off-diagonal entry of 1) — the driver rolls such a step back instead of returning it.  One 1024-thread workgroup
+// per batch member, the panel is read once; sums per thread -> wave -> 16 waves in fixed order.  P <= 8.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int P>
+__global__ __launch_bounds__(1024) void ritz_guard_kernel(const T* __restrict__ X, const T* __restrict__ MX,
+                                                          T* __restrict__ orth, int N, long ldx, long sX, long ldm,
+                                                          long sM) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::n;
+  constexpr int NG = P * (P + 1) / 2;
+  __shared__ T part[16][NG];
+  const int b = blockIdx.x;
+  const T* Xb = X + (long)b * sX;
+  const T* Mb = MX + (long)b * sM;
+  const bool same = (MX == X);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T g[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) g[i] = T(0);
+  for (int j = tid * VN; j < N; j += 1024 * VN) {
+    VT x[P], m[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) x[c] = *reinterpret_cast<const VT*>(Xb + (long)c * ldx + j);
+    if (same) {
+#pragma unroll
+      for (int c = 0; c < P; ++c) m[c] = x[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < P; ++c) m[c] = *reinterpret_cast<const VT*>(Mb + (long)c * ldm + j);
+    }
+    int i = 0;
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+      for (int d = c; d < P; ++d, ++i)
+#pragma unroll
+        for (int v = 0; v < VN; ++v) g[i] += x[c][v] * m[d][v];
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const T s = wave_sum(g[i]);
+    if (lane == 0) part[wave][i] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    T dev = T(0);
+    bool bad = false;
+    int i = 0;
+    for (int c = 0; c < P; ++c)
+      for (int d = c; d < P; ++d, ++i) {
+        T s = T(0);
+        for (int w = 0; w < 16; ++w) s += part[w][i];          // fixed order
+        const T e = fabs(s - (c == d ? T(1) : T(0)));
+        if (e != e) bad = true;
+        dev = e > dev ? e : dev;
+      }
+    if (bad) dev = T(INFINITY);
+    const T old = orth[b];
+    orth[b] = (dev > old || old != old) ? dev : old;
+  }
+}
+
+// the same from a Gram block computed on K1 (panels wider than 8): G (B, P, P) compact, one wave per member
+template <typename T>
+__global__ __launch_bounds__(64) void gram_guard_kernel(const T* __restrict__ G, T* __restrict__ orth, int P) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const T* Gb = G + (long)b * P * P;
+  T dev = T(0);
+  int bad = 0;
+  for (int i = lane; i < P * P; i += 64) {
+    const int c = i / P, d = i - c * P;
+    const T e = fabs(Gb[i] - (c == d ? T(1) : T(0)));
+    bad |= (e != e);
+    dev = e > dev ? e : dev;
+  }
+  dev = wave_max(dev);
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) bad |= __shfl_xor(bad, sft, 64);
+  if (lane == 0) {
+    if (bad) dev = T(INFINITY);
+    const T old = orth[b];
+    orth[b] = (dev > old || old != old) ? dev : old;
   }
 }
 
@@ -436,6 +536,37 @@ static int davidson_orth(T* V, int B, int N, int k0, int q, long ldv, long sV, T
   return XK_OK;
 }
 
+// orth[b] = max(orth[b], max|X^T (MX) - I|) for the P-row panels X, MX (MX == X: plain Gram).  Gs: scratch of B*P*P
+// elements and ws: xk_dense_mm_workspace_elems(B, P, N, P, 0), both only used for P > 8.
+template <typename T>
+static int ritz_guard(const T* X, const T* MX, T* orth, int B, int N, int P, long ldx, long sX, long ldm, long sM,
+                      T* Gs, long gs_elems, T* ws, long ws_elems, void* stream) {
+  constexpr int VN = Vec16<T>::n;
+  const bool vec = !(ldx % VN) && !(sX % VN) && !(ldm % VN) && !(sM % VN) && !((uintptr_t)X & 15) &&
+                   !((uintptr_t)MX & 15) && ldx >= (long)((N + VN - 1) / VN) * VN &&
+                   ldm >= (long)((N + VN - 1) / VN) * VN;
+  if (P <= 8 && vec) {
+    const int Nv = (N + VN - 1) / VN * VN;
+    switch (P) {
+#define XK_CASE(PP)                                                                                            \
+  case PP:                                                                                                     \
+    hipLaunchKernelGGL((ritz_guard_kernel<T, PP>), dim3(B), dim3(1024), 0, (hipStream_t)stream, X, MX, orth,   \
+                       Nv, ldx, sX, ldm, sM);                                                                  \
+    break;
+      XK_CASE(1) XK_CASE(2) XK_CASE(3) XK_CASE(4) XK_CASE(5) XK_CASE(6) XK_CASE(7) XK_CASE(8)
+#undef XK_CASE
+    }
+    XK_LAUNCH_CHECK();
+    return XK_OK;
+  }
+  if (!Gs || gs_elems < (long)B * P * P) return XK_ERR_ARG;
+  int rc = dense_mm(X, MX, Gs, ws, ws_elems, B, P, N, P, ldx, sX, ldm, sM, (long)P, (long)P * P, stream);
+  if (rc != XK_OK) return rc;
+  hipLaunchKernelGGL((gram_guard_kernel<T>), dim3(B), dim3(64), 0, (hipStream_t)stream, Gs, orth, P);
+  XK_LAUNCH_CHECK();
+  return XK_OK;
+}
+
 template <typename T>
 static int davidson_extend_t(const T* V, const T* AV, T* Tm, T* Tn, int B, int N, int k0, int q, long ldv, long sV,
                              long ldav, long sAV, long ldt, long sT, T* ws, long ws_elems, void* stream) {
@@ -457,18 +588,30 @@ extern "C" {
 
 #define XK_DEFINE_CHAIN(SUF, T)                                                                                    \
   int xk_davidson_ritz_##SUF(const T* V, const T* AV, const T* Y, const T* lam, T* X, T* Tn, T* rmax,              \
-                             const int* info, const int* flag, T* cond, double* status, int B, int k, int N,       \
-                             int P,                                                                                \
+                             const int* info, const int* flag, T* cond, T* orth, double* status, int B, int k,     \
+                             int N, int P,                                                                         \
                              long ldv, long sV, long ldav, long sAV, long sY, long sYa, long sYc, long sLam,       \
-                             long ldx, long sX, long ldt, long sT, void* stream) {                                 \
+                             long ldx, long sX, long ldt, long sT, T* Gs, long gs_elems, T* ws, long ws_elems,     \
+                             void* stream) {                                                                       \
     if (B <= 0 || k <= 0 || N <= 0 || P <= 0 || !rmax || !info || !status) return XK_ERR_ARG;                      \
     int rc = xk::ritz_c(V, AV, Y, lam, X, Tn, rmax, B, k, N, P, ldv, sV, ldav, sAV, sY, sYa, sYc, sLam, ldx, sX,   \
                         ldt, sT, stream);                                                                          \
     if (rc != XK_OK) return rc;                                                                                    \
+    if (orth) {                                                                                                    \
+      rc = xk::ritz_guard<T>(X, X, orth, B, N, P, ldx, sX, ldx, sX, Gs, gs_elems, ws, ws_elems, stream);           \
+      if (rc != XK_OK) return rc;                                                                                  \
+    }                                                                                                              \
     hipLaunchKernelGGL((xk::group_status_rezero_kernel<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, rmax, info,  \
-                       flag, cond, status, B);                                                                     \
+                       flag, cond, orth, status, B);                                                               \
     XK_LAUNCH_CHECK();                                                                                             \
     return XK_OK;                                                                                                  \
+  }                                                                                                                \
+  int xk_ritz_guard_##SUF(const T* X, const T* MX, T* orth, int B, int N, int P, long ldx, long sX, long ldm,      \
+                          long sM, T* Gs, long gs_elems, T* ws, long ws_elems, void* stream) {                     \
+    if (B < 0 || N <= 0 || P <= 0 || !X || !orth) return XK_ERR_ARG;                                               \
+    if (B == 0) return XK_OK;                                                                                      \
+    if (!MX) { MX = X; ldm = ldx; sM = sX; }                                                                       \
+    return xk::ritz_guard<T>(X, MX, orth, B, N, P, ldx, sX, ldm, sM, Gs, gs_elems, ws, ws_elems, stream);          \
   }                                                                                                                \
   int xk_davidson_orth_##SUF(T* V, int B, int N, int k0, int q, long ldv, long sV, T* C, T* W, int* info,          \
                              T* cond, T* ws, long ws_elems, int passes, void* stream) {                            \

@@ -26,6 +26,7 @@
 namespace xk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Mfma;
@@ -37,6 +38,19 @@ template <> struct Mfma<float> {
   }
   // D element `r` of lane l: row m(r, l), column c = l & 31
   static __device__ __forceinline__ int drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+// fp32, panels of 9 .. 16 columns (BASELINE configs[4]: a 16-column eigen-block): v_mfma_f32_16x16x4_f32.  With the
+// 32-wide form above half of every MFMA's output columns are padding at P = 16 — the matrix pipe was 0.69 busy for
+// 27 % of its peak and the launch issue-bound at 0.65 of the HBM roofline (profiles/r03_c5w_mfma_pmc.json); the 16-wide
+// form issues half the matrix-core cycles for the same useful flops, so the launch is HBM-bound again.
+struct Mfma16f {
+  static constexpr int TM = 16, TK = 4, SH = 4, MSK = 15, NACC = 4;
+  typedef f32x4 acc_t;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // D element `r` of lane l: row m = 4 * (l >> 4) + r, column c = l & 15
+  static __device__ __forceinline__ int drow(int r, int lane) { return 4 * (lane >> 4) + r; }
 };
 template <> struct Mfma<double> {
   static constexpr int TM = 16, TK = 4, SH = 4, MSK = 15, NACC = 4;
@@ -78,12 +92,11 @@ __device__ __forceinline__ double wide_ld_x(double, const WRsrc r, unsigned voff
 }
 
 // NT = number of panel-column tiles of width TM handled per wave (P <= NT*TM)
-template <typename T, int NT>
+template <typename T, int NT, typename MM>
 __global__ __launch_bounds__(256) void dense_wide_cols(
     const T* __restrict__ A, const T* __restrict__ Xrm, T* __restrict__ W, int M, int N, long lda, long sA,
     long ldxr, long sXr, int P, int col_tiles, int nslab, int rows_per_slab) {
   typedef typename Vec16<T>::type VT;
-  typedef Mfma<T> MM;
   typedef typename MM::acc_t acc_t;
   constexpr int VN = Vec16<T>::n;
   constexpr int WCOLS = VN * MM::TM;            // operator columns per wave (128 fp32 / 32 fp64)
@@ -180,6 +193,10 @@ __global__ __launch_bounds__(256) void dense_wide_cols(
   }
 }
 
+// the 16-wide tile of an element type (fp64 has only the one)
+template <typename T> struct Narrow { typedef Mfma<T> type; };
+template <> struct Narrow<float> { typedef Mfma16f type; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void wide_fold(const T* __restrict__ W, T* __restrict__ Y, int N, int P,
                                                   int nslab, long ldy, long sY, long total) {
@@ -195,9 +212,15 @@ __global__ __launch_bounds__(256) void wide_fold(const T* __restrict__ W, T* __r
   Y[b * sY + (long)c * ldy + n] = s;
 }
 
+// MFMA tile width serving P panel columns: 16 for fp64 and for fp32 panels of at most 16 columns, else 32
 template <typename T>
-static int wide_nslab(int B, int M, int N) {
-  constexpr int WC = Vec16<T>::n * Mfma<T>::TM * 4;   // columns per block
+static int wide_tile(int P) {
+  return (sizeof(T) == 8 || P <= 16) ? 16 : 32;
+}
+
+template <typename T>
+static int wide_nslab(int B, int M, int N, int P) {
+  const int WC = Vec16<T>::n * wide_tile<T>(P) * 4;   // columns per block
   const int ct = (N + WC - 1) / WC;
   int nslab = (2048 + B * ct - 1) / (B * ct);
   const int max_slab = (M + 127) / 128;
@@ -208,27 +231,30 @@ static int wide_nslab(int B, int M, int N) {
 template <typename T>
 static int wide_cols(const T* A, const T* Xrm, T* Y, T* ws, long ws_elems, int B, int M, int N, int P, long lda,
                      long sA, long ldxr, long sXr, long ldy, long sY, hipStream_t st) {
-  typedef Mfma<T> MM;
   constexpr int VN = Vec16<T>::n;
-  constexpr int WCOLS = VN * MM::TM;
   if (P > 32 || P < 1) return XK_ERR_ARG;
+  const int TM = wide_tile<T>(P), TK = (sizeof(T) == 8 || TM == 16) ? 4 : 2;
+  const int WCOLS = VN * TM;
   if ((N % WCOLS) || (lda % VN) || (sA % VN) || ((uintptr_t)A & 15)) return XK_ERR_UNSUPPORTED;
-  const int NT = (P + MM::TM - 1) / MM::TM;           // fp32: 1; fp64: 1 or 2
-  if (ldxr < (long)NT * MM::TM) return XK_ERR_ARG;    // X must be padded to whole tiles
+  const int NT = (P + TM - 1) / TM;                   // fp32: 1; fp64: 1 or 2
+  if (ldxr < (long)NT * TM) return XK_ERR_ARG;        // X must be padded to whole tiles
   const int ct = (N + 4 * WCOLS - 1) / (4 * WCOLS);
-  int nslab = wide_nslab<T>(B, M, N);
+  int nslab = wide_nslab<T>(B, M, N, P);
   while ((long)B * nslab * P * (long)N > ws_elems && nslab > 1) --nslab;
   if ((long)B * nslab * P * (long)N > ws_elems) return XK_ERR_ARG;
   int rps = (M + nslab - 1) / nslab;
-  rps = (rps + MM::TK - 1) / MM::TK * MM::TK;         // whole MFMA K-steps per slab
+  rps = (rps + TK - 1) / TK * TK;                     // whole MFMA K-steps per slab
   nslab = (M + rps - 1) / rps;
   const dim3 grid((unsigned)((long)B * nslab * ct));
-  if (NT == 1)
-    hipLaunchKernelGGL((dense_wide_cols<T, 1>), grid, dim3(256), 0, st, A, Xrm, ws, M, N, lda, sA, ldxr, sXr, P, ct,
-                       nslab, rps);
+  if (sizeof(T) == 4 && TM == 16)
+    hipLaunchKernelGGL((dense_wide_cols<T, 1, typename Narrow<T>::type>), grid, dim3(256), 0, st, A, Xrm, ws, M, N,
+                       lda, sA, ldxr, sXr, P, ct, nslab, rps);
+  else if (NT == 1)
+    hipLaunchKernelGGL((dense_wide_cols<T, 1, Mfma<T>>), grid, dim3(256), 0, st, A, Xrm, ws, M, N, lda, sA, ldxr, sXr,
+                       P, ct, nslab, rps);
   else
-    hipLaunchKernelGGL((dense_wide_cols<T, 2>), grid, dim3(256), 0, st, A, Xrm, ws, M, N, lda, sA, ldxr, sXr, P, ct,
-                       nslab, rps);
+    hipLaunchKernelGGL((dense_wide_cols<T, 2, Mfma<T>>), grid, dim3(256), 0, st, A, Xrm, ws, M, N, lda, sA, ldxr, sXr,
+                       P, ct, nslab, rps);
   XK_LAUNCH_CHECK();
   const long tot = (long)B * P * N;
   hipLaunchKernelGGL((wide_fold<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, Y, N, P, nslab, ldy,
@@ -242,13 +268,14 @@ static int wide_cols(const T* A, const T* Xrm, T* Y, T* ws, long ws_elems, int B
 extern "C" {
 
 long xk_dense_wide_workspace_elems(int B, int M, int N, int P, int elem_size) {
-  const int ns = elem_size == 8 ? xk::wide_nslab<double>(B, M, N) : xk::wide_nslab<float>(B, M, N);
+  const int ns = elem_size == 8 ? xk::wide_nslab<double>(B, M, N, P) : xk::wide_nslab<float>(B, M, N, P);
   return (long)B * ns * P * (long)N;
 }
 
-// padded panel width the row-major X must have: whole MFMA tiles (32 for fp32; 16 or 32 for fp64)
+// padded panel width the row-major X must have: whole MFMA tiles (fp64 and fp32 up to 16 columns: 16-wide tiles;
+// wider fp32 panels: 32)
 int xk_dense_wide_padded_width(int P, int elem_size) {
-  const int tm = elem_size == 8 ? 16 : 32;
+  const int tm = (elem_size == 8 || P <= 16) ? 16 : 32;
   return (P + tm - 1) / tm * tm;
 }
 

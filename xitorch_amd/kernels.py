@@ -116,12 +116,47 @@ def lincomb(V, C, out, k, P, coef_layout="ac", alpha=1.0, beta=0.0):
     return out
 
 
-def group_status(rmax, info, flag, status):
+def group_status(rmax, info, flag, status, orth=None):
     """status (3 doubles on the device) = {max rmax (NaN-propagating), max info, max flag or 0}: one launch instead of
-    three reductions and three converting copies (the host reads it once per Davidson step, symeig.py:190-197)."""
+    three reductions and three converting copies (the host reads it once per Davidson step, symeig.py:190-197).
+    orth (B,), optional: the guard values of `ritz_guard`; status[4] = their maximum (status needs 5 doubles), orth is
+    re-zeroed."""
+    if orth is not None and status.numel() < 5:
+        raise _capi.NativeLibraryError("group_status: status needs 5 doubles when orth is given")
     rc = fn("xk_group_status_" + suffix(rmax.dtype))(ptr(rmax), ptr(info), ptr(flag) if flag is not None else None,
+                                                     ptr(orth) if orth is not None else None,
                                                      ptr(status), rmax.shape[0], stream_ptr())
     check(rc, "xk_group_status")
+
+
+def ritz_guard(X, orth, P, N, MX=None):
+    """orth[b] = max(orth[b], max_{c,d} |<X_c, (M X)_d> - delta_cd|) over the first P rows of the panel-major Ritz
+    block X (B, >=P, ld) (MX: the panel M X, default X itself).  The a-posteriori check of a Rayleigh-Ritz block: the
+    reference's eigenvectors are orthonormal by construction (whole-basis CholeskyQR every iteration,
+    _utils/tensor.py:8-19, symeig.py:207-223); here a block that is not is rolled back by the driver."""
+    require_device(X, "Ritz block")
+    B = X.shape[0]
+    M_ = MX if MX is not None else X
+    gs = _guard_scratch(B, P, X.dtype, X.device) if P > 8 else None
+    ws, nws = (None, 0)
+    if P > 8:
+        nws = fn("xk_dense_mm_workspace_elems")(B, P, N, P, 0)
+        ws = _workspace(max(nws, 1), X.dtype, X.device)
+    rc = fn("xk_ritz_guard_" + suffix(X.dtype))(ptr(X), ptr(M_), ptr(orth), B, N, P, X.stride(1), X.stride(0),
+                                                 M_.stride(1), M_.stride(0), ptr(gs), (gs.numel() if gs is not None else 0),
+                                                 ptr(ws), nws, stream_ptr())
+    check(rc, "xk_ritz_guard")
+
+
+_gs_cache = {}
+
+
+def _guard_scratch(B, P, dtype, device):
+    key = (dtype, device, torch.cuda.current_stream().cuda_stream)
+    g = _gs_cache.get(key)
+    if g is None or g.numel() < B * P * P:
+        g = _gs_cache[key] = torch.empty(B * P * P, dtype=dtype, device=device)
+    return g
 
 
 def _check_ritz_shapes(V, AV, Y, lam, X, Tn, k, P):
@@ -189,18 +224,29 @@ def panel_transform(Tp, W, P):
 
 
 # --------------------------------------------------------------------------- Davidson chain (one C call per stage)
-def davidson_ritz(V, AV, Y, lam, X, Tn, rmax, info, flag, status, k, P, cond=None):
-    """ritz_residual + group status in one C call (xk_davidson_ritz): X = Y^T V, Tn = -(Y^T AV - lam X),
-    status = {max|resid| (NaN-propagating), max info, max flag[, max cond]}; rmax (and cond) are left zeroed for the
-    next step (symeig.py:178-197)."""
+def davidson_ritz(V, AV, Y, lam, X, Tn, rmax, info, flag, status, k, P, cond=None, orth=None, n_true=None):
+    """ritz_residual + (guard of the Ritz block) + group status in one C call (xk_davidson_ritz): X = Y^T V,
+    Tn = -(Y^T AV - lam X), status = {max|resid| (NaN-propagating), max info, max flag[, max cond[, max orth]]}; rmax
+    (and cond, orth) are left zeroed for the next step (symeig.py:178-197).  orth (B,): switches the a-posteriori guard
+    on (see `ritz_guard`; n_true = the unpadded vector length)."""
     B, N = V.shape[0], V.shape[2]
     if lam.stride(-1) != 1 and P > 1:
         raise _capi.NativeLibraryError("lam must have unit stride along its last dim")
     _check_ritz_shapes(V, AV, Y, lam, X, Tn, k, P)
+    gs, ws, nws = None, None, 0
+    if orth is not None:
+        if status.numel() < 5:
+            raise _capi.NativeLibraryError("davidson_ritz: status needs 5 doubles when orth is given")
+        if P > 8:
+            gs = _guard_scratch(B, P, V.dtype, V.device)
+            nws = fn("xk_dense_mm_workspace_elems")(B, P, N, P, 0)
+            ws = _workspace(max(nws, 1), V.dtype, V.device)
     rc = fn("xk_davidson_ritz_" + suffix(V.dtype))(
         ptr(V), ptr(AV), ptr(Y), ptr(lam), ptr(X), ptr(Tn), ptr(rmax), ptr(info), ptr(flag) if flag is not None else None,
-        ptr(cond) if cond is not None else None, ptr(status), B, k, N, P, V.stride(1), V.stride(0), AV.stride(1), AV.stride(0), Y.stride(0), Y.stride(1),
-        Y.stride(2), lam.stride(0), X.stride(1), X.stride(0), Tn.stride(1), Tn.stride(0), stream_ptr())
+        ptr(cond) if cond is not None else None, ptr(orth) if orth is not None else None, ptr(status), B, k, N, P,
+        V.stride(1), V.stride(0), AV.stride(1), AV.stride(0), Y.stride(0), Y.stride(1),
+        Y.stride(2), lam.stride(0), X.stride(1), X.stride(0), Tn.stride(1), Tn.stride(0),
+        ptr(gs), (gs.numel() if gs is not None else 0), ptr(ws), nws, stream_ptr())
     check(rc, "xk_davidson_ritz")
 
 

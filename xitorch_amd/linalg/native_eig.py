@@ -108,6 +108,7 @@ class _Group:
         self.B, self.N, self.Npad, self.p = B, N, Npad, p
         self.dtype, self.device, self.mode = dtype, device, mode
         self.small_eigh, self.orth_passes = small_eigh, orth_passes
+        self.nguess0 = nguess
         self.cap = min(N, nguess + 8 * p) if N > nguess else nguess
         z = lambda *shape: torch.zeros(shape, dtype=dtype, device=device)
         self.Vs, self.AVs = z(B, self.cap, Npad), z(B, self.cap, Npad)
@@ -116,9 +117,12 @@ class _Group:
         self.Wflat = torch.empty((B * 32 * 32,), dtype=dtype, device=device)
         self._cscratch = None                     # coefficient scratch of the one-call chain stages, B * p * cap
         self.info = torch.zeros((B,), dtype=torch.int32, device=device)
-        # max|resid|, chol flag, K3t self-check flag, squared pivot ratio of the last orthonormalised panel(s)
-        self.status = torch.zeros((4,), dtype=torch.float64, device=device)
+        # max|resid|, chol flag, K3t self-check flag, squared pivot ratio of the last orthonormalised panel(s),
+        # a-posteriori guard max|X^T M X - I| of the Ritz block(s) formed since the last status
+        self.status = torch.zeros((5,), dtype=torch.float64, device=device)
         self.cond = torch.zeros((B,), dtype=dtype, device=device)
+        self.orth = torch.zeros((B,), dtype=dtype, device=device)
+        self.MXtmp = z(B, p, Npad) if opM is not None else None
         self.adaptive = False                     # orth_passes="auto": one pass until a panel's condition estimate says no
         self.passes_now = 2                       # (the first panel is orthonormalised with two)
         self.two_pass_from = None
@@ -297,13 +301,15 @@ class _Group:
         if fused_status:
             # rotation + residual + status in one C call; rmax comes back zeroed for the next step
             K.davidson_ritz(self.Vs, self.AVs, Y, lam, X, self.newpanel, self.rmax, self.info, tri_flag, self.status,
-                            k, p, cond=self.cond)
+                            k, p, cond=self.cond, orth=self.orth)
         elif self.opM is None:
             K.ritz_residual(self.Vs, self.AVs, Y, lam, X, self.newpanel, self.rmax, k, p)
+            K.ritz_guard(X, self.orth, p, self.Npad)
         else:
             # residual A X - lam (M X): rotate M V instead of V, then the eigenvectors separately
-            K.ritz_residual(self.MVs, self.AVs, Y, lam, X, self.newpanel, self.rmax, k, p)
+            K.ritz_residual(self.MVs, self.AVs, Y, lam, self.MXtmp, self.newpanel, self.rmax, k, p)
             K.lincomb(self.Vs, Y, X, k, p, coef_layout="ac", alpha=1.0, beta=0.0)
+            K.ritz_guard(X, self.orth, p, self.Npad, MX=self.MXtmp)
         if self.precond is not None:
             # (extension) preconditioned correction t = K^-1 (-resid); the residual test above is unaffected
             if self.precond[0] == "diag":
@@ -314,7 +320,7 @@ class _Group:
                 self.newpanel.copy_(tmp)
         self.lam = lam
         if not fused_status:
-            K.group_status(self.rmax, self.info, tri_flag, self.status)
+            K.group_status(self.rmax, self.info, tri_flag, self.status, orth=self.orth)
         end_ritz()
 
     def compress(self):
@@ -334,14 +340,69 @@ class _Group:
             buf[:, :pk].copy_(tmp)
         self.T.zero_()
         self.T[:, :pk, :pk] = torch.diag_embed(lam_all)
+        # the kept Ritz block becomes the basis and T its diagonal: only true if the block is (M-)orthonormal — the same
+        # a-posteriori guard as for a returned block, folded into the next status read
+        K.ritz_guard(self.Vs, self.orth, pk, self.Npad, MX=self.MVs)
         self.k = pk
         self.nrestart += 1
+
+    def rollback(self, k_good, passes):
+        """Guard failure: back to the last basis width whose Ritz block passed (the basis is append-only between thick
+        restarts, so rows [0, k_good) of V, A V, M V and the leading block of T are exactly that basis), the rest of the
+        run on `passes` re-orthogonalised projection passes."""
+        self.k = k_good
+        self._compress = None
+        self._orth_done = False
+        self.adaptive = False
+        self.orth_passes = max(int(self.orth_passes), int(passes))
+        self.info.zero_()
+        self.cond.zero_()
+        self.orth.zero_()
+        self.best_slot, self.best_evals = -1, None
+        self.reorthonormalise(k_good)
+
+    def reorthonormalise(self, k):
+        """What the reference does every iteration — CholeskyQR of the WHOLE basis (tallqr, _utils/tensor.py:8-19,
+        symeig.py:207-223) — done once, after a guard failure, on the basis the run returns to: block Gram-Schmidt with
+        re-orthogonalisation over the first k vectors, panel by panel ([projection against the panels before it,
+        CholeskyQR], twice, the first CholeskyQR shifted).  The products A V and M V receive the same linear
+        transformations (no operator apply), then T = V^T A V is rebuilt whole.  The basis a roll-back returns to
+        passed the guard only in the directions of its Ritz block; without this step what it has lost elsewhere stays
+        (measured: a residual floor of |A| times the loss, the run then grows to the full space)."""
+        N, B = self.N, self.B
+        bufs = [b for b in (self.Vs, self.AVs, self.MVs) if b is not None]
+        coef_basis = self.Vs if self.opM is None else self.MVs
+        u = 1.1102230246251565e-16 if self.dtype == torch.float64 else 5.9604644775390625e-08
+        k0 = 0
+        while k0 < k:
+            q = min(self.p if k0 > 0 else max(self.nguess0, 1), 32, k - k0)
+            panel = self.Vs[:, k0:k0 + q]
+            for it in range(2):
+                if k0 > 0:
+                    C = _gram(coef_basis, k0, panel, q, N)                  # C[b,c,a] = <(M)V_a, t_c>
+                    for buf in bufs:
+                        K.lincomb(buf, C, buf[:, k0:k0 + q], k0, q, coef_layout="ca", alpha=-1.0, beta=1.0)
+                Mp = panel if self.opM is None else self.MVs[:, k0:k0 + q]
+                G = K.dense_mm(panel[:, :, :N], Mp[:, :, :N])
+                G = (G + G.transpose(1, 2)) * 0.5
+                if it == 0:
+                    sh = min(1e-3, 11.0 * (float(N) * q + float(q) * (q + 1)) * u)
+                    tr = torch.diagonal(G, dim1=-2, dim2=-1).sum(-1)
+                    G = G + (sh * tr)[:, None, None] * torch.eye(q, dtype=G.dtype, device=G.device)
+                Wq = torch.empty((B, q, q), dtype=self.dtype, device=self.device)
+                K.panel_chol(G.contiguous(), Wq, self.info, q)
+                for buf in bufs:
+                    K.panel_transform(buf[:, k0:k0 + q], Wq, q)
+            k0 += q
+        Tn = K.dense_mm(self.Vs[:, :k, :N], self.AVs[:, :k, :N], wide=False)   # Tn[b,c,a] = <V_a, (A V)_c>
+        self.T[:, :k, :k] = (Tn + Tn.transpose(1, 2)) * 0.5
 
     def expand_orth(self):
         """First half of the expansion: (thick restart if due,) the residual panel of the last Rayleigh-Ritz step is
         orthonormalised against the basis.  Cheap and free of side effects beyond basis rows >= k, so the driver
         enqueues it BEFORE it reads the step's status: the host round trip (status -> decision -> next launches)
-        then runs under these kernels instead of leaving the GPU idle.  `undo_orth` takes it back."""
+        then runs under these kernels instead of leaving the GPU idle (a step that is repeated — K3 fallback, guard
+        roll-back — simply overwrites these rows)."""
         restarted = self._compress is not None
         if restarted:
             self.compress()
@@ -389,6 +450,13 @@ class _Group:
             self.two_pass_from = it
         elif self.adaptive and self.two_pass_from is None and self.passes_now == 2 and cond2 <= limit and it >= 1:
             self.passes_now = 1                   # the start block and the first panel were benign: fast order
+
+    def distrust(self, it):
+        """the guard is above its 'good' level: no more one-pass panels in this run"""
+        if self.adaptive and self.passes_now == 1:
+            self.passes_now = 2
+        if self.adaptive and self.two_pass_from is None:
+            self.two_pass_from = it
 
     def speculate_orth(self):
         """expand_orth ahead of the status read — unless the step is not repeatable afterwards (a pending thick
@@ -453,10 +521,55 @@ def _sub_operator(A, B, N, b0, b1):
     return sub
 
 
+class _GuardFailure(RuntimeError):
+    """the a-posteriori guard failed and the run cannot be rolled back to a basis that passed it"""
+
+
+# A-posteriori guard on every Rayleigh-Ritz block, g = max|X^T M X - I| over the batch (status[4]):
+#   g <= GOOD            the basis width of this step becomes the roll-back point
+#   GOOD < g <= BAD      the rest of the run takes two projection passes (nothing is undone)
+#   g > BAD (or NaN)     the step is void: never a best / converged iterate; the run goes back to the last roll-back
+#                        point with re-orthogonalised passes (trace["orth_redo"]); with none left it is repeated from the
+#                        start block with three passes, and if that fails too an error is raised
+#                        point — whose basis is re-orthonormalised as a whole, like the reference does every iteration —
+# Healthy runs measure 1e-15 .. 1.3e-12 (fp64) / 1e-6 .. 1e-5 (fp32) (profiles/r04_guard_scan.jsonl); two copies of one
+# eigenpair give 1.
+GUARD_GOOD = {torch.float64: 1e-10, torch.float32: 5e-5}
+GUARD_BAD = {torch.float64: 1e-8, torch.float32: 5e-4}
+GUARD_MAX_REDO = 3
+
+
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
              groups="auto", chain="calls", **unused):
+    """Block Davidson on the HIP kernels; see `_davidson` for the options.  This wrapper is the last line of the
+    a-posteriori guard: a run whose Ritz blocks fail it and that cannot be rolled back (thick restarts rewrite the
+    basis) is repeated once from the start block with three re-orthogonalised projection passes; a second failure
+    raises — a block that fails the guard is never returned."""
+    kw = dict(M=M, max_niter=max_niter, nguess=nguess, v_init=v_init, max_addition=max_addition, min_eps=min_eps,
+              verbose=verbose, V0=V0, process_group=process_group, trace=trace, rng_device=rng_device,
+              small_eigh=small_eigh, overlap=overlap, precond=precond, reserve_cus=reserve_cus, restart=restart,
+              groups=groups, chain=chain, **unused)
+    try:
+        return _davidson(A, neig, mode, orth_passes=orth_passes, **kw)
+    except _GuardFailure as err:
+        if isinstance(orth_passes, int) and orth_passes >= 3:
+            raise RuntimeError("xitorch_amd davidson: %s" % err)
+        first = dict(trace) if trace is not None else None
+        try:
+            res = _davidson(A, neig, mode, orth_passes=3, **kw)
+        except _GuardFailure as err2:
+            raise RuntimeError("xitorch_amd davidson: %s (also with three orthogonalisation passes)" % err2)
+        if trace is not None:
+            trace["orth_rerun"] = {"reason": str(err), "first_run": {k: first.get(k) for k in ("niter", "orth_redo")}}
+        return res
+
+
+def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
+              min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
+              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
+              groups="auto", chain="calls", **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -485,10 +598,10 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         (extension) ``"native"`` (default): the wanted eigenpairs of the Rayleigh–Ritz matrix come from native
         kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
         iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
-        flags a result; from 129 to 640 vectors (448 for fewer than 16 batch members per group) the same route with
-        the matrix in global memory (K3g: 2x faster than the library at order 192-256, level with it around 500,
-        measured; fallback: the library);
-        ``torch.linalg.eigh`` beyond that and for more than 16 wanted pairs; ``"jacobi"`` / ``"tri"`` force one of
+        flags a result; from 129 to 768 vectors, or 17 to 64 wanted / kept pairs at any order, the same route with
+        the matrix in global memory (K3g, one launch per Householder step over several workgroups per matrix: 2.4x
+        the library at order 582, measured; fallback: the library);
+        ``torch.linalg.eigh`` beyond 768 vectors or 64 pairs; ``"jacobi"`` / ``"tri"`` force one of
         the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
@@ -537,8 +650,11 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         (xk_chain.hip) — except that blocks of up to 8 vectors take ONE pass while the fused CholeskyQR kernel's
         condition estimate (squared pivot ratio, read with the iteration's status) stays below 1e4; the first panel
         that exceeds it puts the rest of the run on two passes (``trace["orth_two_pass_from"]``).  With a
-        preconditioner, ``restart=``, ``M`` or ``chain="kernels"``: always two.  An integer forces the number of passes
-        (1 = one pass throughout; not checked).
+        preconditioner, ``restart=``, ``M`` or ``chain="kernels"``: always two.  An integer forces the number of passes.
+        Whatever the setting, every Rayleigh–Ritz block is checked a posteriori (``max|X^T M X - I|``, one small kernel,
+        read with the iteration's status): a block above ``GUARD_BAD`` is never a best / converged iterate, the run goes
+        back to the last basis width whose block passed and continues with re-orthogonalised passes
+        (``trace["orth_redo"]``, ``trace["orth_guard_history"]``).
     process_group: torch.distributed group or None
         (extension) when given, the batch is sharded over the group's ranks and the stopping test
         uses the all-reduced (MAX) residual, so all ranks iterate in lock step (RCCL over xGMI)
@@ -665,12 +781,16 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     stop_reason = "max_niter"
     niter = 0
     distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
-    gstat = torch.zeros((4,), dtype=torch.float64, device=device) if distributed else None
+    gstat = torch.zeros((5,), dtype=torch.float64, device=device) if distributed else None
     n_fallback = [0]
     cond_hist = [[] for _ in range(G)]            # squared pivot ratio of each group's panels (status[3]), as read
+    guard_good, guard_bad = GUARD_GOOD[dtype], GUARD_BAD[dtype]
+    guard_hist, redo = [], []
+    k_good = groups[0].k                          # roll-back point: the start block (CholeskyQR2)
+    n_restart_seen = 0
     for it in range(max_niter):
         niter = it + 1
-        local_max, bad = 0.0, 0.0
+        local_max, bad, guard = 0.0, 0.0, 0.0
         deferred = []
         k_rr = groups[0].k                      # the basis width this iteration's Rayleigh-Ritz runs on (all groups)
         # Every group's Rayleigh-Ritz chain AND the orthonormalisation of its next block are enqueued before the host
@@ -689,19 +809,29 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                     groups[g].small()
                     groups[g].speculate_orth()
             with torch.cuda.stream(streams[g]):
-                st_g, bad_g, tri_g, cond_g = groups[g].status.tolist()   # host waits for THIS group's stream only
+                # host waits for THIS group's stream only
+                st_g, bad_g, tri_g, cond_g, orth_g = groups[g].status.tolist()
                 if tri_g != 0:
                     # the tridiagonalisation kernel's self-check failed for some member: same step on Jacobi (the
-                    # speculative orthonormalisation consumed its output: redo that too, it only touched rows >= k)
+                    # speculative orthonormalisation consumed its output: redo that too, it only touched rows >= k).
+                    # A flagged result may hold zero / non-finite eigenvectors; the speculative CholeskyQR of the panel
+                    # made from them then set the STICKY Cholesky flag (and cond / the guard) although the step that
+                    # counts is the repeated one: clear what the speculation left, unless it was set before
+                    if bad_g == 0:
+                        groups[g].info.zero_()
+                    groups[g].cond.zero_()
+                    groups[g].orth.zero_()
                     groups[g].small(force_jacobi=True)
                     groups[g].speculate_orth()
-                    st_g, bad_g, tri_g, cond_g = groups[g].status.tolist()
+                    st_g, bad_g, tri_g, cond_g, orth_g = groups[g].status.tolist()
                     n_fallback[0] += 1
                 groups[g].note_condition(cond_g, it)
                 cond_hist[g].append(cond_g)
             if st_g != st_g:
                 st_g = float("inf")
-            local_max, bad = max(local_max, st_g), max(bad, bad_g)
+            if orth_g != orth_g:
+                orth_g = float("inf")
+            local_max, bad, guard = max(local_max, st_g), max(bad, bad_g), max(guard, orth_g)
             # a local residual above the threshold already rules out global convergence (the global value is the max
             # over groups and ranks): the panel product of this group — and of the ones deferred so far — is certain
             if local_max >= min_eps and bad == 0 and k_rr < N:
@@ -718,12 +848,43 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                 # device, one all-reduce (MAX) over the ranks, one read
                 torch.amax(torch.stack([grp.status for grp in groups]), dim=0, out=gstat)
                 allreduce_max_(gstat, process_group)
-                max_resid, bad = gstat.tolist()[:2]
+                gl = gstat.tolist()
+                max_resid, bad, guard = gl[0], gl[1], gl[4]
             if max_resid != max_resid:
                 max_resid = float("inf")
-        if bad != 0:
-            raise RuntimeError("xitorch_amd davidson: the panel Gram matrix is not positive definite "
-                               "(linearly dependent guess/residual vectors)")
+            if guard != guard:
+                guard = float("inf")
+        guard_hist.append(guard)
+        if groups[0].nrestart != n_restart_seen:        # a thick restart rewrote the basis since the last step
+            n_restart_seen, k_good = groups[0].nrestart, None
+        if bad != 0 or guard > guard_bad:
+            # The basis lost its orthogonality (or a panel its rank).  The reference cannot get here: it
+            # re-orthonormalises the whole basis every iteration (tallqr of [V, t], _utils/tensor.py:8-19,
+            # symeig.py:207-223).  This step is void; every rank / group takes the same decision (the values are the
+            # all-reduced ones), so the groups stay in lock step.
+            if k_good is None or k_good >= k_rr or len(redo) >= GUARD_MAX_REDO:
+                if bad != 0 and not redo:
+                    raise RuntimeError("xitorch_amd davidson: the panel Gram matrix is not positive definite "
+                                       "(linearly dependent guess/residual vectors)")
+                if trace is not None:
+                    trace.update(niter=niter, orth_redo=redo, orth_guard_history=guard_hist)
+                raise _GuardFailure("the Ritz block lost its orthonormality (max|X^T M X - I| = %.2e at iteration %d, "
+                                    "basis of %d vectors) and no earlier basis is left to return to" % (guard, niter, k_rr))
+            redo.append({"iter": niter, "guard": guard, "chol_flag": bad, "k_from": k_rr, "k_to": k_good,
+                         "passes": 2 + len(redo)})
+            for g in range(G):
+                with torch.cuda.stream(streams[g]):
+                    groups[g].rollback(k_good, 2 + len(redo) - 1)
+            best_resid = float("inf")
+            history.append(max_resid)
+            if verbose:
+                print("Iter %3d (guess size: %d): guard %.2e: back to %d vectors" % (it + 1, k_rr, guard, k_good))
+            continue
+        if guard <= guard_good:
+            k_good = k_rr
+        else:
+            for grp in groups:
+                grp.distrust(it)
         history.append(max_resid)
         if verbose:
             print("Iter %3d (guess size: %d): resid: %.3e" % (it + 1, k_rr, max_resid))
@@ -759,10 +920,13 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
                      basis_size=groups[0].k, best_resid=best_resid, stop_reason=stop_reason, groups=G,
                      k3_fallbacks=n_fallback[0], restarts=groups[0].nrestart, panel_kernel=ops[0].last_kernel,
                      orth_two_pass_from=[grp.two_pass_from for grp in groups], orth_adaptive=bool(adaptive),
-                     orth_cond2_history=cond_hist)
+                     orth_cond2_history=cond_hist, orth_guard_history=guard_hist, orth_redo=redo)
     evals = evals.reshape(*bdims, p)
     evecs = Xall[:, :, :N].transpose(-2, -1).reshape(*bdims, N, p)
     return evals, evecs
+
+
+davidson.__doc__ = _davidson.__doc__ + "\n    (" + davidson.__doc__ + ")\n"
 
 
 def exacteig(A, neig, mode, M=None):
