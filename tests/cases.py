@@ -52,6 +52,37 @@ DAVIDSON_CASES_F32 = [
 ]
 
 
+# dense `exacteig` at the shapes of the reference's only benchmark harness (benchmarks/benchmarks_solve.py:37-59:
+# symeig(A, neig=10, mode="lowest") with method=None -> exacteig, n in {100, 350, 700}, create_random_square_matrix with
+# seed 123), both ends of the spectrum, with and without an overlap operator, and a batched case
+EXACTEIG_CASES = [
+    dict(name="n100_lowest10", n=100, batch=(), neig=10, mode="lowest", minmax=(-1.0, 1.0)),
+    dict(name="n350_lowest10", n=350, batch=(), neig=10, mode="lowest", minmax=(0.0, 1.0)),
+    dict(name="n700_lowest10", n=700, batch=(), neig=10, mode="lowest", minmax=(-1.0, 1.0)),
+    dict(name="n700_uppest10", n=700, batch=(), neig=10, mode="uppest", minmax=(0.2, 1.0)),
+    dict(name="n100_uppest10_M", n=100, batch=(), neig=10, mode="uppest", minmax=(-1.0, 1.0), M=True),
+    dict(name="n350_lowest10_M", n=350, batch=(), neig=10, mode="lowest", minmax=(0.5, 1.0), M=True),
+    dict(name="n700_lowest10_M", n=700, batch=(), neig=10, mode="lowest", minmax=(-1.0, 1.0), M=True),
+    dict(name="n120_b3_lowest4", n=120, batch=(3,), neig=4, mode="lowest", minmax=(-1.0, 1.0)),
+]
+
+
+def exacteig_inputs(case):
+    """(A, M) of an EXACTEIG case: the benchmark's matrix (batched cases: one seed per member), M SPD or None"""
+    n, batch = case["n"], tuple(case["batch"])
+    nb = 1
+    for d in batch:
+        nb *= d
+    mats = [random_symmetric(n, case["minmax"][0], case["minmax"][1], 123 + b) for b in range(nb)]
+    A = torch.stack(mats).reshape(*batch, n, n)
+    M = None
+    if case.get("M"):
+        g = torch.Generator().manual_seed(91 + n)
+        R2 = torch.rand((*batch, n, n), dtype=f64, generator=g)
+        M = 0.02 * (R2 + R2.transpose(-2, -1)) + torch.eye(n, dtype=f64)
+    return A, M
+
+
 def random_symmetric(n, min_eival, max_eival, seed):
     """Prescribed linspace spectrum in a seeded random orthogonal basis — restates what
     xitorch/_utils/tensor.py:46-76 (create_random_square_matrix, hermitian branch) computes."""

@@ -89,6 +89,28 @@ def save(name, **arrs):
     print("wrote", name, {k: tuple(np.shape(v)) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------- symeig / exacteig (dense)
+def gen_exacteig():
+    from xitorch._utils.tensor import create_random_square_matrix
+    for case in cases.EXACTEIG_CASES:
+        A, M = cases.exacteig_inputs(case)
+        if not case["batch"]:
+            # the input generator restates the reference's benchmark generator: same matrix
+            Aref = create_random_square_matrix(case["n"], is_hermitian=True, min_eival=case["minmax"][0],
+                                               max_eival=case["minmax"][1], seed=123)
+            exact(A, Aref.to(A.dtype), "exacteig %s input matrix" % case["name"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rA = xitorch.LinearOperator.m(A, is_hermitian=True)
+            rM = xitorch.LinearOperator.m(M, is_hermitian=True) if M is not None else None
+        ev_r, X_r = ref_symeig.exacteig(rA, case["neig"], case["mode"], rM)
+        ev_o, X_o = osym.exacteig(oops.DenseOp(A, True), case["neig"], case["mode"],
+                                  oops.DenseOp(M, True) if M is not None else None)
+        exact(ev_r, ev_o, "exacteig %s evals" % case["name"])
+        exact(X_r, X_o, "exacteig %s evecs" % case["name"])
+        save("exacteig_" + case["name"], evals=ev_r, X=X_r)
+
+
 # --------------------------------------------------------------------------- symeig / davidson
 def gen_davidson(only=None):
     for case in cases.DAVIDSON_CASES + cases.DAVIDSON_CASES_F32:
@@ -246,7 +268,9 @@ def gen_extra():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["davidson", "solve", "root", "extra"]
+    which = sys.argv[1:] or ["davidson", "exacteig", "solve", "root", "extra"]
+    if "exacteig" in which:
+        gen_exacteig()
     only = [w.split(":", 1)[1] for w in which if w.startswith("davidson:")]      # e.g. davidson:s1_900_b2_lowest8_f32
     if "davidson" in which or only:
         gen_davidson(only or None)

@@ -32,6 +32,19 @@ def test_oracle_davidson(case):
     assert (torch.matmul(mat, X) - MX * ev.unsqueeze(-2)).abs().max().item() <= 10 * case["min_eps"]
 
 
+@pytest.mark.parametrize("case", cases.EXACTEIG_CASES, ids=[c["name"] for c in cases.EXACTEIG_CASES])
+def test_oracle_exacteig(case):
+    # the dense method at the reference benchmark's shapes (benchmarks_solve.py:37-59), reference outputs as fixtures
+    gold = np.load(os.path.join(GOLD, "exacteig_%s.npz" % case["name"]))
+    A, M = cases.exacteig_inputs(case)
+    ev, X = osym.exacteig(oops.DenseOp(A, True), case["neig"], case["mode"], oops.DenseOp(M, True) if M is not None else None)
+    assert np.abs(ev.numpy() - gold["evals"]).max() <= 1e-12
+    MX = torch.matmul(M, X) if M is not None else X
+    assert (torch.matmul(A, X) - MX * ev.unsqueeze(-2)).abs().max().item() <= 1e-11
+    sig = torch.linalg.svdvals(torch.matmul(torch.from_numpy(gold["X"]).transpose(-2, -1), MX))
+    assert sig.min().item() >= 1 - 1e-10 and sig.max().item() <= 1 + 1e-10
+
+
 @pytest.mark.parametrize("case", cases.DAVIDSON_CASES_F32, ids=[c["name"] for c in cases.DAVIDSON_CASES_F32])
 def test_oracle_davidson_fp32_mixed_convergence(case):
     # fp32 reference golden (r04): on the generating machine the oracle is bit-equal to the reference (make_golden.py

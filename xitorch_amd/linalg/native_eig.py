@@ -32,7 +32,7 @@ from xitorch_amd._util import bcast_shape
 from xitorch_amd.linalg._panel import PanelOperator, pad_len
 from xitorch_amd.dist import allreduce_max_
 
-__all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend"]
+__all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend", "native_partial_eigh"]
 
 _PRELAUNCH = True          # enqueue the next group's chain early (module attribute: measurement scripts flip it for A/B)
 # largest basis the global-memory Rayleigh-Ritz solver (K3g, tridiagonalisation spread over several workgroups per
@@ -929,18 +929,97 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
 davidson.__doc__ = _davidson.__doc__ + "\n    (" + davidson.__doc__ + ")\n"
 
 
+# orders / widths the native dense eigensolvers serve (K3g: xk_eigh_big.hip; below 129 / 17 also the LDS kernels)
+EXACTEIG_NATIVE_MAX_N = K.SMALL_EIGH_BIG_MAX_K
+EXACTEIG_NATIVE_MAX_P = K.SMALL_EIGH_BIG_MAX_P
+
+
+def _native_dense_ok(mat, neig):
+    n = mat.shape[-1]
+    return (mat.is_cuda and mat.dtype in (torch.float64, torch.float32) and 8 <= n <= EXACTEIG_NATIVE_MAX_N
+            and 1 <= neig <= min(EXACTEIG_NATIVE_MAX_P, n) and mat.numel() > 0
+            and K.small_eigh_big_ok(n, neig, mat.dtype))
+
+
+def native_partial_eigh(mat, neig, mode):
+    """Lowest / uppermost ``neig`` eigenpairs of the dense symmetric matrices ``mat (*B, n, n)`` on the native HIP
+    eigensolvers — Householder tridiagonalisation, bisection, inverse iteration, back-transformation: K3t (LDS-resident,
+    n <= 128, neig <= 16) or K3g (global-memory work matrix, n <= 768, neig <= 64).  Only the wanted pairs are computed
+    (the reference's exacteig computes all n and slices, symeig.py:22-24,255-264).  Returns ``evals (*B, neig)``
+    ascending and ``evecs (*B, n, neig)``; members whose self-check flags the result are redone on
+    ``torch.linalg.eigh``."""
+    bdims, n = mat.shape[:-2], mat.shape[-1]
+    T = mat.reshape(-1, n, n)
+    if T.stride(-1) != 1:
+        T = T.contiguous()
+    upp = (mode != "lowest")
+    if n <= K.SMALL_EIGH_MAX_K and neig <= K.SMALL_EIGH_MAX_P and n >= K.SMALL_EIGH_TRI_MIN_K and \
+            K.small_eigh_tri_ok(n, neig, T.dtype):
+        lam, Yt, flag = K.small_eigh(T, n, neig, uppest=upp, method="tri")
+    else:
+        lam, Yt, flag = K.small_eigh_big(T, n, neig, uppest=upp)
+    X = Yt.transpose(1, 2)
+    if int(flag.max().item()) != 0:                   # (rare) self-check failed somewhere: those members on the library
+        bad = torch.nonzero(flag, as_tuple=False).flatten()
+        l2, U2 = torch.linalg.eigh(T[bad])
+        l2, U2 = take_eigpairs(l2, U2, neig, mode)
+        lam = lam.clone()
+        X = X.clone()
+        lam[bad], X[bad] = l2, U2
+    return lam.reshape(*bdims, neig), X.reshape(*bdims, n, neig)
+
+
+class _NativeEigh(torch.autograd.Function):
+    """``neig`` extreme eigenpairs of a dense symmetric matrix from the native HIP eigensolver, with the reference's
+    degeneracy-aware backward (degen_symeig, symeig.py:47-98).  The backward pass completes the eigenbasis with the
+    differentiable `_DegenEigh` (only there), expresses the incoming eigenvector gradient in that basis — X = U_sel R^T
+    with R = X^T U_sel, a signed permutation unless wanted eigenvalues coincide — and applies the same masked formula;
+    being built from differentiable torch ops on the saved INPUT it supports higher derivatives like the reference's."""
+
+    @staticmethod
+    def forward(ctx, A, neig, mode):
+        lam, X = native_partial_eigh(A.detach(), neig, mode)
+        ctx.save_for_backward(A, X)
+        ctx.neig, ctx.mode = neig, mode
+        return lam, X
+
+    @staticmethod
+    def backward(ctx, glam, gX):
+        A, X = ctx.saved_tensors
+        n, p = A.shape[-1], ctx.neig
+        lam_all, U = _DegenEigh.apply(A)
+        lo, hi = (0, p) if ctx.mode == "lowest" else (n - p, n)
+        pad = (lo, n - hi)
+        gl = torch.nn.functional.pad(glam, pad) if glam is not None else None
+        gU = None
+        if gX is not None:
+            R = torch.matmul(X.transpose(-2, -1), U[..., lo:hi]).detach()
+            gU = torch.nn.functional.pad(torch.matmul(gX, R), pad)
+        return _degen_eigh_backward(lam_all, U, gl, gU), None, None
+
+
 def exacteig(A, neig, mode, M=None):
-    """Eigendecomposition by building the full matrix (reference: exacteig, symeig.py:11-44).
-    A thin `torch.linalg.eigh` call (with the degeneracy-aware backward of `_DegenEigh`)."""
+    """Eigendecomposition by building the full matrix (reference: exacteig, symeig.py:11-44).  On a HIP device, for real
+    matrices of order 8 .. 768 and up to 64 wanted pairs — the reference's own benchmark shapes, n in {100, 350, 700} with
+    neig = 10 (benchmarks/benchmarks_solve.py:37-59) — the eigenpairs come from the native dense eigensolver
+    (`native_partial_eigh`: only the wanted pairs are computed); everything else (CPU tensors, complex Hermitian, larger
+    orders) is `torch.linalg.eigh` like the reference.  Both carry the degeneracy-aware backward of degen_symeig."""
     Amat = A.fullmatrix()
     if M is None:
+        if _native_dense_ok(Amat, neig):
+            return _NativeEigh.apply(Amat, neig, mode)
         evals, evecs = _DegenEigh.apply(Amat)
         return take_eigpairs(evals, evecs, neig, mode)
     L = torch.linalg.cholesky(M.fullmatrix())
     Linv = torch.inverse(L)
     LinvH = Linv.transpose(-2, -1).conj()
-    evals, evecs = _DegenEigh.apply(torch.matmul(Linv, torch.matmul(Amat, LinvH)))
-    evals, evecs = take_eigpairs(evals, evecs, neig, mode)
+    A2 = torch.matmul(Linv, torch.matmul(Amat, LinvH))
+    if _native_dense_ok(A2, neig):
+        A2 = (A2 + A2.transpose(-2, -1)) * 0.5          # (the kernels read one triangle: make both agree)
+        evals, evecs = _NativeEigh.apply(A2, neig, mode)
+    else:
+        evals, evecs = _DegenEigh.apply(A2)
+        evals, evecs = take_eigpairs(evals, evecs, neig, mode)
     return evals, torch.matmul(LinvH, evecs)
 
 
@@ -956,28 +1035,32 @@ class _DegenEigh(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, glam, gU):
-        import warnings
-        from xitorch_amd.debug import is_debug_enabled
-        from xitorch_amd._util import MathWarning
         lam, U = ctx.saved_tensors
-        UH = U.transpose(-2, -1).conj()
-        thresh = torch.finfo(lam.dtype).eps ** 0.6
-        if gU is not None:
-            gap = lam.unsqueeze(-2) - lam.unsqueeze(-1)
-            degen = torch.abs(gap) <= thresh
-            gap = gap.masked_fill(degen, float("inf"))
-            if is_debug_enabled():
-                xtg = UH @ gU
-                viol = (xtg - xtg.transpose(-2, -1).conj())[degen]
-                if not torch.allclose(viol, torch.zeros_like(viol)):
-                    warnings.warn(MathWarning(
-                        "Degeneracy appears but the loss function seem to depend strongly on the "
-                        "eigenvector. The gradient might be incorrect.\nEigenvalues:\n%s\nDegenerate map:\n%s\n"
-                        "Requirements (should be all 0s):\n%s" % (str(lam), str(degen), str(viol))))
-            inner = gap.pow(-1) * torch.matmul(UH, gU)
-            res = torch.matmul(U, torch.matmul(inner, UH))
-        else:
-            res = torch.zeros_like(U)
-        if glam is not None:
-            res = res + torch.matmul(U, glam.unsqueeze(-1) * UH)
-        return (res + res.transpose(-2, -1).conj()) * 0.5
+        return _degen_eigh_backward(lam, U, glam, gU)
+
+
+def _degen_eigh_backward(lam, U, glam, gU):
+    import warnings
+    from xitorch_amd.debug import is_debug_enabled
+    from xitorch_amd._util import MathWarning
+    UH = U.transpose(-2, -1).conj()
+    thresh = torch.finfo(lam.dtype).eps ** 0.6
+    if gU is not None:
+        gap = lam.unsqueeze(-2) - lam.unsqueeze(-1)
+        degen = torch.abs(gap) <= thresh
+        gap = gap.masked_fill(degen, float("inf"))
+        if is_debug_enabled():
+            xtg = UH @ gU
+            viol = (xtg - xtg.transpose(-2, -1).conj())[degen]
+            if not torch.allclose(viol, torch.zeros_like(viol)):
+                warnings.warn(MathWarning(
+                    "Degeneracy appears but the loss function seem to depend strongly on the "
+                    "eigenvector. The gradient might be incorrect.\nEigenvalues:\n%s\nDegenerate map:\n%s\n"
+                    "Requirements (should be all 0s):\n%s" % (str(lam), str(degen), str(viol))))
+        inner = gap.pow(-1) * torch.matmul(UH, gU)
+        res = torch.matmul(U, torch.matmul(inner, UH))
+    else:
+        res = torch.zeros_like(U)
+    if glam is not None:
+        res = res + torch.matmul(U, glam.unsqueeze(-1) * UH)
+    return (res + res.transpose(-2, -1).conj()) * 0.5
