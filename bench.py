@@ -66,6 +66,12 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run the launcher / process-group / timing / JSON plumbing of the N > 1 path on CPU "
                          "ranks over gloo with a tiny sharded stand-in step (no performance numbers)")
+    ap.add_argument("--config", default=None, choices=["c3", "c3g", "c4", "c5", "c5w"],
+                    help="one of the OTHER BASELINE.json configs as a bench line of the same shape (bench_secondary.py): "
+                         "c3 BiCGStab banded + implicit backward, c3g native GMRES on the same systems, c4 Broyden shard + "
+                         "implicit backward, c5 / c5w the fp32 N=32768 shard with a 6- / 16-column block")
+    ap.add_argument("--cfg-batch", type=int, default=0, help="--config: operators / systems per GPU (0 = the config's own)")
+    ap.add_argument("--gmres-restart", type=int, default=0, help="--config c3g: restarted GMRES(m) (0 = un-restarted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="4x4096", help="BxN of the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -411,6 +417,23 @@ def main():
 
     from xitorch_amd import LinearOperator, synthetic, kernels as XK
     from xitorch_amd.linalg import symeig
+
+    if args.config:
+        # one of the other BASELINE configs: same fences, same JSON shape, its own roofline (bench_secondary.py)
+        import bench_secondary
+
+        def cfg_fence():
+            if group is not None:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+        line = bench_secondary.run(args, dev, group, world, rank, cfg_fence, backend)
+        if rank == 0:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(line), flush=True)
+        if group is not None:
+            torch.distributed.destroy_process_group()
+        return
 
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     esize = 8 if args.dtype == "f64" else 4

@@ -1,0 +1,330 @@
+"""`python bench.py --config c3|c3g|c4|c5|c5w`: the other BASELINE.json configs as bench lines of the same JSON shape as
+the headline (`metric / value / unit / ms_per_step / roofline / check`), measured the same way: W untimed warm-up steps,
+exactly K timed steps between barrier + synchronize fences, the dominant kernel's launch duration from HIP events inside
+the timed region, `roofline.achieved` = SURVEY 8d's ALGORITHMIC bytes per launch / that duration.
+
+  c3   BASELINE configs[2]: linalg.solve, BiCGStab on the banded (bw = 127) operator, N = 65536, batch = 256, fp64, WITH
+       its implicit backward (adjoint BiCGStab + band gradient); dominant kernel: the banded apply,
+       bytes = B (2 hb + 1) N s + 2 B N c s per launch (solve.py:192-324, linalg/solve.py:119-222)
+  c3g  the same systems through the native GMRES (solve.py:326-433), forward only
+  c4   BASELINE configs[3], per-GPU shard: optimize.rootfinder Broyden on tanh(A y + 0.1) + y / 2, N = 8192, batch = 64,
+       fp64, implicit backward through linalg.solve; dominant kernel: the function evaluation's batched matvec,
+       bytes = B N^2 s per evaluation; Gm.mv of rank r moves 2 r L s + 2 L s (rootsolver.py:15-206, _jacobian.py:51-222)
+  c5   BASELINE configs[4], per-GPU shard: symeig davidson on 16 x 32768^2 fp32, 6-column block (K1s, triangle)
+  c5w  the same with the 16-column block BASELINE states ("MFMA A@V panel"): K1w on the matrix cores,
+       bytes = B N^2 s + 2 B N p s per launch
+
+With --gpus N each rank holds one shard (weak scaling) and the solvers exchange their few-byte global decisions through
+`process_group`; `value` counts the units of all ranks over the MAX time.
+"""
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+PEAK_HBM = 8000.0        # GB/s (MI355X_MICROARCH.md)
+PEAK_F32 = 157.3         # TFLOP/s dense fp32 MFMA
+
+
+def _avg_ms(events):
+    ms = [a.elapsed_time(b) for (a, b) in events]
+    return (sum(ms) / len(ms), len(ms)) if ms else (float("nan"), 0)
+
+
+def _timed(step, steps, warmup, fence, group, dev):
+    for _ in range(warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    marks, last = [], None
+    for _ in range(steps):
+        last = step(True)
+        marks.append(time.perf_counter())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+    step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)]
+    return elapsed, step_ms, last
+
+
+def _roofline(bytes_per_launch, avg_ms, nlaunch, kernel, extra=None):
+    ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms == avg_ms and avg_ms > 0 else None
+    r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": PEAK_HBM, "unit": "GB/s",
+         "frac": (ach / PEAK_HBM) if ach else None, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+         "avg_launch_ms": avg_ms, "launches_timed": nlaunch,
+         "timing": "HIP events around every launch of the kernel inside the timed region (the stream it runs on)"}
+    if extra:
+        r.update(extra)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------- c3 / c3g
+def _banded_problem(dev, B, N, hb, offset):
+    from xitorch_amd import synthetic as syn
+    import xitorch_amd as xa
+    band = syn.banded(B, N, hb=hb, device=dev, batch_offset=offset)
+    xs = syn.banded_rhs_solution(B, N, device=dev, batch_offset=offset)
+    with torch.no_grad():
+        rhs = xa.BandedLinearOperator(band).mm(xs)
+    return band, xs, rhs
+
+
+def config_c3(args, dev, group, world, rank, fence):
+    import xitorch_amd as xa
+    from xitorch_amd.linalg import solve
+    B, N, hb = args.cfg_batch or 256, 65536, 63
+    band, xs, rhs = _banded_problem(dev, B, N, hb, rank * B)
+    band.requires_grad_()
+    opts = dict(rtol=1e-10, atol=1e-12, posdef=True)
+    traces = []
+
+    def step(timed):
+        ev = []
+        tr = {"k1_events": ev if timed else None}
+        btr = {"k1_events": ev if timed else None}
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                 # a convergence warning would be a failed step
+            x = solve(xa.BandedLinearOperator(band), rhs, method="bicgstab", process_group=group, trace=tr,
+                      bck_options=dict(method="bicgstab", process_group=group, trace=btr, **opts), **opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            gband, = torch.autograd.grad(x.sum(), (band,))
+            torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if timed:
+            traces.append((tr, btr, ev, (t1 - t0) * 1e3, (t2 - t1) * 1e3, x.detach(), float(gband[0, hb, 0])))
+        del gband
+        return x.detach()
+    elapsed, step_ms, x = _timed(step, args.steps, args.warmup, fence, group, dev)
+    tr, btr, _, fwd_ms, bwd_ms, _, _ = traces[-1]
+    events = [(a, b) for t in traces for (a, b, pc, nb) in t[2]]
+    avg, nl = _avg_ms(events)
+    s, c = 8, 1
+    apply_bytes = B * (2 * hb + 1) * N * s + 2 * B * N * c * s
+    it_bytes = 2 * apply_bytes + 16 * B * N * c * s            # 2 applies + (10 reads + 6 writes) vectors
+    niter_f, niter_b = tr["niter"], btr.get("niter")
+    err = (x - xs).abs().max().item()
+    return {
+        "metric": "linear systems/s of linalg.solve(bicgstab) with implicit backward, banded bw=127 N=65536 batch=256 "
+                  "+ banded-apply GB/s (roofline.achieved)",
+        "value": B * world * args.steps / elapsed, "unit": "systems/s (forward + backward)",
+        "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64",
+        "config": {"workload": "BASELINE configs[2]: linalg.solve BiCGStab on banded (bw=127) N=65536 batch=%d (%d per "
+                               "GPU) fp64 with implicit backward (adjoint BiCGStab + band gradient), rtol=1e-10"
+                               % (B * world, B), "global_batch": B * world, "batch_per_gpu": B,
+                   "forward_ms": fwd_ms, "backward_ms": bwd_ms, "niter_forward": niter_f, "niter_backward": niter_b,
+                   "applies_forward": tr["napply"], "applies_backward": btr.get("napply"),
+                   "forward_only_systems_per_s": B * world / (fwd_ms * 1e-3)},
+        "roofline": _roofline(apply_bytes, avg, nl, "banded_mm_kernel (xk_banded_mm: A x and A^T x)", {
+            "bicgstab_iteration": {"algorithmic_bytes": it_bytes, "achieved_GBps_forward":
+                                   it_bytes * niter_f / (fwd_ms * 1e-3) / 1e9,
+                                   "frac_forward": it_bytes * niter_f / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM,
+                                   "note": "2 applies + (10 reads + 6 writes) of B x N vectors per iteration (SURVEY 8d) "
+                                           "over the whole forward solve, host syncs and set-up included"}}),
+        "check": {"ok": bool(err < 1e-7), "max_err_vs_manufactured_solution": err,
+                  "tolerance": "1e-7 absolute on |x*| <= 1 (rtol 1e-10 times the condition number)"},
+        "step_ms": step_ms,
+    }
+
+
+def config_c3g(args, dev, group, world, rank, fence):
+    import xitorch_amd as xa
+    from xitorch_amd.linalg import native_krylov as nk
+    B, N, hb = args.cfg_batch or 256, 65536, 63
+    m = 30 if not args.gmres_restart else max(args.max_niter, args.gmres_restart + 1)   # total Arnoldi steps allowed
+    band, xs, rhs = _banded_problem(dev, B, N, hb, rank * B)
+    A = xa.BandedLinearOperator(band)
+    traces = []
+
+    def step(timed):
+        ev = []
+        tr = {"k1_events": ev if timed else None}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                # (30 un-restarted steps stop at ~7e-7: reported, not hidden)
+            x = nk.gmres(A, rhs, rtol=1e-10, atol=1e-12, posdef=True, max_niter=m, process_group=group, trace=tr,
+                         **({"restart": args.gmres_restart} if args.gmres_restart else {}))
+        if timed:
+            traces.append((tr, ev))
+        return x
+    elapsed, step_ms, x = _timed(step, args.steps, args.warmup, fence, group, dev)
+    tr = traces[-1][0]
+    events = [(a, b) for t in traces for (a, b, pc, nb) in t[1]]
+    avg, nl = _avg_ms(events)
+    apply_bytes = B * (2 * hb + 1) * N * 8 + 2 * B * N * 8
+    err = (x - xs).abs().max().item()
+    return {
+        "metric": "linear systems/s of native gmres (max_niter=%d), banded bw=127 N=65536 batch=256 + banded-apply GB/s" % m,
+        "value": B * world * args.steps / elapsed, "unit": "systems/s", "ms_per_step": elapsed / args.steps * 1e3,
+        "dtype": "f64",
+        "config": {"workload": "BASELINE configs[2]'s systems through gmres (solve.py:326-433), reference semantics "
+                               "(true residual every iteration), max_niter=%d%s" %
+                               (m, (", restart=%d" % args.gmres_restart) if args.gmres_restart else ""),
+                   "global_batch": B * world, "batch_per_gpu": B, "arnoldi_steps": tr.get("arnoldi_steps"),
+                   "applies": tr["napply"], "host_syncs": tr.get("host_syncs"), "converged": tr["converged"],
+                   "best_resid": tr["best_resid"]},
+        "roofline": _roofline(apply_bytes, avg, nl, "banded_mm_kernel (xk_banded_mm)"),
+        "check": {"ok": bool(err < 1e-4), "max_err_vs_manufactured_solution": err, "converged": tr["converged"]},
+        "step_ms": step_ms,
+    }
+
+
+# ------------------------------------------------------------------------------------------------- c4
+def config_c4(args, dev, group, world, rank, fence):
+    import xitorch_amd as xa
+    from xitorch_amd import synthetic as syn
+    from xitorch_amd.optimize import rootfinder
+    B, N = args.cfg_batch or 64, 8192
+    A = syn.root_matrix(B, N, device=dev, batch_offset=rank * B) * 2.0
+    y0 = torch.zeros(B, N, dtype=torch.float64, device=dev)
+    mv_events = []
+    record = [False]
+
+    def fcn(y, A_):
+        op = xa.LinearOperator.m(A_, is_hermitian=False)
+        if record[0] and not torch.is_grad_enabled():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            z = op.mv(y)
+            e1.record()
+            mv_events.append((e0, e1))
+        else:
+            z = op.mv(y)
+        return torch.tanh(z + 0.1) + y / 2.0
+    Ad = A.clone().requires_grad_()
+    traces = []
+
+    def step(timed):
+        record[0] = timed
+        tr = {}
+        t0 = time.perf_counter()
+        y = rootfinder(fcn, y0, params=(Ad,), method="broyden1", alpha=-1.0, max_rank=32, f_tol=1e-8,
+                       process_group=group, trace=tr,
+                       bck_options=dict(method="bicgstab", posdef=True, rtol=1e-10, process_group=group))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g, = torch.autograd.grad(y.sum(), (Ad,))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        record[0] = False
+        if timed:
+            traces.append((tr, (t1 - t0) * 1e3, (t2 - t1) * 1e3, float(g[0, 0, 0])))
+        del g
+        return y.detach()
+    elapsed, step_ms, y = _timed(step, args.steps, args.warmup, fence, group, dev)
+    tr, fwd_ms, bwd_ms, _ = traces[-1]
+    avg, nl = _avg_ms(mv_events)
+    s = 8
+    fcn_bytes = B * N * N * s + 2 * B * N * s
+    r = tr.get("rank") or 0
+    L = B * N
+    with torch.no_grad():
+        fn = fcn(y, A).norm().item()
+    return {
+        "metric": "batch members/s of optimize.rootfinder(broyden1) + implicit backward, tanh(A y) N=8192 "
+                  "+ function-evaluation matvec GB/s (roofline.achieved)",
+        "value": B * world * args.steps / elapsed, "unit": "members/s (forward + backward)",
+        "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64",
+        "config": {"workload": "BASELINE configs[3] per-GPU shard: rootfinder broyden1 on tanh(A y + 0.1) + y/2, N=8192 "
+                               "batch=%d (%d per GPU) fp64, alpha=-1, max_rank=32, f_tol=1e-8; backward: implicit, "
+                               "linalg.solve bicgstab rtol=1e-10" % (B * world, B),
+                   "global_batch": B * world, "batch_per_gpu": B, "forward_ms": fwd_ms, "backward_ms": bwd_ms,
+                   "nfev": tr.get("nfev"), "niter": tr.get("niter"), "rank": r,
+                   "host_syncs_forward": tr.get("host_syncs", tr.get("nfev")),
+                   "Gm_mv_algorithmic_bytes_at_final_rank": 2 * r * L * s + 2 * L * s},
+        "roofline": _roofline(fcn_bytes, avg, nl, "dense_mm_rows<double,1> (xk_dense_mm: the evaluation's A_b y_b)"),
+        "check": {"ok": bool(fn < 1e-6 * (B ** 0.5)), "fnorm_at_returned_root": fn,
+                  "note": "the returned iterate is the one BEFORE the converged one (quirk Q1): |f| slightly above f_tol"},
+        "step_ms": step_ms,
+    }
+
+
+# ------------------------------------------------------------------------------------------------- c5 / c5w
+def _config_c5(args, dev, group, world, rank, fence, p, label):
+    import xitorch_amd as xa
+    from xitorch_amd import synthetic as syn, kernels as XK
+    from xitorch_amd.linalg import symeig
+    B, N = args.cfg_batch or 16, 32768
+    kind = "S1" if p <= 6 else "S1:%d" % p
+    mat = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    syn.dense_symmetric(B, N, kind, dtype=torch.float32, device=dev, out=mat, batch_offset=rank * B)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    exact = syn.spectrum(kind, N, device=dev)[:p]
+    traces = []
+    XK.prefill_timing_events(2 * 40 * (args.steps + 1))
+
+    def step(timed):
+        ev = []
+        tr = {"k1_events": ev if timed else None}
+        with torch.no_grad():
+            evals, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=2e-3, rng_device="device",
+                              max_niter=60, process_group=group, trace=tr)
+        if timed:
+            traces.append((tr, ev))
+        return evals, X
+    elapsed, step_ms, (evals, X) = _timed(step, args.steps, args.warmup, fence, group, dev)
+    tr = traces[-1][0]
+    events = [(a, b) for t in traces for (a, b, pc, nb) in t[1] if pc == p]
+    nbl = [nb for t in traces for (a, b, pc, nb) in t[1] if pc == p][0]
+    avg, nl = _avg_ms(events)
+    s = 4
+    symm = tr.get("panel_kernel") == "K1s"
+    full_bytes = nbl * N * N * s + 2 * nbl * N * p * s
+    tri_bytes = nbl * N * (N + 1) // 2 * s + 2 * nbl * N * p * s
+    flops = 2.0 * nbl * N * N * p
+    err = (evals.double() - exact).abs().max().item()
+    extra = {"operators_per_launch": nbl, "TFLOPs": flops / (avg * 1e-3) / 1e12,
+             "frac_of_fp32_matrix_peak": flops / (avg * 1e-3) / 1e12 / PEAK_F32,
+             "full_matrix_equivalent_GBps": full_bytes / (avg * 1e-3) / 1e9}
+    if symm:
+        extra["priced_on"] = "the bytes the kernel must move: upper triangle + panels (the operator is exactly symmetric)"
+    return {
+        "metric": "eigpairs/s of symeig(davidson) fp32 N=32768 (per-GPU shard of batch 128) + panel-product GB/s",
+        "value": B * world * p * args.steps / elapsed, "unit": "eigpairs/s", "ms_per_step": elapsed / args.steps * 1e3,
+        "dtype": "f32",
+        "config": {"workload": "BASELINE configs[4] per-GPU shard: linalg.symeig davidson lowest-%d on "
+                               "MatrixLinearOperator N=32768 batch=%d (%d per GPU) fp32, %s, min_eps=2e-3"
+                               % (p, B * world, B, label), "global_batch": B * world, "batch_per_gpu": B,
+                   "iterations_per_step": tr["niter"], "panel_products_per_step": tr["napply"],
+                   "panel_kernel": tr.get("panel_kernel"), "batch_groups": tr.get("groups"),
+                   "orth_redo": tr.get("orth_redo")},
+        "roofline": _roofline(tri_bytes if symm else full_bytes, avg, nl,
+                              "dense_symm_tiles<float,6> (K1s)" if symm else
+                              "dense_wide_cols<float,1,Mfma16f> (K1w, v_mfma_f32_16x16x4_f32)", extra),
+        "check": {"ok": bool(err < 5e-4), "max_eval_err_vs_closed_form": err,
+                  "tolerance": "5e-4 absolute on a spectrum of scale 100 in fp32 (eps32 |A| ~ 1e-5, resid^2 / gap)"},
+        "step_ms": step_ms,
+    }
+
+
+def config_c5(args, dev, group, world, rank, fence):
+    return _config_c5(args, dev, group, world, rank, fence, 6, "6-column eigen-block (upper-triangle kernel K1s)")
+
+
+def config_c5w(args, dev, group, world, rank, fence):
+    return _config_c5(args, dev, group, world, rank, fence, 16,
+                      "16-column eigen-block on the matrix cores (K1w), as BASELINE states the config")
+
+
+CONFIGS = {"c3": config_c3, "c3g": config_c3g, "c4": config_c4, "c5": config_c5, "c5w": config_c5w}
+
+
+def run(args, dev, group, world, rank, fence, backend):
+    out = CONFIGS[args.config](args, dev, group, world, rank, fence)
+    out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+    out["config"]["parallelism"] = "batch-sharded x%d (weak: one shard per GPU)" % world
+    out["config"]["comm_backend"] = backend
+    order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "check", "step_ms"]
+    return {k: out[k] for k in order if k in out}
+
+
+if __name__ == "__main__":
+    sys.exit("run through bench.py: python bench.py --config c3|c3g|c4|c5|c5w")

@@ -255,3 +255,36 @@ def test_gmres_device_state_semantics(dev):
                   posdef=True).cpu()
     assert torch.isfinite(Xd).all()
     assert (D @ Xd - Bd).norm().item() <= 1e-9
+
+
+def test_gmres_restarted_cycles_reach_a_tight_tolerance(dev):
+    """(r04, extension) GMRES(m): cycles of m Arnoldi steps restarted from the true residual, the reference's stopping
+    and best-iterate rules across the cycles (reference: un-restarted only, solve.py:384-389).  A restart length the run
+    never reaches leaves the un-restarted path bit for bit."""
+    from xitorch_amd.linalg import native_krylov as nk
+    g = torch.Generator().manual_seed(21)
+    Bn, N, nc = 2, 300, 2
+    R = torch.randn(Bn, N, N, dtype=torch.float64, generator=g) / N ** 0.5
+    Am = (0.9 * R + 2.0 * torch.eye(N, dtype=torch.float64)).to(dev)
+    rhs = torch.randn(Bn, N, nc, dtype=torch.float64, generator=g).to(dev)
+    A = xa.LinearOperator.m(Am, is_hermitian=False)
+    Xref = torch.linalg.solve(Am, rhs)
+    tr0, tr1, tr2 = {}, {}, {}
+    X0 = nk.gmres(A, rhs, rtol=1e-10, atol=1e-12, max_niter=200, trace=tr0)
+    assert tr0["converged"] and tr0["restarts"] == 0
+    X1 = nk.gmres(A, rhs, rtol=1e-10, atol=1e-12, max_niter=2000, restart=8, trace=tr1)
+    assert tr1["converged"] and tr1["restarts"] >= 2 and tr1["arnoldi_steps"] >= tr0["arnoldi_steps"]
+    assert ((X1 - Xref).norm() / Xref.norm()).item() <= 1e-8
+    # every cycle but the last has exactly 8 steps: restarts = floor((steps - 1) / 8)
+    assert tr1["restarts"] == (tr1["arnoldi_steps"] - 1) // 8
+    X2 = nk.gmres(A, rhs, rtol=1e-10, atol=1e-12, max_niter=200, restart=150, trace=tr2)
+    assert tr2["restarts"] == 0 and tr2["arnoldi_steps"] == tr0["arnoldi_steps"] and torch.equal(X2, X0)
+    # not converging within max_niter: warning + the best iterate over all cycles
+    with pytest.warns(xa.ConvergenceWarning if hasattr(xa, "ConvergenceWarning") else Warning):
+        tr3 = {}
+        X3 = nk.gmres(A, rhs, rtol=1e-14, atol=1e-16, max_niter=20, restart=4, trace=tr3)
+    assert not tr3["converged"] and tr3["restarts"] == 4
+    r3 = (Am @ X3 - rhs).norm(dim=-2).max().item()
+    assert abs(r3 - tr3["best_resid"]) <= 1e-9 * max(1.0, r3)
+    with pytest.raises(Exception):
+        nk.gmres(A, rhs, restart=0)

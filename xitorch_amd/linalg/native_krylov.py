@@ -360,6 +360,8 @@ def bicgstab(A, B, E=None, M=None, posdef=None, precond_l=None, precond_r=None, 
     if all_ranks_agree_true(torch.allclose(B, B * 0, rtol=rtol, atol=atol), B.device, process_group):
         return _zeros_like_solution(A, B, bdims)
     prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=False)
+    if trace is not None and trace.get("k1_events") is not None:
+        prob.opA.events = trace["k1_events"]          # measurement: HIP events around every operator apply
     kr = _Kry(prob)
     pl, pr = _precond(precond_l, prob), _precond(precond_r, prob)
     stop = _stop_vector(prob, rtol, atol)
@@ -457,6 +459,8 @@ def cg(A, B, E=None, M=None, posdef=None, precond=None, max_niter=None, rtol=1e-
     if all_ranks_agree_true(torch.allclose(B, B * 0, rtol=rtol, atol=atol), B.device, process_group):
         return _zeros_like_solution(A, B, bdims)
     prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=True)
+    if trace is not None and trace.get("k1_events") is not None:
+        prob.opA.events = trace["k1_events"]          # measurement: HIP events around every operator apply
     kr = _Kry(prob)
     pre = _precond(precond, prob)
     stop = _stop_vector(prob, rtol, atol)
@@ -530,7 +534,7 @@ class _GmresState:
 
 
 def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-8, eps=1e-12,
-          resid_calc_every=1, process_group=None, trace=None, **unused):
+          resid_calc_every=1, restart=None, process_group=None, trace=None, **unused):
     r"""
     Solve the linear equations using the Generalised minimal residual method on HIP kernels
     (reference: gmres, xitorch/_impls/linalg/solve.py:326-433; real operators only, like the reference's).
@@ -567,6 +571,13 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
         says that every system has converged (one more operator apply and one pass over the basis saved per skipped
         iteration; stopping decisions are still taken on true residuals only, best-iterate tracking sees the
         checked iterates).
+    restart: int or None
+        (extension) ``None`` (default): un-restarted, like the reference, whose Krylov basis grows until ``max_niter``
+        (solve.py:384-389: it preallocates ``max_niter`` vectors).  An integer ``m``: GMRES(m) — after ``m`` Arnoldi steps
+        the iterate and its true residual are formed, the basis is dropped and the next cycle starts from that residual
+        (memory ``m + 1`` vectors per system instead of ``max_niter``; lets systems that need more steps than fit
+        reach a tight ``rtol``).  Stopping rule and best-iterate rule are unchanged and run across the cycles; ``max_niter``
+        bounds the total number of steps.
     process_group: torch.distributed group or None
         (extension) batch-sharded multi-GPU run: the stopping test is all-reduced over the group
 
@@ -585,6 +596,8 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
     if all_ranks_agree_true(torch.allclose(B, B * 0, rtol=rtol, atol=atol), B.device, process_group):
         return _zeros_like_solution(A, B, bdims)
     prob = _Problem(A, B, E, M, bdims, posdef, need_hermit=False)
+    if trace is not None and trace.get("k1_events") is not None:
+        prob.opA.events = trace["k1_events"]          # measurement: HIP events around every operator apply
     kr = _Kry(prob)
     S, N, ld = prob.S, prob.N, prob.ld
     dtype, dev = prob.dtype, prob.device
@@ -592,15 +605,27 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
     stop = _stop_vector(prob, rtol, atol)
     every = max(1, int(resid_calc_every))
     msteps = min(nr, max_niter) - 1           # Arnoldi steps whose column enters an iterate (solve.py:389,403)
+    if restart is not None:
+        restart = int(restart)
+        if restart < 1:
+            raise ValueError("gmres: restart must be a positive number of Arnoldi steps, got %d" % restart)
+        msteps = max_niter - 1 if max_niter > 1 else 0      # (restarted: the total is not bounded by the order)
+    mcyc = msteps if restart is None else min(restart, max(msteps, 1))     # Arnoldi steps per cycle
+    if mcyc > 8192:
+        # (xk_gmres_solve keeps the least-squares solution of a system in LDS: at most 8192 basis vectors; the dense
+        #  Hessenberg of an un-restarted run would be 8 S k^2 bytes long before that)
+        raise NativeLibraryError("xitorch_amd gmres: a Krylov basis of %d vectors per system is not supported (limit "
+                                 "8192); pass max_niter <= 8193 or restart=m" % mcyc)
     rhs = prob.rhs.reshape(S, ld)
     beta = rhs.norm(dim=-1)                                                      # (S,)
     best = float(allreduce_max_(beta.max().double().reshape(1), process_group).item())      # solve.py:380-381
     xbufs = [torch.zeros((S, 1, ld), dtype=dtype, device=dev) for _ in range(2)]
     best_i, cur_i = 0, 1                      # xbufs[0] = x0 = 0 is the best iterate so far (:382)
     converged = False
-    nsteps, nsync = 0, 1
+    nsteps, nsync, ncycles = 0, 1, 0
     if msteps > 0:
-        cap = min(msteps + 1, 32)
+        cap = min(mcyc + 1, 32)
+        x_base = None                         # restarted cycles: the iterate the current cycle corrects
         Q = torch.zeros((S, cap, ld), dtype=dtype, device=dev)
         Q[:, 0] = rhs / torch.where(beta == 0, torch.full_like(beta, eps), beta).unsqueeze(-1)   # :385, _safedenom
         st = _GmresState(S, cap - 1, dev)
@@ -622,51 +647,57 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
                                               stream_ptr()), "xk_gmres_solve")
             x = xbufs[cur_i]
             K.lincomb(Q, ycoef, x, kd, 1, coef_layout="ca", alpha=1.0, beta=0.0)
+            if x_base is not None:
+                x.add_(x_base)
             prob.apply(x.reshape(prob.Bt, prob.nc, ld), tmp)
             kr.resid(prob.rhs, tmp, rtrue, None, Ptrue, None)
             status_of(Ptrue, kr.nblk, 1)
 
+        cyc0 = 0                              # global index of the current cycle's first Arnoldi step
         for k in range(msteps):
             nsteps = k + 1
-            if k + 2 > cap:                                           # grow the basis storage
-                newcap = min(msteps + 1, 2 * cap)
+            j = k - cyc0                                              # step index inside the cycle
+            if j + 2 > cap:                                           # grow the basis storage
+                newcap = min(mcyc + 1, 2 * cap)
                 Qn = torch.zeros((S, newcap, ld), dtype=dtype, device=dev)
                 Qn[:, :cap].copy_(Q)
                 Q, cap = Qn, newcap
                 ycoef = torch.zeros((S, 1, cap), dtype=dtype, device=dev)
-                st.grow(cap - 1, msteps)
-            # w = A q_k (solve.py:390) straight into basis row k+1; with a shift E the fused shift kernel wants
-            # contiguous (S, ld) arrays, so q_k / w pass through two contiguous buffers (O(N) copies)
+                st.grow(cap - 1, mcyc)
+            # w = A q_j (solve.py:390) straight into basis row j+1; with a shift E the fused shift kernel wants
+            # contiguous (S, ld) arrays, so q_j / w pass through two contiguous buffers (O(N) copies)
             if prob.E is None:
-                prob.apply(Q[:, k].reshape(prob.Bt, prob.nc, ld), Q[:, k + 1].reshape(prob.Bt, prob.nc, ld))
+                prob.apply(Q[:, j].reshape(prob.Bt, prob.nc, ld), Q[:, j + 1].reshape(prob.Bt, prob.nc, ld))
             else:
-                rtrue.reshape(S, ld).copy_(Q[:, k])
+                rtrue.reshape(S, ld).copy_(Q[:, j])
                 prob.apply(rtrue, tmp)
-                Q[:, k + 1].copy_(tmp.reshape(S, ld))
-            wrow = Q[:, k + 1:k + 2]
-            c1 = K.dense_mm(Q[:, :k + 1, :N], wrow[:, :, :N])                      # (S, 1, k+1): <q_j, w>
-            K.lincomb(Q, c1, wrow, k + 1, 1, coef_layout="ca", alpha=-1.0, beta=1.0)
-            c2n = K.dense_mm(Q[:, :k + 2, :N], wrow[:, :, :N])                     # second pass; last entry |w1|^2
-            check(fn("xk_gmres_step_" + sfx)(ptr(c1), c1.stride(0), ptr(c2n), c2n.stride(0), k, st.cap, ptr(st.R),
+                Q[:, j + 1].copy_(tmp.reshape(S, ld))
+            wrow = Q[:, j + 1:j + 2]
+            c1 = K.dense_mm(Q[:, :j + 1, :N], wrow[:, :, :N])                      # (S, 1, j+1): <q_i, w>
+            K.lincomb(Q, c1, wrow, j + 1, 1, coef_layout="ca", alpha=-1.0, beta=1.0)
+            c2n = K.dense_mm(Q[:, :j + 2, :N], wrow[:, :, :N])                     # second pass; last entry |w1|^2
+            check(fn("xk_gmres_step_" + sfx)(ptr(c1), c1.stride(0), ptr(c2n), c2n.stride(0), j, st.cap, ptr(st.R),
                                              ptr(st.cs), ptr(st.sn), ptr(st.g), ptr(inv_hn), ptr(Pest), S,
                                              stream_ptr()), "xk_gmres_step")
-            check(fn("xk_gmres_finish_" + sfx)(ptr(Q), ptr(c2n), c2n.stride(0), ptr(inv_hn), S, N, k, Q.stride(1),
+            check(fn("xk_gmres_finish_" + sfx)(ptr(Q), ptr(c2n), c2n.stride(0), ptr(inv_hn), S, N, j, Q.stride(1),
                                                Q.stride(0), stream_ptr()), "xk_gmres_finish")
             status_of(Pest, 1, 0)
-            checked = (k + 1) % every == 0 or k == msteps - 1
+            cycle_end = restart is not None and j + 1 == mcyc
+            checked = (k + 1) % every == 0 or k == msteps - 1 or cycle_end
             if checked:
-                true_residual(k + 1)
+                true_residual(j + 1)
             allreduce_max_(status4, process_group)
             est_mx, est_bad, tr_mx, tr_bad = status4.tolist()                      # the iteration's host read
             nsync += 1
             if not checked and est_bad == 0:
                 # the least-squares residual says every system is done: decide on the true residual, like the
                 # reference does every iteration; from here on every iterate is checked
-                true_residual(k + 1)
+                true_residual(j + 1)
                 allreduce_max_(status4, process_group)
                 est_mx, est_bad, tr_mx, tr_bad = status4.tolist()
                 nsync += 1
                 checked, every = True, 1
+            just = cur_i                                                            # buffer of the iterate just formed
             if checked:
                 if tr_mx < best:                                                    # solve.py:417-421
                     best = tr_mx
@@ -674,10 +705,23 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
                 if tr_bad == 0:                                                     # :423-425
                     converged = True
                     break
+            if cycle_end and k < msteps - 1:
+                # GMRES(m): the next cycle corrects the iterate just formed, starting from its TRUE residual
+                if x_base is None:
+                    x_base = torch.zeros((S, 1, ld), dtype=dtype, device=dev)
+                x_base.copy_(xbufs[just])
+                rcur = rtrue.reshape(S, ld)
+                beta = rcur.norm(dim=-1)
+                Q[:, 0] = rcur / torch.where(beta == 0, torch.full_like(beta, eps), beta).unsqueeze(-1)
+                for t in (st.R, st.cs, st.sn, st.g):
+                    t.zero_()
+                st.g[:, 0] = beta.double()
+                cyc0 = k + 1
+                ncycles += 1
     if trace is not None:
         # niter counts like the reference's loop: the pass that tests x_k is pass k + 1
         trace.update(niter=nsteps + 1, napply=prob.napply, converged=converged, best_resid=best, arnoldi_steps=nsteps,
-                     host_syncs=nsync)
+                     host_syncs=nsync, restarts=ncycles)
     if not converged:
         warnings.warn(ConvergenceWarning("Convergence is not achieved after %d iterations. "
                                          "Max norm of resid: %.3e" % (max_niter, best)))
