@@ -383,8 +383,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.k1s_run > 0:
-        from xitorch_amd._capi import fn as _fn
-        _fn("xk_dense_symm_tune")(1, args.k1s_run)
+        from xitorch_amd import kernels as _XK
+        _XK.K1S_OPTS = int(args.k1s_run) << 8       # column slabs per workgroup run (an argument of the K1s entry points)
     group, backend, rccl_world = None, None, 1
     # XITORCH_BENCH_FORCE_PG=1: create the RCCL process group even for one rank (smoke test of the N > 1 plumbing —
     # init, barrier, all-reduce of the timing — on a single-GPU box; the solver's own all-reduces need >= 2 ranks)

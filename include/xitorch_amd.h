@@ -15,7 +15,11 @@
  *    stream-ordered work; nothing is allocated on behalf of the caller — a
  *    `*_workspace_elems` query precedes calls that need scratch.
  *  - every launch goes to the `stream` argument (a hipStream_t passed as
- *    void*; NULL = the default stream).  No hidden global state.
+ *    void*; NULL = the default stream).  No hidden global state: nothing in
+ *    the library is process-wide and writable — launch shapes and measurement
+ *    switches are ARGUMENTS (0 = the shipped default), the only objects with a
+ *    lifetime are the ones the caller creates and hands back (CU-masked streams,
+ *    RCCL communicators).  Two threads / two devices of one process share nothing.
  *  - PANEL-MAJOR vectors: a block of P vectors of length N is stored (P, N),
  *    pitch `ld*` between vectors, `s*` between batch members.  This is the
  *    reference's "Fortran order" (N, P) view (_utils/tensor.py:21-32).
@@ -75,26 +79,25 @@ int xk_dense_mm_f32(const float* A, const float* X, float* Y, float* ws, long ws
 long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size);
 /* Results are run-to-run bit-identical: the four waves of a workgroup add into the LDS row accumulator in a fixed
  * order (phase rotation with barriers), partial slots are folded in a fixed order.
- * xk_dense_symm_tune — measurement hook, returns the previous value: what = 0: bit 0 non-temporal stores of the row /
- * column partials, bit 1 non-temporal loads in the fold (default 3); what = 1: column slabs per workgroup run
- * (row partials per row tile = ceil(slabs / run), default 1).  Process-wide; not for use while other threads launch. */
-int xk_dense_symm_tune(int what, int value);
+ * opts (measurements; 0 = the shipped behaviour; results do not depend on it): bit 0 plain instead of non-temporal
+ * stores of the row / column partials, bit 1 plain instead of non-temporal loads in the fold, bits 8..15 column slabs
+ * per workgroup run (0 = 1; row partials per row tile = ceil(slabs / run), at most 64). */
 int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, long ws_elems, int B,
-                      int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+                      int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream);
 int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,
-                      int P, long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+                      int P, long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream);
 /* The two halves of the call above as separate launches (P <= 6): the tile kernel leaves per-slab / per-row-tile
  * partial sums in `ws`, the fold adds them into Y.  The eigensolver's two-group pipeline runs the tile kernels of
  * both groups back to back on one (CU-masked) stream and each fold on its group's own stream, off that
- * critical path; `ws` must stay untouched between the two calls. */
+ * critical path; `ws` must stay untouched between the two calls, and both take the same `opts`. */
 int xk_dense_symm_tiles_f64(const double* A, const double* X, double* ws, long ws_elems, int B, int N, int P,
-                            long lda, long sA, long ldx, long sX, void* stream);
+                            long lda, long sA, long ldx, long sX, int opts, void* stream);
 int xk_dense_symm_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
-                            long lda, long sA, long ldx, long sX, void* stream);
+                            long lda, long sA, long ldx, long sX, int opts, void* stream);
 int xk_dense_symm_fold_f64(double* Y, const double* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
-                           void* stream);
+                           int opts, void* stream);
 int xk_dense_symm_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
-                           void* stream);
+                           int opts, void* stream);
 
 /* ---- K1w: wide panels on the matrix cores (MFMA) --------------------------------------------
  * Y[b,c,n] = sum_i A[b,i,n] Xrm[b,i,c]  (= A^T X; = A X for a Hermitian operator), c < P <= 32, in ONE
@@ -191,14 +194,14 @@ int xk_small_eigh_f32(const float* T, float* lam, float* Y, float* ws, long ws_e
  * instead of ~8 Jacobi sweeps over the whole matrix, which is what the Davidson loop — interested in p << k
  * pairs only (symeig.py:174-175, 255-264) — needs.  Same outputs as xk_small_eigh_*; info[b] != 0 flags a
  * batch member whose result failed the kernel's residual / orthogonality check (caller re-runs on the Jacobi
- * kernel).  Returns XK_ERR_UNSUPPORTED when xk_small_eigh_tri_lds_bytes(k, p, elem_size) exceeds 160 KiB. */
+ * kernel).  Returns XK_ERR_UNSUPPORTED when xk_small_eigh_tri_lds_bytes(k, p, elem_size) exceeds 160 KiB.
+ * threads: workgroup size, a multiple of 64 in [64, 1024], 0 = the measured default (512); profile: NULL, or a device
+ * buffer of >= 8 int64 that receives the cycle counter at the phase boundaries of block 0 (measurements). */
 long xk_small_eigh_tri_lds_bytes(int k, int p, int elem_size);
-int xk_small_eigh_tri_set_threads(int nthreads);   /* tuning knob: workgroup size (multiple of 64), 0 = default */
-int xk_small_eigh_tri_set_profile(long long* device_buf);   /* profiling: cycle stamps of the kernel's phases (NULL = off) */
 int xk_small_eigh_tri_f64(const double* T, double* lam, double* Y, int* info, int B, int k, int p, int uppest,
-                          long ldt, long sT, void* stream);
+                          long ldt, long sT, int threads, long long* profile, void* stream);
 int xk_small_eigh_tri_f32(const float* T, float* lam, float* Y, int* info, int B, int k, int p, int uppest, long ldt,
-                          long sT, void* stream);
+                          long sT, int threads, long long* profile, void* stream);
 
 /* ---- banded operator (DIA storage) -------------------------------------------------------------
  * band (B, 2*hb+1, N), band[b,d,i] = A_b[i, i+d-hb]; entries outside the matrix are ignored.
@@ -291,22 +294,18 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  * memory, k - 1 launches (one per step, look-ahead form) over several workgroups per matrix; then bisection / inverse
  * iteration / self-check in LDS like K3t and the back-transformation from the reflectors parked in the work copy, one
  * workgroup per matrix.  The whole sequence is enqueued on `stream` by one call.  Only the lower triangle of T is read.
- * ws: xk_small_eigh_big_workspace_elems(B, k) elements (work copies + the steps' hand-over blocks).
+ * ws: xk_small_eigh_big_workspace_elems(B, k, wg) elements (work copies + the steps' hand-over blocks).
+ * wg: workgroups per matrix of the step kernels, 0 = automatic (by batch and order), 1 .. 32; threads: 0 = 512, or 256.
  * lam (B, p) ascending, Y (B, p, k) eigenvectors, info[b] != 0 -> redo that call on the library solver.
  * xk_small_eigh_big_batch(k, p, elem_size): shifts factorised at a time (> 0) when the problem fits the 160 KiB of
  * LDS, 0 when it does not.  8 <= k <= 768, p <= 64 (also the solver for MORE THAN 16 wanted pairs at any order: wide
  * eigen-blocks, thick restarts; the batch of vectors in work lives in LDS, finished ones in the rows of Y). */
 int xk_small_eigh_big_batch(int k, int p, int elem_size);
-long xk_small_eigh_big_workspace_elems(int B, int k);
-/* measurement hook (no reference counterpart): what 0 = workgroups per matrix of the step kernels (0 automatic, 1 .. 32;
- * changes what xk_small_eigh_big_workspace_elems returns), what 1 = their threads per workgroup (256 / 512), what 2 / 3
- * = leave the final kernel after a phase / skip parts of the step kernel (timing only: wrong results by construction);
- * returns the previous value. */
-int xk_small_eigh_big_tune(int what, int value);
+long xk_small_eigh_big_workspace_elems(int B, int k, int wg);
 int xk_small_eigh_big_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* info, int B, int k,
-                          int p, int uppest, long ldt, long sT, void* stream);
+                          int p, int uppest, long ldt, long sT, int wg, int threads, void* stream);
 int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long ws_elems, int* info, int B, int k,
-                          int p, int uppest, long ldt, long sT, void* stream);
+                          int p, int uppest, long ldt, long sT, int wg, int threads, void* stream);
 
 /* ---- Davidson chain: one C call per stage of an iteration (xitorch/_impls/linalg/symeig.py:160-223) -------------
  * The stages between two operator-panel products are two to eight small launches each; issued from C++ they cost a
@@ -449,6 +448,29 @@ int xk_broyden_axpy_f64(double* out, const double* u0, double g0, const double* 
                         long ldv, const double* coef, const double* scale, int k, double gamma, long L, void* stream);
 int xk_broyden_axpy_f32(float* out, const float* u0, double g0, const float* u1, double g1, const float* V, long ldv,
                         const float* coef, const float* scale, int k, double gamma, long L, void* stream);
+
+/* ---- device-side collectives of the sharded solvers (RCCL over xGMI) -------------------------
+ * The per-iteration exchanges that reproduce the reference's GLOBAL decisions under batch sharding — MAX of
+ * {max|resid|, flags} (xitorch/_impls/linalg/symeig.py:188-203), MAX of {max residual norm, unconverged flag}
+ * (_impls/linalg/solve.py:157,166,301,310), SUM of the Broyden inner products (_impls/optimize/root/_jacobian.py:172-182) —
+ * as in-place all-reduces enqueued on the caller's stream, right behind the kernel that wrote the few doubles: the
+ * host's one status read per iteration then returns reduced values.  librccl is looked up at the first call (the copy
+ * the process already maps first); without it every entry point returns -2.  No RCCL type crosses the ABI.
+ * xk_comm_available: 1 when a librccl was found.
+ * xk_comm_unique_id: fills 128 opaque bytes on ONE rank; the caller distributes them (any side channel).
+ * xk_comm_init_rank: this process' communicator of `nranks` ranks on HIP device `device` (collective over the ranks).
+ * xk_comm_init_all: ndev communicators of one process, one per device devs[i] (devs == NULL: 0 .. ndev-1).
+ * xk_comm_size: ranks / this rank of a communicator.   xk_comm_destroy: releases it (NULL: no-op).
+ * xk_allreduce_f64 / _f32: buf[0..n) <- reduction over the ranks, op 0 = SUM, 1 = MAX, 2 = MIN, in place, on `stream`.
+ *   One communicator serves one stream at a time.  Return codes: 0 ok, < 0 argument / unsupported, 1000 + ncclResult_t. */
+int xk_comm_available(void);
+int xk_comm_unique_id(void* id128);
+int xk_comm_init_rank(const void* id128, int nranks, int rank, int device, void** comm);
+int xk_comm_init_all(int ndev, const int* devs, void** comms);
+int xk_comm_size(void* comm, int* nranks, int* rank);
+int xk_comm_destroy(void* comm);
+int xk_allreduce_f64(void* comm, double* buf, long n, int op, void* stream);
+int xk_allreduce_f32(void* comm, float* buf, long n, int op, void* stream);
 
 #ifdef __cplusplus
 }

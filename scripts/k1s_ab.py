@@ -37,17 +37,21 @@ class Variant:
         self.lib = ctypes.CDLL(os.path.abspath(path))
         self.f = getattr(self.lib, "xk_dense_symm_" + sfx)
         self.f.restype = I
-        self.f.argtypes = [Pv, Pv, Pv, Pv, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, Pv]
+        # the product library takes `opts` (r04: no process-wide tuning state); the archived kernels under micro/ keep
+        # the r03 signature and their own xk_dense_symm_tune
+        self.has_opts = not hasattr(self.lib, "xk_dense_symm_tune")
+        self.f.argtypes = [Pv, Pv, Pv, Pv, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg] + ([I] if self.has_opts else []) + [Pv]
         self.lib.xk_dense_symm_workspace_elems.restype = Lg
         self.lib.xk_dense_symm_workspace_elems.argtypes = [I, I, I, I]
         self.nws = self.lib.xk_dense_symm_workspace_elems(B, N, P, es)
         self.ws = torch.empty(self.nws, dtype=dtype, device=dev)
 
     def run(self, Y):
-        if self.L is not None:
+        if self.L is not None and not self.has_opts:
             self.lib.xk_dense_symm_tune(1, self.L)
+        extra = ((self.L or 0) << 8,) if self.has_opts else ()
         rc = self.f(ptr(A), ptr(X), ptr(Y), ptr(self.ws), self.nws, B, N, P, A.stride(1), A.stride(0), X.stride(1),
-                    X.stride(0), Y.stride(1), Y.stride(0), stream_ptr())
+                    X.stride(0), Y.stride(1), Y.stride(0), *extra, stream_ptr())
         assert rc == 0, (self.name, rc)
 
 

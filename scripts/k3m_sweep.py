@@ -6,7 +6,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from xitorch_amd import kernels as K, _capi
 dev = torch.device("cuda:0")
-tune = _capi.fn("xk_small_eigh_big_tune")
+def tune(what, value):
+    """launch shape of K3g through the Python layer's module attributes (arguments of the C entry points since r04);
+    what 2 / 3 — leave the final kernel after a phase / skip parts of the step kernel: wrong results by construction —
+    exist only in a library built with -DXK_DEBUG (xk_debug_small_eigh_big)"""
+    if what == 0:
+        K.K3G_WG = int(value)
+    elif what == 1:
+        K.K3G_THREADS = int(value)
+    else:
+        try:
+            _capi.fn("xk_debug_small_eigh_big")(what, value)
+        except Exception:                                   # noqa: the shipped library has no such symbol
+            if value:
+                raise SystemExit("phase timings need a -DXK_DEBUG build of xk_eigh_big.hip")
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 
 

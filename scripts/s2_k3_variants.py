@@ -6,7 +6,7 @@ import os, sys, json, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import xitorch_amd as xa
-from xitorch_amd import synthetic as syn, _capi
+from xitorch_amd import synthetic as syn, _capi, kernels as K
 from xitorch_amd.linalg import symeig
 dev = torch.device("cuda:0")
 B, N, p = 64, 16384, 6
@@ -14,7 +14,20 @@ mat = torch.empty((B, N, N), dtype=torch.float64, device=dev)
 syn.dense_symmetric(B, N, "S2", device=dev, out=mat)
 A = xa.LinearOperator.m(mat, is_hermitian=True)
 exact = syn.spectrum("S2", N, device=dev)[:p]
-tune = _capi.fn("xk_small_eigh_big_tune")
+def tune(what, value):
+    """launch shape of K3g through the Python layer's module attributes (arguments of the C entry points since r04);
+    what 2 / 3 — leave the final kernel after a phase / skip parts of the step kernel: wrong results by construction —
+    exist only in a library built with -DXK_DEBUG (xk_debug_small_eigh_big)"""
+    if what == 0:
+        K.K3G_WG = int(value)
+    elif what == 1:
+        K.K3G_THREADS = int(value)
+    else:
+        try:
+            _capi.fn("xk_debug_small_eigh_big")(what, value)
+        except Exception:                                   # noqa: the shipped library has no such symbol
+            if value:
+                raise SystemExit("phase timings need a -DXK_DEBUG build of xk_eigh_big.hip")
 for spec in sys.argv[1:]:
     parts = spec.split(":")
     W, reserve = int(parts[0]), int(parts[1])

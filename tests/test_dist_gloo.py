@@ -174,3 +174,72 @@ def test_world_size_8_gloo_uneven_shards():
         assert results[r]["stops"] == results[0]["stops"]
     expect = [max(results[r]["own_hist"][i] for r in range(world)) for i in range(results[0]["full_niter"])]
     assert results[0]["stops"] == expect
+
+
+def _worker_rows(rank, world, port, results):
+    """Row-block sharding of ONE dense operator over the ranks (B < G: SURVEY 8e, last bullet): products, full matrix,
+    gradient slice, and the eigensolver on the sharded operator == on the unsharded one."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import xitorch_amd as xa
+        from xitorch_amd import dist as xd, synthetic
+        from oracle import symeig as osym
+        grp = dist.group.WORLD
+        out = {}
+        N = 101                                              # uneven row blocks
+        g = torch.Generator().manual_seed(5)
+        mat = torch.randn(2, N, N, dtype=torch.float64, generator=g)
+        x = torch.randn(2, N, 3, dtype=torch.float64, generator=g)
+        A = xa.RowShardedMatrixLinearOperator.from_full(mat, grp, is_hermitian=False)
+        lo, hi = xd.shard_range(N, world, rank)
+        out["rows"] = (lo, hi, tuple(A.local.shape))
+        out["mm"] = (A.mm(x) - mat @ x).abs().max().item()
+        out["rmm"] = (A.rmm(x) - mat.transpose(-2, -1) @ x).abs().max().item()
+        out["mv"] = (A.mv(x[..., 0]) - (mat @ x[..., :1])[..., 0]).abs().max().item()
+        out["full"] = (A.fullmatrix() - mat).abs().max().item()
+        # the replicated loss differentiates into this rank's row block only
+        loc = mat[..., lo:hi, :].clone().requires_grad_()
+        Ag = xa.RowShardedMatrixLinearOperator(loc, N, grp)
+        gl, = torch.autograd.grad((Ag.mm(x) ** 2).sum(), (loc,))
+        full = mat.clone().requires_grad_()
+        gf, = torch.autograd.grad(((full @ x) ** 2).sum(), (full,))
+        out["grad"] = (gl - gf[..., lo:hi, :]).abs().max().item()
+        # one symmetric operator (B = 1 < G), eigensolver replicated on every rank, operator stream split by rows
+        S = synthetic.dense_symmetric(1, 96, "S1")
+        As = xa.RowShardedMatrixLinearOperator.from_full(S, grp, is_hermitian=True)
+        trs, trf = {}, {}
+        ev_s, X_s = osym.davidson(As, 3, "lowest", min_eps=1e-8, trace=trs)
+        ev_f, X_f = osym.davidson(xa.LinearOperator.m(S, is_hermitian=True), 3, "lowest", min_eps=1e-8, trace=trf)
+        out["eig"] = ((ev_s - ev_f).abs().max().item(), trs["niter"], trf["niter"],
+                      (S @ X_s - X_s * ev_s.unsqueeze(-2)).abs().max().item())
+        out["evals"] = ev_s.tolist()
+        with pytest.raises(RuntimeError):
+            xa.RowShardedMatrixLinearOperator(mat[..., :5, :], N, grp)       # wrong block height
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_block_sharded_operator_gloo(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker_rows, args=(world, port, results), nprocs=world, join=True)
+    assert len(results) == world
+    covered = []
+    for rank in range(world):
+        r = results[rank]
+        covered.append(r["rows"][:2])
+        assert r["rows"][2] == (2, r["rows"][1] - r["rows"][0], 101)
+        for key in ("mm", "rmm", "mv", "full", "grad"):
+            assert r[key] < 1e-12, (key, r[key])
+        err, it_s, it_f, resid = r["eig"]
+        assert err < 1e-11 and abs(it_s - it_f) <= 1 and resid < 1e-7, r["eig"]
+        assert r["evals"] == results[0]["evals"]             # every rank holds the same replicated answer
+    assert covered[0][0] == 0 and covered[-1][1] == 101 and all(covered[i][1] == covered[i + 1][0] for i in range(world - 1))

@@ -94,6 +94,21 @@ def _worker(rank, world, port, results):
                          process_group=dist.group.WORLD)
         out["broyden"] = dict(niter=(ts["niter"], tf["niter"]), nfev=(ts["nfev"], tf["nfev"]),
                               err=(ys - yf[l2:h2]).abs().max().item())
+        # ---- ONE operator, fewer members than ranks: row-block sharding (last bullet).  Each rank streams
+        # its rows of A on the native K1 kernel, the p-column panel is all-gathered, the rest of the native Davidson runs
+        # replicated and must be identical on both ranks and equal to the unsharded run
+        Nr = 1030
+        S1 = synthetic.dense_symmetric(1, Nr, "S1", device=dev)
+        As = xa.RowShardedMatrixLinearOperator.from_full(S1, dist.group.WORLD, is_hermitian=True)
+        trs, trf = {}, {}
+        ev_s, X_s = davidson(As, 4, "lowest", min_eps=1e-8, trace=trs)
+        ev_f, _ = davidson(xa.LinearOperator.m(S1, True), 4, "lowest", min_eps=1e-8, trace=trf)
+        Rr = torch.matmul(S1, X_s) - X_s * ev_s.unsqueeze(-2)
+        xg = torch.randn(1, Nr, 5, dtype=torch.float64, generator=torch.Generator().manual_seed(3)).to(dev)
+        out["rows"] = dict(err=(ev_s - ev_f).abs().max().item(), niter=(trs["niter"], trf["niter"]),
+                           resid=Rr.abs().max().item(), evals=ev_s.cpu().tolist(),
+                           mm=(As.mm(xg) - S1 @ xg).abs().max().item(), rmm=(As.rmm(xg) - S1 @ xg).abs().max().item(),
+                           local_rows=As.local.shape[-2])
         results[rank] = out
     finally:
         dist.destroy_process_group()
@@ -127,3 +142,48 @@ def test_sharded_davidson_two_ranks_one_gpu():
             assert err < 1e-8, (meth, err)
         r = results[rank]["broyden"]                              # the whole batch is ONE flat system (Q4)
         assert r["niter"][0] == r["niter"][1] and r["nfev"][0] == r["nfev"][1] and r["err"] < 1e-9, r
+        r = results[rank]["rows"]                                 # one operator split by row blocks over the ranks
+        assert r["local_rows"] == 515 and r["mm"] < 1e-11 and r["rmm"] < 1e-11, r
+        assert r["err"] < 1e-10 and abs(r["niter"][0] - r["niter"][1]) <= 1 and r["resid"] < 1e-7, r
+        assert r["evals"] == results[0]["rows"]["evals"]          # replicated: bit-identical on every rank
+
+
+def test_device_comm_through_the_c_abi_single_rank(dev):
+    """xk_comm_* / xk_allreduce_*: the RCCL communicator and the in-place all-reduce behind the C ABI (csrc/xk_comm.hip),
+    on the one GPU of the test box: a communicator of one rank — library lookup, unique id, init, SUM / MAX / MIN of
+    float64 and float32 on the default and on a side stream, size query, destroy.  (Two ranks need two devices: RCCL
+    refuses a second rank on the same GPU; the multi-rank path verifies itself against known answers at creation,
+    dist.device_comm.)"""
+    from xitorch_amd import _capi
+    from xitorch_amd.dist import DeviceComm
+    assert _capi.fn("xk_comm_available")() == 1
+    uid = DeviceComm.unique_id()
+    assert len(uid) == 128 and any(b != 0 for b in uid)
+    comm = DeviceComm.create(uid, 1, 0, dev)
+    try:
+        assert comm.size() == (1, 0)
+        for dtype in (torch.float64, torch.float32):
+            t = torch.tensor([3.0, -1.0, 7.5, 0.0, 1e-30], dtype=dtype, device=dev)
+            for op in ("sum", "max", "min"):
+                u = t.clone()
+                comm.allreduce_(u, op)
+                torch.cuda.synchronize()
+                assert torch.equal(u, t), (dtype, op)
+        side = torch.cuda.Stream(device=dev)
+        big = torch.arange(100000, dtype=torch.float64, device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            v = big * 2.0
+            comm.allreduce_(v, "sum")             # stream-ordered behind the kernel that produced v
+            w = v + 1.0
+        side.synchronize()
+        assert torch.equal(w, big * 2.0 + 1.0)
+        with pytest.raises(Exception):
+            comm.allreduce_(torch.zeros(3, dtype=torch.int32, device=dev), "sum")
+    finally:
+        comm.close()
+    # a process group of one rank never creates a communicator: the helpers are no-ops
+    from xitorch_amd import dist as xd
+    assert xd.device_comm(None, dev) is None
+    t = torch.ones(2, dtype=torch.float64, device=dev)
+    assert xd.allreduce_max_(t, None) is t and xd.allreduce_sum_(t, None) is t

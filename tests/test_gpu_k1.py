@@ -108,15 +108,14 @@ def test_small_eigh_vs_oracle(dev, B, k, p, uppest, dtype):
 
 @pytest.fixture
 def symm_run():
-    """slabs per workgroup run of K1s (xk_dense_symm_tune(1, L)); restored afterwards"""
-    from xitorch_amd._capi import fn
-    prev = []
+    """slabs per workgroup run of K1s (bits 8..15 of the entry points' `opts` argument, handed through the Python
+    layer's K1S_OPTS); restored afterwards"""
+    prev = K.K1S_OPTS
 
     def select(v):
-        prev.append(fn("xk_dense_symm_tune")(1, v))
+        K.K1S_OPTS = int(v) << 8
     yield select
-    if prev:
-        fn("xk_dense_symm_tune")(1, prev[0])
+    K.K1S_OPTS = prev
 
 
 @pytest.mark.parametrize("B,N,P,dtype", [(2, 2048, 6, torch.float64), (3, 1536, 4, torch.float64),
@@ -405,14 +404,12 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
         buf[:, :k, :k] = torch.tril(Tm).to(dtype) + torch.triu(torch.full((k, k), float("nan"), dtype=dtype), 1)
         # the tridiagonalisation is spread over W workgroups per matrix, one launch per Householder step (automatic W,
         # an odd W, 8 with 256-thread workgroups, 16): same answers, each bit-reproducible
-        tune = _capi.fn("xk_small_eigh_big_tune")
-        try:
+        if True:
             for W, threads in ((0, 512), (3, 512), (8, 256), (16, 512)):
-                tune(0, W); tune(1, threads)
                 tag = (kind, W, threads)
                 dbuf = buf.to(dev)
-                lam, Y, info = K.small_eigh_big(dbuf, k, p, uppest=uppest)
-                lam2, Y2, _ = K.small_eigh_big(dbuf, k, p, uppest=uppest)
+                lam, Y, info = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, threads=threads)
+                lam2, Y2, _ = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, threads=threads)
                 assert torch.equal(lam, lam2) and torch.equal(Y, Y2), tag
                 assert int(info.max()) == 0, tag
                 lam, Y = lam.cpu().double(), Y.cpu().double()
@@ -426,5 +423,3 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
                 assert res.abs().max().item() < tol * scale * 100, tag
                 G = torch.matmul(Yc.transpose(-2, -1), Yc)
                 assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
-        finally:
-            tune(0, 0); tune(1, 512)

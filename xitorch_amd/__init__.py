@@ -8,7 +8,7 @@ Drop-in surface (same names as the reference package `xitorch`):
 """
 from xitorch_amd.editable import EditableModule
 from xitorch_amd.purefn import get_pure_function, make_sibling, PureFunction
-from xitorch_amd.linop import LinearOperator, MatrixLinearOperator, BandedLinearOperator
+from xitorch_amd.linop import LinearOperator, MatrixLinearOperator, BandedLinearOperator, RowShardedMatrixLinearOperator
 from xitorch_amd.debug import is_debug_enabled, set_debug_mode, enable_debug, disable_debug
 from xitorch_amd._util import ConvergenceWarning, MathWarning, GetSetParamsError
 

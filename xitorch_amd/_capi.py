@@ -70,18 +70,14 @@ def _declare(L):
         sigs["xk_davidson_extend_t_" + sfx] = (I, [P, P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P, Lg, P])
     sigs["xk_small_eigh_workspace_elems"] = (Lg, [I, I, I])
     sigs["xk_small_eigh_tri_lds_bytes"] = (Lg, [I, I, I])
-    sigs["xk_small_eigh_tri_set_threads"] = (I, [I])
-    sigs["xk_small_eigh_tri_set_profile"] = (I, [P])
     for sfx in ("f64", "f32"):
-        sigs["xk_small_eigh_tri_" + sfx] = (I, [P, P, P, P, I, I, I, I, Lg, Lg, P])
+        sigs["xk_small_eigh_tri_" + sfx] = (I, [P, P, P, P, I, I, I, I, Lg, Lg, I, P, P])
     sigs["xk_small_eigh_big_batch"] = (I, [I, I, I])
-    sigs["xk_small_eigh_big_workspace_elems"] = (Lg, [I, I])
-    sigs["xk_small_eigh_big_tune"] = (I, [I, I])
+    sigs["xk_small_eigh_big_workspace_elems"] = (Lg, [I, I, I])
     for sfx in ("f64", "f32"):
-        sigs["xk_small_eigh_big_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, Lg, Lg, P])
+        sigs["xk_small_eigh_big_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, Lg, Lg, I, I, P])
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
-    sigs["xk_dense_symm_tune"] = (I, [I, I])
     sigs["xk_dense_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
     sigs["xk_dense_wide_padded_width"] = (I, [I, I])
     sigs["xk_dense_rows_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
@@ -91,9 +87,9 @@ def _declare(L):
         sigs["xk_dense_wide_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
     for sfx in ("f64", "f32"):
         sigs["xk_group_status_" + sfx] = (I, [P, P, P, P, P, I, P])
-        sigs["xk_dense_symm_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
-        sigs["xk_dense_symm_tiles_" + sfx] = (I, [P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, P])
-        sigs["xk_dense_symm_fold_" + sfx] = (I, [P, P, Lg, I, I, I, Lg, Lg, P])
+        sigs["xk_dense_symm_" + sfx] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, P])
+        sigs["xk_dense_symm_tiles_" + sfx] = (I, [P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, I, P])
+        sigs["xk_dense_symm_fold_" + sfx] = (I, [P, P, Lg, I, I, I, Lg, Lg, I, P])
     for sfx in ("f64", "f32"):
         sigs["xk_banded_mm_" + sfx] = (I, [P, P, P, I, I, I, I, Lg, Lg, Lg, Lg, Lg, I, P])
         sigs["xk_kry_dots_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, P])
@@ -118,6 +114,14 @@ def _declare(L):
         sigs["xk_kry_resid_" + sfx] = (I, [P] * 6 + [I, I, Lg, I, P])
         sigs["xk_cg_update_" + sfx] = (I, [P] * 8 + [I, I, Lg, I, D, I, P])
         sigs["xk_cg_p_" + sfx] = (I, [P] * 4 + [I, I, Lg, I, D, P])
+    sigs["xk_comm_available"] = (I, [])
+    sigs["xk_comm_unique_id"] = (I, [P])
+    sigs["xk_comm_init_rank"] = (I, [P, I, I, I, P])
+    sigs["xk_comm_init_all"] = (I, [I, P, P])
+    sigs["xk_comm_size"] = (I, [P, P, P])
+    sigs["xk_comm_destroy"] = (I, [P])
+    sigs["xk_allreduce_f64"] = (I, [P, P, Lg, I, P])
+    sigs["xk_allreduce_f32"] = (I, [P, P, Lg, I, P])
     sigs["xk_vec_dots_workspace_elems"] = (Lg, [])
     for sfx in ("f64", "f32"):
         sigs["xk_vec_dots_" + sfx] = (I, [P] * 8 + [I, Lg, P, Lg, P, P])

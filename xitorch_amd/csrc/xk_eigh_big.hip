@@ -626,16 +626,29 @@ static long big_lds_elems(long n, long p, long pb) { (void)p; return 4 * n + 16 
 
 extern "C" int xk_small_eigh_big_batch(int k, int p, int elem_size);
 
-// measurement hooks: workgroups per matrix of the step kernels (0 = automatic), their threads per workgroup, "leave the
-// final kernel after phase", "skip parts of the step kernel" (the last two give wrong results by construction)
-static int g_big_w = 0;
-static int g_big_threads = 512;
+// No process-wide state: the launch shape (workgroups per matrix of the step kernels, their threads) arrives as
+// arguments of the entry point (0 = the measured defaults).  The two measurement switches that give WRONG results by
+// construction — "leave the final kernel after phase n", "skip parts of the step kernel" — exist only in a -DXK_DEBUG
+// build (scripts/k3m_sweep.py builds its own copy); the shipped library passes 0 for both.
+#ifdef XK_DEBUG
 static int g_big_stop = 0;
 static int g_big_skip = 0;
+extern "C" int xk_debug_small_eigh_big(int what, int value) {
+  int old = -1000;
+  if (what == 2) { old = g_big_stop; g_big_stop = value; }
+  if (what == 3) { old = g_big_skip; g_big_skip = value; }
+  return old;
+}
+#define XK_BIG_STOP g_big_stop
+#define XK_BIG_SKIP g_big_skip
+#else
+#define XK_BIG_STOP 0
+#define XK_BIG_SKIP 0
+#endif
 
 namespace xk {
-static int big_pick_w(int B, int k) {
-  if (g_big_w > 0) return g_big_w;
+static int big_pick_w(int B, int k, int wg) {
+  if (wg > 0) return wg;
   // measured (scripts/k3m_sweep.py, s2_k3_variants.py): alone on the chip 8 workgroups per matrix are fastest for 32
   // matrices; beside the panel stream of the Davidson pipeline, which leaves 64 CUs to everything else, 4 are (128
   // workgroups = two rounds on those CUs instead of four) — the pipeline is where this kernel runs
@@ -647,15 +660,14 @@ static int big_pick_w(int B, int k) {
 
 template <typename T, int NT>
 static void big_launch_step(const T* Tin, T* S, T* aux, long aux_stride, int B, int k, int j, int W, long ldt, long sT,
-                            hipStream_t st) {
-  const int nt = g_big_threads;
+                            int nt, hipStream_t st) {
   const size_t lds = (size_t)step_lds_elems(k, nt / 64) * sizeof(T);
   if (j < 0)
     hipLaunchKernelGGL((tridiag_step_kernel<T, NT, true>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k, j,
-                       W, ldt, sT, g_big_skip);
+                       W, ldt, sT, XK_BIG_SKIP);
   else
     hipLaunchKernelGGL((tridiag_step_kernel<T, NT, false>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k,
-                       j, W, ldt, sT, g_big_skip);
+                       j, W, ldt, sT, XK_BIG_SKIP);
 }
 
 template <typename T, int NT>
@@ -665,26 +677,26 @@ static int big_launch_final(T* ws, const T* aux, long aux_stride, T* lam, T* Y, 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((tridiag_eigh_big_kernel<T, NT>), dim3(B), dim3(512), (size_t)lds, st, ws, aux, aux_stride, lam, Y,
-                     info, k, p, pb, uppest, g_big_stop);
+                     info, k, p, pb, uppest, XK_BIG_STOP);
   return XK_OK;
 }
 
 template <typename T>
 static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k, int p, int uppest,
-                   long ldt, long sT, hipStream_t st) {
+                   long ldt, long sT, int wg, int nt, hipStream_t st) {
   const int pb = xk_small_eigh_big_batch(k, p, (int)sizeof(T));
   if (pb == 0) return XK_ERR_UNSUPPORTED;
   const long lds = big_lds_elems(k, p, pb) * (long)sizeof(T) + 64;
-  const int W = big_pick_w(B, k);
+  const int W = big_pick_w(B, k, wg);
   const long aux_stride = (long)k * (7 + 2 * W);
   if (ws == nullptr || ws_elems < (long)B * k * k + (long)B * aux_stride) return XK_ERR_ARG;
   T* aux = ws + (long)B * k * k;
   for (int j = -1; j <= k - 3; ++j) {                     // (column slots of 64 that are still live: 2 / 4 / 8 / 12)
     const int m2 = k - (j + 2);
-    if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
-    else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
-    else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
-    else big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, st);
+    if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    else big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
   }
   const int rc = k <= 512 ? big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, st)
                           : big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, st);
@@ -705,30 +717,19 @@ int xk_small_eigh_big_batch(int k, int p, int elem_size) {
   return 0;
 }
 
-long xk_small_eigh_big_workspace_elems(int B, int k) {
-  const int W = xk::big_pick_w(B, k);
+long xk_small_eigh_big_workspace_elems(int B, int k, int wg) {
+  const int W = xk::big_pick_w(B, k, wg);
   return (long)B * k * k + (long)B * k * (7 + 2 * W);
-}
-
-/* measurement hook: what 0 = workgroups per matrix of the step kernels (0 automatic, 1 .. 32), what 1 = their threads
- * per workgroup (256 / 512), what 2 = leave the final kernel after phase 2 / 3 / 5, what 3 = bit mask of step-kernel
- * parts to skip (1 row sweep, 2 reflector + partial sums, 4 partial flush) — 2 and 3 give wrong results by construction.
- * Returns the previous value. */
-int xk_small_eigh_big_tune(int what, int value) {
-  int old = -1000;
-  if (what == 0) { old = g_big_w; if (value >= 0 && value <= 32) g_big_w = value; }
-  if (what == 1) { old = g_big_threads; if (value == 256 || value == 512) g_big_threads = value; }
-  if (what == 2) { old = g_big_stop; g_big_stop = value; }
-  if (what == 3) { old = g_big_skip; g_big_skip = value; }
-  return old;
 }
 
 #define XK_DEFINE_EIGH_BIG(SUF, T)                                                                            \
   int xk_small_eigh_big_##SUF(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k,      \
-                              int p, int uppest, long ldt, long sT, void* stream) {                           \
+                              int p, int uppest, long ldt, long sT, int wg, int threads, void* stream) {      \
     if (B < 0 || k < 8 || k > 768 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                   \
+    if (wg < 0 || wg > 32 || (threads != 0 && threads != 256 && threads != 512)) return XK_ERR_ARG;           \
     if (B == 0) return XK_OK;                                                                                 \
-    return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, (hipStream_t)stream);    \
+    return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, wg,                      \
+                          threads ? threads : 512, (hipStream_t)stream);                                      \
   }
 
 XK_DEFINE_EIGH_BIG(f64, double)

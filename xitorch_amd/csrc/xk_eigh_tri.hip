@@ -445,17 +445,6 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
 
 extern "C" {
 
-static int xk_tri_threads = 0;
-static long long* xk_tri_dbg = nullptr;
-/* profiling hook: device buffer of >= 8 int64 receiving the cycle counter at the phase boundaries of block 0 */
-int xk_small_eigh_tri_set_profile(long long* device_buf) { xk_tri_dbg = device_buf; return XK_OK; }
-/* tuning knob (benchmarks): threads per workgroup of xk_small_eigh_tri_*, a multiple of 64 in [64, 1024]; 0 = default */
-int xk_small_eigh_tri_set_threads(int nthreads) {
-  if (nthreads != 0 && (nthreads < 64 || nthreads > 1024 || nthreads % 64)) return XK_ERR_ARG;
-  xk_tri_threads = nthreads;
-  return XK_OK;
-}
-
 /* LDS bytes the kernel needs for order k and p wanted pairs (elem_size 8 / 4); the caller compares with 160 KiB */
 long xk_small_eigh_tri_lds_bytes(int k, int p, int elem_size) {
   const long n = k, ld = n | 1;
@@ -466,8 +455,9 @@ long xk_small_eigh_tri_lds_bytes(int k, int p, int elem_size) {
 
 #define XK_DEFINE_EIGH_TRI(SUF, T)                                                                          \
   int xk_small_eigh_tri_##SUF(const T* Tin, T* lam, T* Y, int* info, int B, int k, int p, int uppest,        \
-                              long ldt, long sT, void* stream) {                                             \
+                              long ldt, long sT, int threads, long long* profile, void* stream) {            \
     if (B < 0 || k < 1 || p < 1 || p > k || k > 128 || p > xk::TRI_MAXP) return XK_ERR_ARG;                  \
+    if (threads != 0 && (threads < 64 || threads > 1024 || threads % 64)) return XK_ERR_ARG;                 \
     if (B == 0) return XK_OK;                                                                                \
     const long lds = xk_small_eigh_tri_lds_bytes(k, p, (int)sizeof(T));                                      \
     if (lds > 160 * 1024) return XK_ERR_UNSUPPORTED;                                                         \
@@ -477,9 +467,9 @@ long xk_small_eigh_tri_lds_bytes(int k, int p, int elem_size) {
     /* threads: 512 (8 waves) measured best at every order: 64 / 128 / 256 -> 2.9x / 1.7x / 1.2x slower (the    */  \
     /* LDS-latency chains of a step want other waves to hide behind), 1024 -> 1.1x slower (barrier skew and the  */  \
     /* reflector arithmetic that every wave repeats)                                                              */  \
-    int nthr = xk_tri_threads > 0 ? xk_tri_threads : 512;                                                    \
+    const int nthr = threads > 0 ? threads : 512;                                                            \
     hipLaunchKernelGGL((xk::tridiag_eigh_kernel<T>), dim3(B), dim3(nthr), (size_t)lds, (hipStream_t)stream,  \
-                       Tin, lam, Y, info, k, p, uppest, ldt, sT, xk_tri_dbg);                                \
+                       Tin, lam, Y, info, k, p, uppest, ldt, sT, profile);                                   \
     XK_LAUNCH_CHECK();                                                                                       \
     return XK_OK;                                                                                            \
   }

@@ -45,7 +45,7 @@
 //   ring slots re-issued per row or per 16 B vector instead of per row pair: 5.66 / 5.67 (nothing); runs of L = 2 slabs:
 //   equal alone, 4.6 % slower inside the eigensolver's pipeline; L = 4 / 8: 8 / 29 % slower (the launch has only ~8-11
 //   tiles per resident workgroup, so longer work items lose more in the tail than the saved row partials return).
-//   L = 1 is the default; the knob stays for measurements (xk_dense_symm_tune).
+//   L = 1 is the default; the knob stays for measurements (bits 8..15 of the entry points' `opts`).
 //
 // Traffic per launch: B*N^2*s/2 (+2 % for the diagonal tiles) + B*(NT + NS/L)*P*N*s of partials written
 // and read once — vs B*N^2*s for the general kernel.
@@ -527,27 +527,17 @@ __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, con
   Y[b * sY + (long)c * ldy + n] = s;
 }
 
-// Tuning state (process-wide; written only through xk_dense_symm_tune, a measurement hook):
-//   [0] bit 0: the row / column partials leave with non-temporal stores, bit 1: the fold reads them with
-//       non-temporal loads (written once, read once, milliseconds apart: keeping them out of L2's way was worth
-//       1.2 % of the eigensolver call in round 2);
-//   [1] L: column slabs per run (row partials per row tile = ceil(slabs / L)).
-static int g_symm_tune[2] = {3, 1};
-
 }  // namespace xk
 
 extern "C" {
 
-// measurement hook: set tuning value `what` (0: non-temporal flags, 1: slabs per run), return the previous one.
-// Results do not depend on either (the run length changes the summation order of the row partials — still a
-// fixed order).  Not meant to be flipped while launches are being issued from other threads.
-int xk_dense_symm_tune(int what, int value) {
-  if (what < 0 || what > 1) return XK_ERR_ARG;
-  const int old = xk::g_symm_tune[what];
-  if (what == 0 && value >= 0 && value <= 3) xk::g_symm_tune[0] = value;
-  if (what == 1 && value >= 1 && value <= 64) xk::g_symm_tune[1] = value;
-  return old;
-}
+// `opts` of the entry points below (no process-wide state; 0 = the shipped behaviour):
+//   bit 0: the row / column partials leave with PLAIN stores instead of non-temporal ones, bit 1: the fold reads them
+//          with plain loads (written once, read once, milliseconds apart: keeping them out of L2's way was worth 1.2 %
+//          of the eigensolver call in round 2);
+//   bits 8..15: L, column slabs per workgroup run (0 = 1; row partials per row tile = ceil(slabs / L)).
+// Results do not depend on either (the run length changes the summation order of the row partials — still a fixed
+// order); both exist for measurements.
 
 // workspace (elements): row partials (B, NS, P, N) + column partials (B, NT, P, N) — sized for runs of one slab
 long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
@@ -560,9 +550,9 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
 
 #define XK_DEFINE_SYMM(SUF, T)                                                                              \
   static int symm_launch_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P,     \
-                               long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream,       \
-                               int phase) {                                                                 \
-    if (B < 0 || N < 0 || P < 0) return XK_ERR_ARG;                                                         \
+                               long lda, long sA, long ldx, long sX, long ldy, long sY, int opts,           \
+                               void* stream, int phase) {                                                   \
+    if (B < 0 || N < 0 || P < 0 || opts < 0 || opts > 0xffff) return XK_ERR_ARG;                            \
     if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
     if (phase != 0 && P > 6) return XK_ERR_UNSUPPORTED;   /* split phases: one column chunk only */         \
     constexpr int VN = xk::Vec16<T>::n;                                                                     \
@@ -572,7 +562,8 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
       return XK_ERR_UNSUPPORTED;                                                                            \
     if ((long)xk::SYMM_TRH * lda * (long)sizeof(T) > 0x7fffffe0L) return XK_ERR_UNSUPPORTED;               \
     hipStream_t st = (hipStream_t)stream;                                                                   \
-    const int L = xk::g_symm_tune[1], fl = xk::g_symm_tune[0];                                              \
+    const int L = ((opts >> 8) & 0xff) ? ((opts >> 8) & 0xff) : 1, fl = 3 & ~opts;                          \
+    if (L > 64) return XK_ERR_ARG;                                                                          \
     const int NS = (N + SLAB - 1) / SLAB, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;                       \
     const int NSL = (NS + L - 1) / L;                                                                       \
     int nruns = 0;                                                                                          \
@@ -605,18 +596,19 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
     return XK_OK;                                                                                           \
   }                                                                                                         \
   int xk_dense_symm_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P, long lda, \
-                          long sA, long ldx, long sX, long ldy, long sY, void* stream) {                    \
-    return symm_launch_##SUF(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, stream, 0);         \
+                          long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream) {          \
+    return symm_launch_##SUF(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, opts, stream, 0);   \
   }                                                                                                         \
   int xk_dense_symm_tiles_##SUF(const T* A, const T* X, T* ws, long ws_elems, int B, int N, int P,          \
-                                long lda, long sA, long ldx, long sX, void* stream) {                       \
-    return symm_launch_##SUF(A, X, (T*)nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, stream, 1);  \
+                                long lda, long sA, long ldx, long sX, int opts, void* stream) {             \
+    return symm_launch_##SUF(A, X, (T*)nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, opts,        \
+                             stream, 1);                                                                    \
   }                                                                                                         \
   int xk_dense_symm_fold_##SUF(T* Y, const T* ws, long ws_elems, int B, int N, int P, long ldy, long sY,    \
-                               void* stream) {                                                              \
+                               int opts, void* stream) {                                                    \
     /* the fold never touches A or X: alignment-checked placeholders */                                     \
     return symm_launch_##SUF((const T*)ws, (const T*)ws, Y, (T*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, \
-                             stream, 2);                                                                    \
+                             opts, stream, 2);                                                              \
   }
 
 #define XK_SYMM_CASE(PP)                                                                                  \

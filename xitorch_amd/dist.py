@@ -12,10 +12,20 @@ only traffic is what reproduces the reference's *global* decisions (SURVEY.md §
 
 All messages are a few bytes to a few hundred bytes: latency-bound, so they are fused into one
 call per decision and never sit on the bandwidth path.
+
+Where the all-reduce runs (r04): for HIP tensors on an RCCL ("nccl") group the reduction is enqueued through the C
+ABI (`xk_allreduce_f64 / _f32`, csrc/xk_comm.hip) IN PLACE on the caller's current stream — no hop through the process
+group's own stream, no c10d work object — from a communicator created once per (group, device, stream) with
+`xk_comm_init_rank` (the unique id travels through the group's own broadcast).  A communicator is verified when it is
+created (a SUM and a MAX with known answers, the outcome agreed by all ranks over c10d); anything that fails — no librccl, two
+ranks on one device, a gloo group — leaves that group on the c10d path for good.  `XITORCH_AMD_DEVICE_COMM=0` forces
+the c10d path.
 """
+import os
 import torch
 
-__all__ = ["shard_range", "allreduce_max_", "allreduce_sum_", "is_distributed", "all_ranks_agree_true"]
+__all__ = ["shard_range", "allreduce_max_", "allreduce_sum_", "is_distributed", "all_ranks_agree_true",
+           "device_comm", "DeviceComm", "close_device_comms"]
 
 
 def is_distributed():
@@ -36,18 +46,148 @@ def _trivial(group):
     return group is None or torch.distributed.get_world_size(group) == 1
 
 
+class DeviceComm:
+    """One RCCL communicator behind the C ABI (include/xitorch_amd.h: xk_comm_*), for the ranks of a process group on
+    one HIP device, used from ONE stream."""
+
+    OPS = {"sum": 0, "max": 1, "min": 2}
+
+    def __init__(self, handle, nranks, rank, device):
+        self.handle, self.nranks, self.rank, self.device = handle, nranks, rank, device
+
+    @staticmethod
+    def create(id_bytes, nranks, rank, device):
+        """collective over the ranks: every rank passes the same 128 bytes of `unique_id()`"""
+        import ctypes
+        from xitorch_amd._capi import fn, check
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        out = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
+        check(fn("xk_comm_init_rank")(buf, int(nranks), int(rank), int(idx), ctypes.byref(out)), "xk_comm_init_rank")
+        return DeviceComm(out, nranks, rank, torch.device("cuda", idx))
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from xitorch_amd._capi import fn, check
+        buf = ctypes.create_string_buffer(128)
+        check(fn("xk_comm_unique_id")(buf), "xk_comm_unique_id")
+        return bytes(buf.raw)
+
+    def allreduce_(self, t, op="max"):
+        """in place on the CURRENT stream; t: contiguous float64 / float32 HIP tensor"""
+        from xitorch_amd._capi import fn, check, ptr, stream_ptr
+        if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float64, torch.float32):
+            raise RuntimeError("DeviceComm.allreduce_: contiguous float64 / float32 HIP tensor expected")
+        name = "xk_allreduce_f64" if t.dtype == torch.float64 else "xk_allreduce_f32"
+        check(fn(name)(self.handle, ptr(t), t.numel(), self.OPS[op], stream_ptr()), name)
+        return t
+
+    def size(self):
+        import ctypes
+        from xitorch_amd._capi import fn, check
+        n, r = ctypes.c_int(), ctypes.c_int()
+        check(fn("xk_comm_size")(self.handle, ctypes.byref(n), ctypes.byref(r)), "xk_comm_size")
+        return n.value, r.value
+
+    def close(self):
+        from xitorch_amd._capi import fn
+        if self.handle is not None:
+            fn("xk_comm_destroy")(self.handle)
+            self.handle = None
+
+
+_COMMS = {}            # (id(group), device index, stream handle) -> DeviceComm
+_NO_DEVICE_COMM = set()   # id(group) of groups that stay on c10d
+
+
+def device_comm(group, device):
+    """The C-ABI communicator of `group` on `device` for the CURRENT stream, created (collectively, self-tested)
+    at first use; None when this group takes the c10d path.  Every rank must reach a creation at the same point
+    of the program — true for the solvers, whose ranks run in lock step."""
+    if _trivial(group) or os.environ.get("XITORCH_AMD_DEVICE_COMM", "1") == "0":
+        return None
+    gid = id(group)
+    if gid in _NO_DEVICE_COMM:
+        return None
+    dist = torch.distributed
+    device = torch.device(device)
+    if device.type != "cuda" or dist.get_backend(group) != "nccl":
+        _NO_DEVICE_COMM.add(gid)
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (gid, idx, torch.cuda.current_stream(device).cuda_stream)
+    comm = _COMMS.get(key)
+    if comm is not None:
+        return comm
+    # Every rank executes the same c10d collectives here whatever fails locally: one broadcast, one agreement before the
+    # RCCL calls, one after.  The self-test compares with the known answers (SUM of rank + 1, MAX of -rank).
+    comm, ok = None, False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    try:
+        from xitorch_amd._capi import fn
+        ok = fn("xk_comm_available")() == 1
+        box = [DeviceComm.unique_id() if (ok and rank == 0) else None]
+    except Exception:                                  # noqa
+        ok, box = False, [None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+    ok = ok and box[0] is not None
+    if all_ranks_agree_true(ok, device, group):
+        try:
+            comm = DeviceComm.create(box[0], world, rank, device)
+            t = torch.tensor([rank + 1.0, -float(rank)], dtype=torch.float64, device=device)
+            a, b = t[:1].clone(), t[1:].clone()
+            comm.allreduce_(a, "sum")
+            comm.allreduce_(b, "max")
+            ok = bool(a.item() == world * (world + 1) / 2 and b.item() == 0.0)
+        except Exception:                              # noqa: any failure means "this group stays on c10d"
+            ok = False
+    else:
+        ok = False
+    if not all_ranks_agree_true(ok, device, group):
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:                          # noqa
+                pass
+        _NO_DEVICE_COMM.add(gid)
+        import warnings
+        warnings.warn("xitorch_amd: device-side collectives unavailable for this process group; using c10d all-reduce")
+        return None
+    _COMMS[key] = comm
+    return comm
+
+
+def close_device_comms():
+    for comm in _COMMS.values():
+        try:
+            comm.close()
+        except Exception:                              # noqa
+            pass
+    _COMMS.clear()
+
+
+def _allreduce_(t, group, name):
+    if _trivial(group):
+        return t
+    if t.is_cuda and t.dtype in (torch.float64, torch.float32) and t.is_contiguous():
+        comm = device_comm(group, t.device)
+        if comm is not None:
+            return comm.allreduce_(t, name)
+    op = torch.distributed.ReduceOp.MAX if name == "max" else torch.distributed.ReduceOp.SUM
+    torch.distributed.all_reduce(t, op=op, group=group)
+    return t
+
+
 def allreduce_max_(t, group=None):
     """In-place MAX over the group (no-op when group is None or has a single rank)."""
-    if not _trivial(group):
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
-    return t
+    return _allreduce_(t, group, "max")
 
 
 def allreduce_sum_(t, group=None):
     """In-place SUM over the group (no-op when group is None or has a single rank)."""
-    if not _trivial(group):
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
-    return t
+    return _allreduce_(t, group, "sum")
 
 
 def all_ranks_agree_true(flag, device, group=None):

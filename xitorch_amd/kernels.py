@@ -299,6 +299,10 @@ def small_eigh_tri_ok(k, p, dtype):
 
 SMALL_EIGH_BIG_MAX_K = 768
 SMALL_EIGH_BIG_MAX_P = 64
+# launch shape of K3g's step kernels handed to every call (0 = the library's measured defaults).  Module attributes of
+# the PYTHON layer, for measurement scripts; the C ABI itself has no state
+K3G_WG = 0
+K3G_THREADS = 0
 
 
 def small_eigh_big_ok(k, p, dtype):
@@ -308,7 +312,7 @@ def small_eigh_big_ok(k, p, dtype):
     return fn("xk_small_eigh_big_batch")(k, p, 8 if dtype == torch.float64 else 4) > 0
 
 
-def small_eigh_big(T, k, p, uppest=False):
+def small_eigh_big(T, k, p, uppest=False, wg=None, threads=None):
     """K3g: lowest / uppermost p eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower triangle read) for
     orders beyond the LDS-resident kernels (129 .. 768) or more than 16 wanted pairs (p <= 64, k >= 8): lam (B, p) ascending, Y (B, p, k), failure flags (B,) int32
     (nonzero -> redo with the library).  Replaces torch.linalg.eigh + _take_eigpairs (symeig.py:174-175) on the large
@@ -320,15 +324,18 @@ def small_eigh_big(T, k, p, uppest=False):
     lam = torch.empty((B, p), dtype=T.dtype, device=T.device)
     Y = torch.empty((B, p, k), dtype=T.dtype, device=T.device)
     info = torch.empty((B,), dtype=torch.int32, device=T.device)
-    nws = fn("xk_small_eigh_big_workspace_elems")(B, k)
+    wg = K3G_WG if wg is None else int(wg)
+    threads = K3G_THREADS if threads is None else int(threads)
+    nws = fn("xk_small_eigh_big_workspace_elems")(B, k, wg)
     ws = _workspace(nws, T.dtype, T.device)
     rc = fn("xk_small_eigh_big_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(ws), nws, ptr(info), B, k, p,
-                                                     1 if uppest else 0, T.stride(1), T.stride(0), stream_ptr())
+                                                     1 if uppest else 0, T.stride(1), T.stride(0), wg, threads,
+                                                     stream_ptr())
     check(rc, "xk_small_eigh_big")
     return lam, Y, info
 
 
-def small_eigh(T, k, p, uppest=False, max_sweeps=16, method="jacobi"):
+def small_eigh(T, k, p, uppest=False, max_sweeps=16, method="jacobi", threads=0, profile=None):
     """Lowest / uppermost `p` eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower
     triangle is read).  Returns lam (B, p) ascending, Y (B, p, k) with Y[b, c] the c-th eigenvector, and an int32
     (B,) tensor: Jacobi sweeps (method "jacobi") or the failure flags of the self-check (method "tri": K3t,
@@ -343,7 +350,8 @@ def small_eigh(T, k, p, uppest=False, max_sweeps=16, method="jacobi"):
     aux = torch.empty((B,), dtype=torch.int32, device=T.device)
     if method == "tri":
         rc = fn("xk_small_eigh_tri_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(aux), B, k, p, 1 if uppest else 0,
-                                                         T.stride(1), T.stride(0), stream_ptr())
+                                                         T.stride(1), T.stride(0), int(threads), ptr(profile),
+                                                         stream_ptr())
         check(rc, "xk_small_eigh_tri")
         return lam, Y, aux
     nws = fn("xk_small_eigh_workspace_elems")(B, k, max_sweeps)
@@ -595,7 +603,10 @@ def _destroy_masked_streams():
 
 
 # --------------------------------------------------------------------------- K1s symmetric storage
-def dense_symm(A, X, out=None):
+K1S_OPTS = 0          # `opts` of the K1s entry points handed to every call (measurement scripts; 0 = shipped behaviour)
+
+
+def dense_symm(A, X, out=None, opts=None):
     """Y[b,c,:] = A_b X[b,c,:] for EXACTLY symmetric A (B or 1, N, N): only the upper triangle is read.
     The caller guarantees A == A^T bit for bit.  X, Y panel-major (B, P, N)."""
     require_device(A, "operator matrix")
@@ -615,7 +626,7 @@ def dense_symm(A, X, out=None):
     nws = fn("xk_dense_symm_workspace_elems")(B, N, P, esize)
     ws = _workspace(nws, X.dtype, X.device)
     rc = fn("xk_dense_symm_" + suffix(X.dtype))(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA,
-                                                 ldx, sX, ldy, sY, stream_ptr())
+                                                 ldx, sX, ldy, sY, K1S_OPTS if opts is None else int(opts), stream_ptr())
     check(rc, "xk_dense_symm")
     return out
 
@@ -684,13 +695,14 @@ def dense_symm_split(A, X, out, tiles_stream, timed=False):
         if timed:
             e0, e1 = timing_event_pair()
             e0.record(tiles_stream)
-        rc = fn("xk_dense_symm_tiles_" + sfx)(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, stream_ptr())
+        rc = fn("xk_dense_symm_tiles_" + sfx)(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, K1S_OPTS,
+                                              stream_ptr())
         check(rc, "xk_dense_symm_tiles")
         if timed:
             e1.record(tiles_stream)
         done.record(tiles_stream)
     cur.wait_event(done)
-    rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, stream_ptr())
+    rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, K1S_OPTS, stream_ptr())
     check(rc, "xk_dense_symm_fold")
     return e0, e1
 

@@ -91,7 +91,7 @@ class _Group:
     """State of the Davidson iteration for one contiguous block of the batch, bound to one HIP stream."""
 
     def __init__(self, opA, opM, B, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
-                 precond=None, restart=None):
+                 precond=None, restart=None, capacity=None):
         self.opA, self.opM = opA, opM
         self.precond = precond                    # None | ("diag", dA, dM) | ("op", PanelOperator)
         # (extension) thick restart: None = never (the reference's ever-growing basis); an int = largest basis
@@ -109,7 +109,16 @@ class _Group:
         self.dtype, self.device, self.mode = dtype, device, mode
         self.small_eigh, self.orth_passes = small_eigh, orth_passes
         self.nguess0 = nguess
-        self.cap = min(N, nguess + 8 * p) if N > nguess else nguess
+        # basis storage: known up front with a thick restart (never more than `restart` vectors + one block) or a
+        # caller's `basis_capacity`; otherwise a first guess that `grow` doubles (each growth is a fresh hipMalloc + copy:
+        # ~0.2 s over an un-restarted 64 x 16384 run that reaches 582 vectors — the first call of a process pays it)
+        if restart is not None:
+            want = restart + p
+        elif capacity is not None:
+            want = int(capacity)
+        else:
+            want = nguess + 8 * p
+        self.cap = max(nguess, min(N, want)) if N > nguess else nguess
         z = lambda *shape: torch.zeros(shape, dtype=dtype, device=device)
         self.Vs, self.AVs = z(B, self.cap, Npad), z(B, self.cap, Npad)
         self.MVs = z(B, self.cap, Npad) if opM is not None else None
@@ -542,7 +551,7 @@ GUARD_MAX_REDO = 3
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
-             groups="auto", chain="calls", **unused):
+             groups="auto", chain="calls", basis_capacity=None, **unused):
     """Block Davidson on the HIP kernels; see `_davidson` for the options.  This wrapper is the last line of the
     a-posteriori guard: a run whose Ritz blocks fail it and that cannot be rolled back (thick restarts rewrite the
     basis) is repeated once from the start block with three re-orthogonalised projection passes; a second failure
@@ -550,7 +559,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
     kw = dict(M=M, max_niter=max_niter, nguess=nguess, v_init=v_init, max_addition=max_addition, min_eps=min_eps,
               verbose=verbose, V0=V0, process_group=process_group, trace=trace, rng_device=rng_device,
               small_eigh=small_eigh, overlap=overlap, precond=precond, reserve_cus=reserve_cus, restart=restart,
-              groups=groups, chain=chain, **unused)
+              groups=groups, chain=chain, basis_capacity=basis_capacity, **unused)
     try:
         return _davidson(A, neig, mode, orth_passes=orth_passes, **kw)
     except _GuardFailure as err:
@@ -569,7 +578,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
 def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
               min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
               rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
-              groups="auto", chain="calls", **unused):
+              groups="auto", chain="calls", basis_capacity=None, **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -636,6 +645,11 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         among them) before the new residual block is appended.  Bounds the memory (2 x restart x N per
         batch member) and keeps the Rayleigh–Ritz matrix inside the LDS-resident eigensolver on slowly converging
         spectra; costs extra iterations.  Must be >= ``3 * neig``.
+    basis_capacity: int or None
+        (extension) basis vectors to allocate storage for up front (2 x capacity x N elements per batch member).  Default:
+        ``restart + neig`` with a thick restart, otherwise ``nguess + 8 neig`` doubled on demand — each doubling is a fresh
+        device allocation and a copy, which the first call of a process pays (~0.2 s for a 64 x 16384 run that reaches
+        582 vectors); a caller that knows the run is long can size it once
     V0: tensor or None
         (extension) start block ``(*batch, na, nguess)`` replacing the random draw
     orth_passes: int or str
@@ -766,7 +780,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         with torch.cuda.stream(streams[g]):
             opM = _PanelOperator(M, bdims, B, N) if M is not None else None
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
-                         precond=_pc_slice(b0, b1), restart=restart)
+                         precond=_pc_slice(b0, b1), restart=restart, capacity=basis_capacity)
             grp.k1_stream = k1_stream
             grp.adaptive = adaptive
             # (panels wider than 32 need the chunked orthonormalisation of xk_davidson_orth)

@@ -24,7 +24,7 @@ from xitorch_amd.debug import is_debug_enabled
 from xitorch_amd._util import bcast_shape
 from xitorch_amd import kernels as _k
 
-__all__ = ["LinearOperator", "MatrixLinearOperator", "BandedLinearOperator"]
+__all__ = ["LinearOperator", "MatrixLinearOperator", "BandedLinearOperator", "RowShardedMatrixLinearOperator"]
 
 
 class LinearOperator(EditableModule):
@@ -599,6 +599,100 @@ class MatrixLinearOperator(LinearOperator):
 
     def _getparamnames(self, prefix=""):
         return [prefix + "mat"]
+
+
+# ------------------------------------------------------------------------ row-block sharded dense operator
+class _GatherRows(torch.autograd.Function):
+    """y = concatenation over the ranks of their row blocks (all-gather); every rank continues with the same replicated
+    y, so the gradient of the (replicated) loss w.r.t. this rank's block is its own slice of grad y."""
+
+    @staticmethod
+    def forward(ctx, y_loc, bounds, rank, group):
+        import torch.distributed as dist
+        world = len(bounds) - 1
+        nmax = max(bounds[r + 1] - bounds[r] for r in range(world))
+        ctx.lo, ctx.hi = bounds[rank], bounds[rank + 1]
+        pad = torch.zeros((*y_loc.shape[:-2], nmax, y_loc.shape[-1]), dtype=y_loc.dtype, device=y_loc.device)
+        pad[..., :ctx.hi - ctx.lo, :] = y_loc
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad.contiguous(), group=group)
+        return torch.cat([parts[r][..., :bounds[r + 1] - bounds[r], :] for r in range(world)], dim=-2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy[..., ctx.lo:ctx.hi, :], None, None, None
+
+
+class RowShardedMatrixLinearOperator(LinearOperator):
+    """One dense operator ``A (*B, N, N)`` split by ROW BLOCKS over the ranks of a process group — the sharding for
+    fewer operators than GPUs (last bullet: the batched-operator dimension cannot spread B < G members; a
+    single huge operator otherwise never leaves one GPU).  Rank r holds rows ``[lo_r, hi_r)`` of every batch member
+    (``local_rows (*B, hi_r - lo_r, N)``, contiguous blocks in rank order, `dist.shard_range`); vectors are REPLICATED:
+
+        A x      each rank streams its row block once (K1 on HIP tensors) -> its rows of the result; one all-gather of
+                 the p-column panel (N p s bytes: 786 KB at N = 16384, p = 6 fp64)        (reference product: linop.py:692-702)
+        A^H x    each rank contracts its rows; one all-reduce(SUM) of the (N, p) result
+
+    Everything else of a solver — Gram / Rayleigh blocks, the small eigenproblem, the stopping rule — then runs
+    replicated and identical on every rank (same start block, deterministic kernels), so no further collective and no
+    ``process_group=`` option is needed: pass this operator to `symeig` / `solve` as it is.  The operator stream, which is
+    the whole cost at these sizes, is divided by the number of ranks; the O(k N) chain is not (k N << N^2 / G)."""
+
+    def __init__(self, local_rows, n, process_group=None, is_hermitian=False):
+        import torch.distributed as dist
+        from xitorch_amd.dist import shard_range
+        self.group = process_group
+        world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(process_group) if world > 1 else 0
+        self.world, self.rank = world, rank
+        self.bounds = [shard_range(n, world, r)[0] for r in range(world)] + [n]
+        if local_rows.shape[-1] != n or local_rows.shape[-2] != self.bounds[rank + 1] - self.bounds[rank]:
+            raise RuntimeError("rank %d of %d holds rows [%d, %d) of the (%d, %d) operator: local block must be "
+                               "(*B, %d, %d), got %s" % (rank, world, self.bounds[rank], self.bounds[rank + 1], n, n,
+                                                         self.bounds[rank + 1] - self.bounds[rank], n,
+                                                         tuple(local_rows.shape)))
+        super().__init__(shape=(*local_rows.shape[:-2], n, n), is_hermitian=is_hermitian, dtype=local_rows.dtype,
+                         device=local_rows.device, _suppress_hermit_warning=True)
+        self.local = local_rows
+
+    @classmethod
+    def from_full(cls, mat, process_group=None, is_hermitian=False):
+        """the row block of this rank cut out of a replicated full matrix (tests, small problems)"""
+        import torch.distributed as dist
+        from xitorch_amd.dist import shard_range
+        world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(process_group) if world > 1 else 0
+        lo, hi = shard_range(mat.shape[-1], world, rank)
+        return cls(mat[..., lo:hi, :].contiguous(), mat.shape[-1], process_group, is_hermitian)
+
+    def _gather(self, y_loc):
+        if self.world == 1:
+            return y_loc
+        return _GatherRows.apply(y_loc, self.bounds, self.rank, self.group)
+
+    def _mm(self, x):
+        return self._gather(_dense_mm(self.local, x, False))
+
+    def _mv(self, x):
+        return self._mm(x.unsqueeze(-1)).squeeze(-1)
+
+    def _rmm(self, x):
+        import torch.distributed as dist
+        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        y = _dense_mm(self.local, x[..., lo:hi, :], True)
+        if self.world > 1:
+            y = y.contiguous()
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        return y
+
+    def _rmv(self, x):
+        return self._rmm(x.unsqueeze(-1)).squeeze(-1)
+
+    def _fullmatrix(self):
+        return self._gather(self.local)
+
+    def _getparamnames(self, prefix=""):
+        return [prefix + "local"]
 
 
 # ------------------------------------------------------------------------ native banded operator
