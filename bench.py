@@ -216,10 +216,10 @@ def _panel_bytes(nb, N, p, esize, symm):
     return mat + 2 * nb * N * p * esize
 
 
-def _k1s_source_hash():
+def _k1s_source_hash(names=("xk_symm.hip", "xk_common.h")):
     import hashlib
     h = hashlib.sha256()
-    for name in ("xk_symm.hip", "xk_common.h"):
+    for name in names:
         h.update(open(os.path.join(ROOT, "xitorch_amd", "csrc", name), "rb").read())
     return h.hexdigest()
 
@@ -249,7 +249,7 @@ def _k1_roofline(k1_events, N, p, esize, symm, b_local):
                 # carries the hash of the kernel source it was measured on (scripts/pmc_traffic.sh): a record of
                 # another kernel is not reported
                 stamp = rec.get("kernel_source_sha256")
-                if symm and stamp != _k1s_source_hash():
+                if stamp != (_k1s_source_hash() if symm else _k1s_source_hash(("xk_dense.hip", "xk_common.h"))):
                     traffic_note = "PMC record is stale (kernel source changed since scripts/pmc_traffic.sh ran): not reported"
                 else:
                     traffic = rec.get("hbm_bytes_per_launch") * nb_launch / rec["B"]
@@ -563,7 +563,7 @@ def main():
     if symm and not args.no_general_extra:
         A.symmetric_storage = False
         gev = []
-        g_el, g_evals, g_tr, g_ms = run(A, max(1, min(args.steps, 3)), 1, gev)
+        g_el, g_evals, g_tr, g_ms = run(A, max(1, min(args.steps, 10)), 1, gev)     # (10 x 0.4 s: VERDICT r03 #6)
         A.symmetric_storage = True
         g_roof, _ = _k1_roofline(gev, N, p, esize, False, b_local)
         general = {"value": b_total * p * len(g_ms) / g_el, "unit": "eigpairs/s", "ms_per_step": g_el / len(g_ms) * 1e3,
