@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--max-niter", type=int, default=200, help="guard only; ~19 iterations are needed")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one batch group on one stream (default: two groups, panel products on a CU-masked stream)")
-    ap.add_argument("--reserve-cus", type=int, default=64,
+    ap.add_argument("--reserve-cus", type=lambda v: v if v == "auto" else int(v), default="auto",
                     help="compute units the panel-product stream leaves to the small kernels of the other batch half")
     ap.add_argument("--k1", default="auto", choices=["auto", "general"],
                     help="auto: upper-triangle kernel when the storage is exactly symmetric; general: full matrix")

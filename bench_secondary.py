@@ -264,7 +264,7 @@ def _config_c5(args, dev, group, world, rank, fence, p, label):
         tr = {"k1_events": ev if timed else None}
         with torch.no_grad():
             evals, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=2e-3, rng_device="device",
-                              max_niter=60, process_group=group, trace=tr)
+                              max_niter=60, process_group=group, reserve_cus=args.reserve_cus, trace=tr)
         if timed:
             traces.append((tr, ev))
         return evals, X
@@ -274,7 +274,7 @@ def _config_c5(args, dev, group, world, rank, fence, p, label):
     nbl = [nb for t in traces for (a, b, pc, nb) in t[1] if pc == p][0]
     avg, nl = _avg_ms(events)
     s = 4
-    symm = tr.get("panel_kernel") == "K1s"
+    symm = tr.get("panel_kernel") in ("K1s", "K1sw")
     full_bytes = nbl * N * N * s + 2 * nbl * N * p * s
     tri_bytes = nbl * N * (N + 1) // 2 * s + 2 * nbl * N * p * s
     flops = 2.0 * nbl * N * N * p
@@ -284,6 +284,12 @@ def _config_c5(args, dev, group, world, rank, fence, p, label):
              "full_matrix_equivalent_GBps": full_bytes / (avg * 1e-3) / 1e9}
     if symm:
         extra["priced_on"] = "the bytes the kernel must move: upper triangle + panels (the operator is exactly symmetric)"
+    if tr.get("panel_kernel") == "K1sw":
+        extra["note"] = ("K1sw streams half the bytes of K1w for the same flops (16 flop / B at P = 16 fp32, just under the "
+                         "ridge): it is bound by MFMA issue per wave (matrix pipe ~0.55 busy, profiles/r04_k1sw_variants.jsonl), "
+                         "not by HBM; `frac` stays priced on HBM as SURVEY 8d defines it, `frac_of_fp32_matrix_peak` is the "
+                         "other roofline; the full-matrix kernel K1w reaches 0.76 of HBM peak on twice the bytes and is "
+                         "20-25 % slower per call")
     return {
         "metric": "eigpairs/s of symeig(davidson) fp32 N=32768 (per-GPU shard of batch 128) + panel-product GB/s",
         "value": B * world * p * args.steps / elapsed, "unit": "eigpairs/s", "ms_per_step": elapsed / args.steps * 1e3,
@@ -295,8 +301,11 @@ def _config_c5(args, dev, group, world, rank, fence, p, label):
                    "panel_kernel": tr.get("panel_kernel"), "batch_groups": tr.get("groups"),
                    "orth_redo": tr.get("orth_redo")},
         "roofline": _roofline(tri_bytes if symm else full_bytes, avg, nl,
-                              "dense_symm_tiles<float,6> (K1s)" if symm else
-                              "dense_wide_cols<float,1,Mfma16f> (K1w, v_mfma_f32_16x16x4_f32)", extra),
+                              {"K1s": "dense_symm_tiles<float,6> (K1s)",
+                               "K1sw": "dense_symm_wide_kernel (K1sw: triangle once, v_mfma_f32_16x16x4_f32 for both "
+                                       "products); its fold runs beside it on the group's stream",
+                               "K1w": "dense_wide_cols<float,1,Mfma16f> (K1w, v_mfma_f32_16x16x4_f32)"}.get(
+                                   tr.get("panel_kernel"), str(tr.get("panel_kernel"))), extra),
         "check": {"ok": bool(err < 5e-4), "max_eval_err_vs_closed_form": err,
                   "tolerance": "5e-4 absolute on a spectrum of scale 100 in fp32 (eps32 |A| ~ 1e-5, resid^2 / gap)"},
         "step_ms": step_ms,
@@ -309,7 +318,7 @@ def config_c5(args, dev, group, world, rank, fence):
 
 def config_c5w(args, dev, group, world, rank, fence):
     return _config_c5(args, dev, group, world, rank, fence, 16,
-                      "16-column eigen-block on the matrix cores (K1w), as BASELINE states the config")
+                      "16-column eigen-block on the matrix cores, as BASELINE states the config")
 
 
 CONFIGS = {"c3": config_c3, "c3g": config_c3g, "c4": config_c4, "c5": config_c5, "c5w": config_c5w}

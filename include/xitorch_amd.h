@@ -99,6 +99,22 @@ int xk_dense_symm_fold_f64(double* Y, const double* ws, long ws_elems, int B, in
 int xk_dense_symm_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
                            int opts, void* stream);
 
+/* ---- K1sw: the same product (exactly symmetric storage, upper triangle streamed once) for WIDE panels on the matrix
+ * cores: 9 <= P <= 16 columns, fp32 — BASELINE configs[4]'s 16-column eigen-block (xitorch/_core/linop.py:695-696 inside
+ * _impls/linalg/symeig.py:163,221).  Every 64-row x 128-byte sub-tile on or above the diagonal is loaded once, turned
+ * through LDS per wave and feeds y_I += A_IJ x_J and y_J += A_IJ^T x_I through v_mfma_f32_16x16x4_f32; row / column sums
+ * leave as partials in `ws` (one wave = one 512-row x 256-column tile, no atomics, no block barriers) and a fold adds the
+ * slots that exist in fixed order: run-to-run bit-identical.  N must be a multiple of 64; the 64 x 64 diagonal blocks are
+ * read whole.  ws: xk_dense_symm_wide_workspace_elems(B, N).  _tiles / _fold: the two launches separately (the
+ * eigensolver's two-group pipeline), `ws` untouched in between. */
+long xk_dense_symm_wide_workspace_elems(int B, int N);
+int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
+                           long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+int xk_dense_symm_wide_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
+                                 long lda, long sA, long ldx, long sX, void* stream);
+int xk_dense_symm_wide_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
+                                void* stream);
+
 /* ---- K1w: wide panels on the matrix cores (MFMA) --------------------------------------------
  * Y[b,c,n] = sum_i A[b,i,n] Xrm[b,i,c]  (= A^T X; = A X for a Hermitian operator), c < P <= 32, in ONE
  * pass over A (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64, exact FMA chains).  Xrm is ROW-major

@@ -188,10 +188,13 @@ def test_fullsize_config5_shard_fp32_symeig(dev):
 
 
 @pytest.mark.timeout(900)
-def test_fullsize_config5_shard_fp32_wide_panel_on_the_matrix_cores(dev):
+@pytest.mark.parametrize("storage,kernel", [("symmetric", "K1sw"), ("general", "K1w")])
+def test_fullsize_config5_shard_fp32_wide_panel_on_the_matrix_cores(dev, storage, kernel):
     """BASELINE configs[4] AS STATED ("fp32, MFMA A@V panel"): the per-GPU shard 16 x 32768^2 fp32 with a 16-column
-    eigen-block (neig = nguess = 16), so that every operator-panel product of the eigensolver goes through K1w — the
-    wide-panel kernel on the matrix cores (v_mfma_f32_32x32x2_f32, xk_wide.hip) — inside the two-group pipeline.
+    eigen-block (neig = nguess = 16), so that every operator-panel product of the eigensolver runs on the matrix cores
+    inside the two-group pipeline: K1sw (r04; exactly symmetric storage, upper triangle streamed once,
+    v_mfma_f32_16x16x4_f32 for both y_I += A_IJ x_J and y_J += A_IJ^T x_I, xk_symmwide.hip) or, for an operator whose
+    storage is only allclose-symmetric, K1w (full matrix, xk_wide.hip).
     Eigenvalues against the closed form at fp32 accuracy, residual identity, orthonormality."""
     B, N, p = 16, 32768, 16
     torch.cuda.empty_cache()
@@ -201,12 +204,14 @@ def test_fullsize_config5_shard_fp32_wide_panel_on_the_matrix_cores(dev):
     mat = torch.empty((B, N, N), dtype=torch.float32, device=dev)
     syn.dense_symmetric(B, N, "S1:16", dtype=torch.float32, device=dev, out=mat)
     A = xa.LinearOperator.m(mat, is_hermitian=True)
+    if storage == "general":
+        A.symmetric_storage = False
     tr = {}
     with torch.no_grad():
         ev, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=2e-3, rng_device="device", max_niter=60,
                        trace=tr)
     assert ev.dtype == torch.float32 and tr["stop_reason"] == "converged"
-    assert tr["panel_kernel"] == "K1w", tr["panel_kernel"]
+    assert tr["panel_kernel"] == kernel, tr["panel_kernel"]
     exact = syn.spectrum("S1:16", N, device=dev)[:p]
     assert (ev.double() - exact).abs().max().item() <= 1e-3
     Xp = X.transpose(-2, -1).contiguous()

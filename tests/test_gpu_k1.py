@@ -423,3 +423,48 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
                 assert res.abs().max().item() < tol * scale * 100, tag
                 G = torch.matmul(Yc.transpose(-2, -1), Yc)
                 assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
+
+
+@pytest.mark.parametrize("B,N,P", [(2, 1024, 16), (1, 2048, 9), (3, 1088, 12), (1, 4096, 16), (2, 2304, 13),
+                                   (1, 8192, 16), (2, 1472, 16)])
+def test_dense_symm_wide_mfma_vs_oracle(dev, B, N, P):
+    """K1sw (r04): exactly symmetric fp32 storage, 9 .. 16 panel columns: the upper triangle is streamed once and both
+    y_I += A_IJ x_J and y_J += A_IJ^T x_I run on the matrix cores (torch.matmul(mat, x), linop.py:695-696, inside the
+    eigensolver of BASELINE configs[4]).  Against the oracle's operator; orders that are not multiples of the 256-column
+    strip or the 512-row tile; only the triangle (plus the 64 x 64 diagonal blocks) may be read; bit-reproducible."""
+    g = torch.Generator().manual_seed(N + P)
+    R = torch.randn(B, N, N, dtype=torch.float32, generator=g)
+    A = (R + R.transpose(1, 2)).contiguous()
+    assert torch.equal(A, A.transpose(1, 2))
+    X = torch.randn(B, P, N, dtype=torch.float32, generator=g)
+    ref = oops.DenseOp(A.double())._mm(X.double().transpose(-2, -1)).transpose(-2, -1)
+    Ad, Xd = A.to(dev), X.to(dev)
+    assert K.symm_wide_ok(Ad, Xd)
+    Y = K.dense_symm_wide(Ad, Xd)
+    scale = ref.abs().max().item()
+    assert (Y.cpu().double() - ref).abs().max().item() / scale < 3e-6 * N ** 0.5
+    assert torch.equal(K.dense_symm_wide(Ad, Xd), Y)
+    # everything strictly below the diagonal and outside the 64 x 64 diagonal blocks is never touched
+    i = torch.arange(N)
+    untouched = (i[:, None] > i[None, :]) & ((i[:, None] // 64) != (i[None, :] // 64))
+    Ap = Ad.clone()
+    Ap[:, untouched.to(dev)] = float("nan")
+    assert torch.equal(K.dense_symm_wide(Ap, Xd), Y)
+    # one operator for the whole panel batch
+    Y1 = K.dense_symm_wide(Ad[:1], Xd)
+    ref1 = torch.matmul(A[:1].double(), X.double().transpose(-2, -1)).transpose(-2, -1)
+    assert (Y1.cpu().double() - ref1).abs().max().item() / scale < 3e-6 * N ** 0.5
+    # the eigensolver's operator wrapper picks this kernel for such panels, also in its split (two-stream) form
+    from xitorch_amd.linalg._panel import PanelOperator
+    op = PanelOperator(LinearOperator.m(Ad, is_hermitian=True), [B], B, N)
+    ld = (N + 7) // 8 * 8
+    Xp = torch.zeros(B, P, ld, dtype=torch.float32, device=dev)
+    Xp[:, :, :N] = Xd
+    out = torch.zeros_like(Xp)
+    op.apply(Xp, out)
+    assert op.last_kernel == "K1sw" and torch.equal(out[:, :, :N], Y)
+    side = torch.cuda.Stream(device=dev)
+    out2 = torch.zeros_like(Xp)
+    op.apply_on(Xp, out2, side)
+    torch.cuda.synchronize()
+    assert torch.equal(out2[:, :, :N], Y)

@@ -1,0 +1,356 @@
+// xitorch_amd :: K1sw — the operator-panel product of an EXACTLY SYMMETRIC operator for wide panels (9 .. 16 columns)
+// on the matrix cores, streaming only the upper triangle:
+//
+//        Y[b, c, :] = A_b X[b, c, :],   A_b == A_b^T bit for bit,   9 <= P <= 16   (fp32: BASELINE configs[4], a 16-column
+//                                                                    eigen-block on a MatrixLinearOperator N = 32768)
+//
+// Replaces `torch.matmul(mat, x)` (xitorch/_core/linop.py:695-696) inside the eigensolver (symeig.py:163,221) where K1s
+// (xk_symm.hip, VALU, P <= 6 per pass) would re-stream the triangle three times and K1w (xk_wide.hip, MFMA) reads the
+// whole matrix: every 64-row x 128-byte sub-tile on or above the diagonal is loaded ONCE and feeds both
+//
+//        row part   y_I += A_IJ  x_J      M = 16 operator rows,    K = 4 operator columns, N = 16 panel columns
+//        col part   y_J += A_IJ^T x_I     M = 16 operator columns, K = 4 operator rows,    N = 16 panel columns
+//
+// through v_mfma_f32_16x16x4_f32 (exact FMA chains).  The contraction index of the row part is the contiguous one, so
+// — as in K1wr (xk_rowswide.hip) — each wave turns its sub-tile through LDS (8 coalesced 16 B/lane non-temporal loads
+// -> ds_write_b64 with a 136-byte pitch) and reads it back in the MFMA operand layouts with ds_read_b64 (two k-steps /
+// two column blocks per read, conflict-free for both parts); the panel operands: x_J (8 values per lane) arrives with
+// each sub-tile's loads from the L1 / L2-resident panel, x_I is parked in LDS once per 64-row band.
+//
+// Decomposition (no atomics, no block barriers, bit-reproducible): a WAVE owns one tile = TR rows x WS = 8 sub-tiles
+// (256 fp32 columns); it walks the tile's 64-row bands top to bottom, each band left to right with the next sub-tile's
+// loads in flight, keeps the band's row sums (16 accumulators) and the strip's column sums (64 accumulators, in AGPRs)
+// in registers and leaves them as partials:  rowP[b][strip][c][row]  once per band,  colP[b][row tile][c][col]  once
+// per tile; `symm_wide_fold` adds, per output element, exactly the slots that exist, in fixed order.  The diagonal
+// 64 x 64 block of a band is used WHOLE (both triangles are in storage and equal) for the row part and not at all for
+// the column part, so no masks exist anywhere; sub-tiles left of it are "loaded" through an out-of-range buffer offset
+// (hardware zeros, no traffic).  Extra traffic of the partials: about 19 % of the triangle bytes at N = 32768.
+#include "xk_common.h"
+
+namespace xk {
+
+constexpr int SW_ROWS = 64;                      // rows per band
+constexpr int SW_SEG_BYTES = 128;                // bytes of one row inside a sub-tile
+constexpr int SW_PITCH = SW_SEG_BYTES + 8;       // 34 dwords: ds_read_b64 of 16 rows / of one row hit 32 distinct banks
+constexpr int SW_TILE_LDS = SW_ROWS * SW_PITCH;  // 8704 B per wave
+constexpr int SW_XI_LDS = 16 * 64 * 4;           // the band's x_I in the column part's B-operand layout (4096 B)
+constexpr int SW_WAVE_LDS = SW_TILE_LDS;                         // 8704 B per wave
+constexpr int SW_NSUB = 8;                       // sub-tiles per strip
+
+typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sw_f32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t SwRsrc;
+
+__device__ __forceinline__ SwRsrc sw_rsrc(const void* base, long bytes) {
+  const uint64_t v = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  void* b = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xffffffffL ? 0xffffffffL : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(b, (short)0, (int)nrec, 0x00020000);
+}
+
+__device__ __forceinline__ sw_f32x4 sw_mma(float a, float b, sw_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// row tiles of strip s: rows [0, min(N, (s + 1) WS)) in pieces of TR
+__host__ __device__ inline int sw_tiles_of_strip(int s, int N, int WS, int TR) {
+  long top = (long)(s + 1) * WS;
+  if (top > N) top = N;
+  return (int)((top + TR - 1) / TR);
+}
+
+// fp32 only (the 16-wide fp64 MFMA holds the matrix pipe ~120 cycles: a symmetric fp64 kernel of this shape would be
+// bound by it at half the triangle rate K1s reaches on the VALU)
+__global__ __launch_bounds__(256) void dense_symm_wide_kernel(
+    const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ rowP, float* __restrict__ colP,
+    int N, int pc, long lda, long sA, long ldx, long sX, int NS, int NT, int TR, int tiles_per_op, long total_tiles) {
+  typedef float T;
+  constexpr int SEG = SW_SEG_BYTES / (int)sizeof(T);          // 32 columns per sub-tile
+  constexpr int WS = SW_NSUB * SEG;                           // 256 columns per strip
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long gt = (long)blockIdx.x * 4 + wave;
+  if (gt >= total_tiles) return;
+  const int b = __builtin_amdgcn_readfirstlane((int)(gt / tiles_per_op));
+  int ti = __builtin_amdgcn_readfirstlane((int)(gt - (long)b * tiles_per_op));
+  int s = 0;
+  for (;;) {                                                   // (scalar: at most N / 256 steps, once per wave)
+    const int cnt = sw_tiles_of_strip(s, N, WS, TR);
+    if (ti < cnt) break;
+    ti -= cnt;
+    ++s;
+  }
+  s = __builtin_amdgcn_readfirstlane(s);
+  const int I = __builtin_amdgcn_readfirstlane(ti);
+  const int col0 = s * WS;
+  const int r_begin = I * TR;
+  int r_end = r_begin + TR;
+  r_end = r_end < N ? r_end : N;
+  r_end = r_end < col0 + WS ? r_end : col0 + WS;              // bands below the strip's last column: lower triangle only
+  char* tile = smem + wave * SW_WAVE_LDS;
+  const float* Ab = A + (long)b * sA;
+  const float* Xb = X + (long)b * sX;
+  const int mm = lane & 15, kq = lane >> 4;                   // MFMA operand coordinates
+  const int lrow = lane >> 3, lcol = lane & 7;                // load phase: 8 rows x 8 lanes of 16 B
+  const bool cok = mm < pc;
+  const float* Xc = Xb + (long)(cok ? mm : 0) * ldx;          // panel column of this lane (columns >= pc: zeros)
+
+  sw_f32x4 acc_col[SW_NSUB][2];
+#pragma unroll
+  for (int t = 0; t < SW_NSUB; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_col[t][h][r] = 0.f;
+
+  const unsigned ldab = (unsigned)(lda * (long)sizeof(T));
+  const unsigned lane_off = (unsigned)lrow * ldab + (unsigned)lcol * 16u;
+  const unsigned st_off = (unsigned)lrow * SW_PITCH + (unsigned)lcol * 16u;
+  constexpr unsigned POISON = 0x7ffffff0u;
+
+  // sub-tile (row0, t): voff of load tt = lane_off + tt * 8 rows; skipped sub-tiles (left of the diagonal block, or past
+  // the matrix) read zeros through the poison offset
+  auto issue = [&](sw_f32x4 (&a)[8], const SwRsrc& ra, int row0, int t, bool exists) {
+    const int c0 = col0 + t * SEG;
+    const bool live = exists && (c0 + SEG > row0) && (c0 < N);
+    const unsigned base = live ? lane_off + (unsigned)(c0 - col0) * (unsigned)sizeof(T) : POISON;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const unsigned voff = live ? base + (unsigned)(tt * 8) * ldab : POISON;
+      a[tt] = __builtin_bit_cast(sw_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)voff, 0, 2));
+    }
+  };
+
+  // ---- ONE wave per SIMD (4 per compute unit, ~390 registers): two register buffers — the next sub-tile's loads are
+  //      issued before this one's LDS turn and MFMAs, across bands — one LDS tile per wave; x_J of the whole strip (64
+  //      values per lane, once per tile) and x_I of the band (16, once per band) stay in registers.  Measured against the
+  //      alternatives on 8 x 32768^2 (profiles/r04_k1sw_variants.jsonl): this 3.5 ms; two waves per SIMD with one buffer
+  //      3.6-3.7; a ring of four buffers + two LDS tiles 3.9 (register-file moves); any variant that spills inside the
+  //      stream 7.6 (a scratch reload turns the counted waits into vmcnt(0)).
+  float xj[SW_NSUB][4][2];                                     // xj[t][j][h] = X[c = mm][col0 + 32 t + 8 j + 2 kq + h]
+#pragma unroll
+  for (int t = 0; t < SW_NSUB; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + t * SEG + 8 * j + 2 * kq;
+      sw_f32x2 v = {0.f, 0.f};
+      if (cok && col < N) v = *reinterpret_cast<const sw_f32x2*>(Xc + col);
+      xj[t][j][0] = v[0];
+      xj[t][j][1] = v[1];
+    }
+  sw_f32x4 abuf[2][8];
+  // descriptor of a band: its 64 rows from column col0 on
+  auto band_rsrc = [&](int row0) {
+    return sw_rsrc(Ab + (long)row0 * lda + col0, ((long)(SW_ROWS - 1) * lda + (N - col0)) * (long)sizeof(T));
+  };
+  if (r_begin >= r_end) return;
+  {
+    const SwRsrc r0 = band_rsrc(r_begin);
+    issue(abuf[0], r0, r_begin, 0, true);
+  }
+  for (int row0 = r_begin; row0 < r_end; row0 += SW_ROWS) {
+    const SwRsrc ra = band_rsrc(row0);
+    const bool more = row0 + SW_ROWS < r_end;
+    const int rown = more ? row0 + SW_ROWS : row0;            // (no next band: poisoned loads, results unused)
+    const SwRsrc rn = band_rsrc(rown);
+    // ---- x_I of the band in the column part's B-operand layout: xi[kk] = X[c = mm][row0 + 4 kk + kq]
+    float xi[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float v = Xc[row0 + 4 * kk + kq];                 // (unconditional load, then select: no exec-masked branches)
+      xi[kk] = cok ? v : 0.f;
+    }
+    sw_f32x4 acc_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_row[i][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < SW_NSUB; ++t) {
+      sw_f32x4(&acur)[8] = abuf[t & 1];
+      sw_f32x4(&anxt)[8] = abuf[(t + 1) & 1];
+      // next sub-tile's loads go out before this one's LDS turn and MFMAs (the last of a band fetches the next band's
+      // first: the prefetch is carried across bands)
+      if (t + 1 < SW_NSUB) issue(anxt, ra, row0, t + 1, true);
+      else issue(anxt, rn, rown, 0, more);
+      __builtin_amdgcn_sched_barrier(0);
+      const int c0 = col0 + t * SEG;
+      const bool both = (c0 >= row0 + SW_ROWS) && (c0 < N);   // right of the diagonal block: column part too
+      // ---- LDS turn: [row][column], 136-byte pitch
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        char* p = tile + st_off + (unsigned)(tt * 8) * SW_PITCH;
+        *reinterpret_cast<sw_f32x2*>(p) = sw_f32x2{acur[tt][0], acur[tt][1]};
+        *reinterpret_cast<sw_f32x2*>(p + 8) = sw_f32x2{acur[tt][2], acur[tt][3]};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the wave's own writes have landed
+      const char* rrow = tile + (unsigned)mm * SW_PITCH + (unsigned)(2 * kq) * 4u;      // + 16 i rows, + 8 j columns
+      const char* rcol = tile + (unsigned)kq * SW_PITCH + (unsigned)(2 * mm) * 4u;      // + 4 kk rows
+      // ---- row part: rows 16 i + mm, columns 8 j + 2 kq (+1): one ds_read_b64 = the A operands of two k-steps; the
+      //      four row blocks are four independent accumulator chains, visited round-robin
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sw_f32x2 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = *reinterpret_cast<const sw_f32x2*>(rrow + (unsigned)(16 * i) * SW_PITCH + (unsigned)(8 * j) * 4u);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc_row[i] = sw_mma(v[i][h], xj[t][j][h], acc_row[i]);
+      }
+      // ---- column part: rows 4 kk + kq, columns 2 mm (even block) and 2 mm + 1 (odd block): one ds_read_b64 = the A
+      //      operands of both column blocks for one k-step; k-steps of either parity go to accumulators of their own
+      //      (four independent chains), added at the end of the sub-tile
+      if (both) {
+        sw_f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+          const sw_f32x2 w0 = *reinterpret_cast<const sw_f32x2*>(rcol + (unsigned)(4 * kk) * SW_PITCH);
+          const sw_f32x2 w1 = *reinterpret_cast<const sw_f32x2*>(rcol + (unsigned)(4 * kk + 4) * SW_PITCH);
+          acc_col[t][0] = sw_mma(w0[0], xi[kk], acc_col[t][0]);
+          acc_col[t][1] = sw_mma(w0[1], xi[kk], acc_col[t][1]);
+          ce = sw_mma(w1[0], xi[kk + 1], ce);
+          co = sw_mma(w1[1], xi[kk + 1], co);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc_col[t][0][r] += ce[r];
+          acc_col[t][1][r] += co[r];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the next turn overwrites the tile
+    }
+    // ---- the band's row sums: rowP[b][s][c][row0 + 16 i + 4 kq + r]   (D: lane holds column c = mm, rows 4 kq + r)
+    if (cok) {
+      float* rp = rowP + (((long)b * NS + s) * 16 + mm) * (long)N + row0 + 4 * kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(acc_row[i], reinterpret_cast<sw_f32x4*>(rp + 16 * i));
+    }
+  }
+  // ---- the tile's column sums: colP[b][I][c][col0 + 32 t + 8 kq + {e0, o0, e1, o1, e2, o2, e3, o3}]
+  if (cok) {
+    float* cp = colP + (((long)b * NT + I) * 16 + mm) * (long)N + col0 + 8 * kq;
+#pragma unroll
+    for (int t = 0; t < SW_NSUB; ++t) {
+      if (col0 + t * SEG < N) {
+        const sw_f32x4 lo = {acc_col[t][0][0], acc_col[t][1][0], acc_col[t][0][1], acc_col[t][1][1]};
+        const sw_f32x4 hi = {acc_col[t][0][2], acc_col[t][1][2], acc_col[t][0][3], acc_col[t][1][3]};
+        __builtin_nontemporal_store(lo, reinterpret_cast<sw_f32x4*>(cp + t * SEG));
+        __builtin_nontemporal_store(hi, reinterpret_cast<sw_f32x4*>(cp + t * SEG + 4));
+      }
+    }
+  }
+}
+
+// Y[b][c][n] = sum of the row partials of the strips that hold row n (strip n / WS and every strip right of it) and of
+// the column partials of the row tiles that hold column n (tiles 0 .. n / TR), each list in ascending order
+__global__ __launch_bounds__(256) void symm_wide_fold(const float* __restrict__ rowP, const float* __restrict__ colP,
+                                                       float* __restrict__ Y, int N, int pc, int NS, int NT, int TR,
+                                                       int WS, long ldy, long sY, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over B * pc * N
+  if (idx >= total) return;
+  const long per_b = (long)pc * N;
+  const long b = idx / per_b;
+  const long rem = idx - b * per_b;
+  const int c = (int)(rem / N);
+  const int n = (int)(rem - (long)c * N);
+  // (eight loads in flight per thread: a serial chain of ~100 dependent strided reads ran at 3.5 TB/s)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float* rp = rowP + (b * NS * 16 + c) * (long)N + n;
+  const long rstep = 16L * N;
+  int s = n / WS;
+  for (; s + 4 <= NS; s += 4) {
+    const float v0 = __builtin_nontemporal_load(rp + s * rstep), v1 = __builtin_nontemporal_load(rp + (s + 1) * rstep);
+    const float v2 = __builtin_nontemporal_load(rp + (s + 2) * rstep), v3 = __builtin_nontemporal_load(rp + (s + 3) * rstep);
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; s < NS; ++s) a0 += __builtin_nontemporal_load(rp + s * rstep);
+  const float* cp = colP + (b * NT * 16 + c) * (long)N + n;
+  const int I1 = n / TR;
+  int I = 0;
+  for (; I + 4 <= I1 + 1; I += 4) {
+    const float v0 = __builtin_nontemporal_load(cp + I * rstep), v1 = __builtin_nontemporal_load(cp + (I + 1) * rstep);
+    const float v2 = __builtin_nontemporal_load(cp + (I + 2) * rstep), v3 = __builtin_nontemporal_load(cp + (I + 3) * rstep);
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; I <= I1; ++I) a1 += __builtin_nontemporal_load(cp + I * rstep);
+  const float sum = (a0 + a1) + (a2 + a3);
+  Y[b * sY + (long)c * ldy + n] = sum;
+}
+
+static int symm_wide_tr(int N) { return N >= 4096 ? 512 : 256; }
+
+static int symm_wide(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P, long lda,
+                     long sA, long ldx, long sX, long ldy, long sY, int phase, hipStream_t st) {
+  constexpr int WS = SW_NSUB * (SW_SEG_BYTES / 4);
+  if (P < 1 || P > 16) return XK_ERR_ARG;
+  if ((N % SW_ROWS) || (lda % 4) || (sA % 4) || (ldx % 2) || (sX % 2) || ((uintptr_t)A & 15) || ((uintptr_t)X & 7) ||
+      ((uintptr_t)ws & 15))
+    return XK_ERR_UNSUPPORTED;
+  if ((long)SW_ROWS * lda * 4 > 0x7fffffe0L) return XK_ERR_UNSUPPORTED;
+  const int TR = symm_wide_tr(N);
+  const int NS = (N + WS - 1) / WS, NT = (N + TR - 1) / TR;
+  const long nrow = (long)B * NS * 16 * N, ncol = (long)B * NT * 16 * N;
+  if (ws == nullptr || ws_elems < nrow + ncol) return XK_ERR_ARG;
+  float* rowP = ws;
+  float* colP = ws + nrow;
+  if (phase != 2) {
+    int tiles = 0;
+    for (int s = 0; s < NS; ++s) tiles += sw_tiles_of_strip(s, N, WS, TR);
+    const long total = (long)B * tiles;
+    const size_t lds = 4 * (size_t)SW_WAVE_LDS;
+    hipLaunchKernelGGL(dense_symm_wide_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), lds, st, A, X, rowP, colP,
+                       N, P, lda, sA, ldx, sX, NS, NT, TR, tiles, total);
+    XK_LAUNCH_CHECK();
+  }
+  if (phase != 1) {
+    const long total = (long)B * P * N;
+    hipLaunchKernelGGL(symm_wide_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rowP, colP, Y, N, P,
+                       NS, NT, TR, WS, ldy, sY, total);
+    XK_LAUNCH_CHECK();
+  }
+  return XK_OK;
+}
+
+}  // namespace xk
+
+extern "C" {
+
+// workspace (elements): row partials (B, NS, 16, N) + column partials (B, NT, 16, N)
+long xk_dense_symm_wide_workspace_elems(int B, int N) {
+  constexpr int WS = xk::SW_NSUB * (xk::SW_SEG_BYTES / 4);
+  const int TR = xk::symm_wide_tr(N);
+  const long NS = (N + WS - 1) / WS, NT = (N + TR - 1) / TR;
+  return (long)B * (NS + NT) * 16 * N;
+}
+
+int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
+                           long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream) {
+  if (B < 0 || N < 0) return XK_ERR_ARG;
+  if (B == 0 || N == 0) return XK_OK;
+  return xk::symm_wide(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, 0, (hipStream_t)stream);
+}
+
+// the two halves as separate launches (the eigensolver's two-group pipeline: tiles on the CU-masked panel stream, the
+// fold on the group's own stream); `ws` must stay untouched in between
+int xk_dense_symm_wide_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
+                                 long lda, long sA, long ldx, long sX, void* stream) {
+  if (B < 0 || N < 0) return XK_ERR_ARG;
+  if (B == 0 || N == 0) return XK_OK;
+  return xk::symm_wide(A, X, nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, 1, (hipStream_t)stream);
+}
+
+int xk_dense_symm_wide_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
+                                void* stream) {
+  if (B < 0 || N < 0) return XK_ERR_ARG;
+  if (B == 0 || N == 0) return XK_OK;
+  return xk::symm_wide((const float*)ws, (const float*)ws, Y, (float*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, 2,
+                       (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -631,6 +631,79 @@ def dense_symm(A, X, out=None, opts=None):
     return out
 
 
+# --------------------------------------------------------------------------- K1sw symmetric storage, wide panels (MFMA)
+SYMM_WIDE_MIN_P, SYMM_WIDE_MAX_P = 9, 16
+SYMM_WIDE_MIN_N = 1024        # below this the tiles are too few to fill the chip: K1w / K1s serve
+
+
+def symm_wide_ok(A, X):
+    """does K1sw (upper triangle streamed once, both products on the matrix cores) serve this operator / panel?"""
+    N, P = X.shape[2], X.shape[1]
+    if A.dtype != torch.float32 or X.dtype != torch.float32 or not (SYMM_WIDE_MIN_P <= P <= SYMM_WIDE_MAX_P):
+        return False
+    lda = A.stride(-2)
+    sA = A.stride(0) if (A.dim() == 3 and A.shape[0] != 1) else 0
+    return (N >= SYMM_WIDE_MIN_N and N % 64 == 0 and lda % 4 == 0 and sA % 4 == 0 and A.data_ptr() % 16 == 0
+            and X.stride(1) % 2 == 0 and X.stride(0) % 2 == 0 and X.data_ptr() % 8 == 0 and 64 * lda * 4 < 2 ** 31 - 32)
+
+
+def _symm_wide_args(A, X, out):
+    B, P, N = X.shape
+    if A.dim() == 2:
+        lda, sA = A.stride(0), 0
+    else:
+        lda, sA = A.stride(1), (A.stride(0) if A.shape[0] != 1 else 0)
+    if A.shape[-1] != N or A.shape[-2] != N or (N > 1 and A.stride(-1) != 1):
+        raise _capi.NativeLibraryError("symmetric operator must be (.., %d, %d) with unit stride" % (N, N))
+    ldx, sX = _panel_strides(X)
+    ldy, sY = _panel_strides(out)
+    nws = fn("xk_dense_symm_wide_workspace_elems")(B, N)
+    return B, P, N, lda, sA, ldx, sX, ldy, sY, nws
+
+
+def dense_symm_wide(A, X, out=None):
+    """Y[b,c,:] = A_b X[b,c,:] for EXACTLY symmetric fp32 A (B or 1, N, N) and 9 .. 16 panel columns: the upper triangle
+    is streamed once, both y_I += A_IJ x_J and y_J += A_IJ^T x_I run on the matrix cores (K1sw).  The caller guarantees
+    A == A^T bit for bit.  X, Y panel-major (B, P, N)."""
+    require_device(A, "operator matrix")
+    require_device(X, "panel")
+    if out is None:
+        out = torch.empty_like(X)
+    B, P, N, lda, sA, ldx, sX, ldy, sY, nws = _symm_wide_args(A, X, out)
+    ws = _workspace(nws, X.dtype, X.device)
+    rc = fn("xk_dense_symm_wide_f32")(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, ldy, sY,
+                                      stream_ptr())
+    check(rc, "xk_dense_symm_wide")
+    return out
+
+
+def dense_symm_wide_split(A, X, out, tiles_stream, timed=False):
+    """K1sw with its two launches on two streams, like `dense_symm_split`: the tile kernel on `tiles_stream`, the fold
+    back on the current stream.  Returns the timing events around the tile kernel when `timed`."""
+    require_device(A, "operator matrix")
+    require_device(X, "panel")
+    B, P, N, lda, sA, ldx, sX, ldy, sY, nws = _symm_wide_args(A, X, out)
+    cur = torch.cuda.current_stream()
+    ws = _workspace(nws, X.dtype, X.device)                 # keyed by the CURRENT (group) stream
+    ready, done = sync_events(cur)
+    ready.record(cur)
+    e0 = e1 = None
+    with torch.cuda.stream(tiles_stream):
+        tiles_stream.wait_event(ready)
+        if timed:
+            e0, e1 = timing_event_pair()
+            e0.record(tiles_stream)
+        rc = fn("xk_dense_symm_wide_tiles_f32")(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, stream_ptr())
+        check(rc, "xk_dense_symm_wide_tiles")
+        if timed:
+            e1.record(tiles_stream)
+        done.record(tiles_stream)
+    cur.wait_event(done)
+    rc = fn("xk_dense_symm_wide_fold_f32")(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, stream_ptr())
+    check(rc, "xk_dense_symm_wide_fold")
+    return e0, e1
+
+
 # --------------------------------------------------------------------------- events without per-launch creation
 # Creating a HIP event costs host time (and every few hundred of them the runtime grows a pool: a ~30 ms stall seen
 # once per process in the benchmark's timed region).  Cross-stream ordering therefore re-records two cached events per

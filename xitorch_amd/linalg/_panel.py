@@ -14,6 +14,8 @@ from xitorch_amd import kernels as K
 
 __all__ = ["PanelOperator", "pad_len", "to_panel", "from_panel"]
 
+K1S_MIN_BYTES = 1.5e9      # operator storage from which the upper-triangle kernel K1s beats the full-matrix kernels
+
 
 def pad_len(n):
     return (n + 7) // 8 * 8     # elements: keeps every vector 64 B aligned for f64 and f32
@@ -38,6 +40,7 @@ class PanelOperator:
         self.A, self.bdims, self.Bt, self.N = A, list(bdims), Bt, N
         self.kind = "generic"
         self.symm = False
+        self.symm_narrow = False
         self.napply = 0
         self.last_kernel = None     # which panel kernel served the last native apply (K1s / K1w / K1wr / K1 / banded)
         self.events = None          # when a list: (start, end, p) HIP events around every native launch
@@ -67,6 +70,12 @@ class PanelOperator:
                 # exactly symmetric storage: stream the upper triangle only (K1s)
                 self.symm = bool(getattr(A, "symmetric_storage", False)) and N % vn == 0 and \
                     self.mat.stride(-2) % vn == 0 and not self.cplx
+                # ... where that pays: K1s walks 1024-row tiles, one workgroup each, and has a floor of ~235 us per
+                # launch (two launches) however small the operator; the one-launch full-matrix kernels are faster up to
+                # ~1.5 GB of operator storage although they read twice the bytes (scripts/k1s_small_crossover.py,
+                # profiles/r04_k1s_small_crossover.jsonl: 1 x 512^2 fp64 127 vs 11 us, 8 x 2048^2 236 vs 44, 4 x 4096^2
+                # 238 vs 95)
+                self.symm_narrow = self.symm and self.mat.numel() * self.mat.element_size() >= K1S_MIN_BYTES
         elif isinstance(A, BandedLinearOperator) and native_t(A.band) and (nA == Bt or nA == 1) \
                 and A.band.is_contiguous():
             self.kind = "banded"
@@ -109,11 +118,19 @@ class PanelOperator:
         and the result ordered into the current stream.  For the symmetric-storage kernel only the tile kernel
         goes to `k1_stream`; its small fold runs on the current stream, off the panel-product critical path."""
         N = self.N
-        if self.kind == "dense" and self.symm and X.shape[1] <= 6 and not self.flip:
+        if self.kind == "dense" and self.symm and self.symm_narrow and X.shape[1] <= 6 and not self.flip:
             self.napply += 1
             self.last_kernel = "K1s"
             e0, e1 = K.dense_symm_split(self.mat, X[:, :, :N], out[:, :, :N], k1_stream,
                                         timed=self.events is not None)
+            if self.events is not None:
+                self.events.append((e0, e1, X.shape[1], X.shape[0]))
+            return out
+        if self.kind == "dense" and self.symm and not self.flip and K.symm_wide_ok(self.mat, X[:, :, :N]):
+            self.napply += 1
+            self.last_kernel = "K1sw"
+            e0, e1 = K.dense_symm_wide_split(self.mat, X[:, :, :N], out[:, :, :N], k1_stream,
+                                             timed=self.events is not None)
             if self.events is not None:
                 self.events.append((e0, e1, X.shape[1], X.shape[0]))
             return out
@@ -134,7 +151,11 @@ class PanelOperator:
             K.dense_mm_complex(self.mat if self.mat.dim() == 3 else self.mat.unsqueeze(0), X[:, :, :N],
                                adjoint=(self.flip != trans), conj_io=(self.flip != self.cj), out=out[:, :, :N])
             return out
-        if self.kind == "dense" and self.symm and X.shape[1] < K.WIDE_MIN_P:
+        if self.kind == "dense" and self.symm and not self.flip and K.symm_wide_ok(self.mat, X[:, :, :N]):
+            # exactly symmetric fp32 storage, 9 .. 16 columns: the triangle once, both products on the matrix cores
+            self.last_kernel = "K1sw"
+            K.dense_symm_wide(self.mat, X[:, :, :N], out=out[:, :, :N])
+        elif self.kind == "dense" and self.symm and self.symm_narrow and X.shape[1] < K.WIDE_MIN_P:
             self.last_kernel = "K1s"
             K.dense_symm(self.mat, X[:, :, :N], out=out[:, :, :N])
         elif self.kind == "dense":

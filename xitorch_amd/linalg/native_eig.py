@@ -550,7 +550,7 @@ GUARD_MAX_REDO = 3
 
 def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
              min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
-             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
+             rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus="auto", restart=None,
              groups="auto", chain="calls", basis_capacity=None, **unused):
     """Block Davidson on the HIP kernels; see `_davidson` for the options.  This wrapper is the last line of the
     a-posteriori guard: a run whose Ritz blocks fail it and that cannot be rolled back (thick restarts rewrite the
@@ -577,7 +577,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
 
 def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
               min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
-              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus=64, restart=None,
+              rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus="auto", restart=None,
               groups="auto", chain="calls", basis_capacity=None, **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
@@ -624,10 +624,12 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         host read of its status and ~20 kernel launches per iteration, and at the batch sizes where the chain is
         exposed the host is the limit: 8 operators of order 16384: 32.7 ms with 2 groups, 40.1 with 3, 52 with 4;
         16 operators: 56.6 vs 69.8 ms with 4 (r02).  An integer forces it (clamped to the batch size)
-    reserve_cus: int
-        (extension) compute units the panel-product stream leaves to the small kernels (default 64 of 256: the
-        HBM-bound panel product is as fast on 192 CUs as on all of them; whole 32-CU mask words measured best:
-        224.2 ms per config-2 call with 64, 227.5 with 32, 233 with 48 or 8, 241 with 96)
+    reserve_cus: int or str
+        (extension) compute units the panel-product stream leaves to the small kernels.  ``"auto"`` (default): 64 of 256
+        for the HBM-bound panel kernels (as fast on 192 CUs as on all of them; whole 32-CU mask words measured best:
+        224.2 ms per config-2 call with 64, 227.5 with 32, 233 with 48 or 8, 241 with 96), 32 when the panel product is
+        K1sw (fp32, 9 .. 16 columns, symmetric storage: issue-bound on the matrix cores, it scales with the CUs it gets —
+        configs[4] shard: 120.6 ms per call with 64, 109.5 with 32, 109.8 with 16 or 8)
     chain: str
         (extension) ``"calls"`` (default): every stage between two operator-panel products (rotation + residual +
         status, orthonormalisation of the new block, extension of T) is enqueued by one C call
@@ -719,6 +721,10 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
             ngrp = 2
         else:
             ngrp = max(2, min(int(groups), B))
+    if reserve_cus == "auto":
+        wide_symm = whole.kind == "dense" and whole.symm and dtype == torch.float32 and \
+            K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and N >= K.SYMM_WIDE_MIN_N and N % 64 == 0
+        reserve_cus = 32 if wide_symm else 64
     if two:
         try:
             grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
