@@ -16,7 +16,8 @@ product K1 is the only O(N^2) work and everything else is an O(k N) stream:
   * the full CholeskyQR of [V, t] (tallqr, _utils/tensor.py:8-19) becomes block Gram–Schmidt of
     the new panel against the (already orthonormal) basis + CholeskyQR of the panel alone — in
     exact arithmetic the same Q, since chol([[I, C],[C^T, G]]) = [[I, C],[0, chol(G - C^T C)]];
-  * one host sync per iteration and batch group (the reference has three: symeig.py:196,200,202);
+  * one host sync per iteration and batch group (the reference has three: symeig.py:196,200,202), also in sharded
+    runs: the all-reduce of the status runs on the device, in stream order, before that read;
   * large batches of native dense operators run as two groups: the panel products of both groups back to back on
     one CU-masked stream, each group's small kernels on its own hardware queue underneath the other group's
     panel product (option `overlap`).
@@ -104,6 +105,7 @@ class _Group:
         self._compress = None                     # (Yt (B, pk, k), lam_all (B, pk)) of a pending restart
         self.nrestart = 0
         self.k1_stream = None                     # two-group pipeline: the (CU-masked) stream of the panel products
+        self.pg = None                            # sharded runs: the process group whose ranks decide together
         self.timeline, self.tag = None, 0         # debugging: (tag, label, start event, end event) per phase
         self.B, self.N, self.Npad, self.p = B, N, Npad, p
         self.dtype, self.device, self.mode = dtype, device, mode
@@ -330,6 +332,14 @@ class _Group:
         self.lam = lam
         if not fused_status:
             K.group_status(self.rmax, self.info, tri_flag, self.status, orth=self.orth)
+        if self.pg is not None:
+            # sharded run: the status the host is about to read becomes the GLOBAL one right here, in stream order
+            # behind the kernel that wrote it (MAX over the ranks of {max|resid|, Cholesky flag, K3 flag, condition
+            # estimate, guard}: symeig.py:188-203 decide on the maximum over ALL batch members) — through the C ABI on
+            # this group's stream when the group is RCCL (dist.device_comm), else c10d.  Every decision below — stop,
+            # K3 fallback, orthonormalisation passes, guard roll-back — is then the same on every rank by construction.
+            torch.nan_to_num_(self.status, nan=float("inf"), posinf=float("inf"))
+            allreduce_max_(self.status, self.pg)
         end_ritz()
 
     def compress(self):
@@ -801,7 +811,8 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
     stop_reason = "max_niter"
     niter = 0
     distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
-    gstat = torch.zeros((5,), dtype=torch.float64, device=device) if distributed else None
+    for grp in groups:
+        grp.pg = process_group if distributed else None
     n_fallback = [0]
     cond_hist = [[] for _ in range(G)]            # squared pivot ratio of each group's panels (status[3]), as read
     guard_good, guard_bad = GUARD_GOOD[dtype], GUARD_BAD[dtype]
@@ -861,19 +872,9 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
                 deferred = []
             else:
                 deferred.append(g)
+        # (sharded runs: every group's status was all-reduced on the device before the host read it — `_Group.small` —
+        #  so the values folded above already are the global ones: no further exchange, no further host read)
         max_resid = local_max
-        if distributed:
-            with torch.cuda.stream(streams[G - 1]):
-                # every group's {max|resid|, flag} is complete (the host has read them): fold them on the
-                # device, one all-reduce (MAX) over the ranks, one read
-                torch.amax(torch.stack([grp.status for grp in groups]), dim=0, out=gstat)
-                allreduce_max_(gstat, process_group)
-                gl = gstat.tolist()
-                max_resid, bad, guard = gl[0], gl[1], gl[4]
-            if max_resid != max_resid:
-                max_resid = float("inf")
-            if guard != guard:
-                guard = float("inf")
         guard_hist.append(guard)
         if groups[0].nrestart != n_restart_seen:        # a thick restart rewrote the basis since the last step
             n_restart_seen, k_good = groups[0].nrestart, None
