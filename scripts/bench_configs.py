@@ -122,7 +122,7 @@ def c5w():
     return c5(p=16, kind="S1:16")
 
 
-def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000, basis_capacity=None):
+def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000, basis_capacity=None, groups="auto"):
     """configs[1] on the slowly converging closed-form spectra S2 / S3 with the opt-in thick restart:
     eigenvalues against the closed form, share of the call spent in the operator-panel product."""
     mat = torch.empty((B, N, N), dtype=torch.float64, device=dev)
@@ -137,7 +137,8 @@ def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000, basis_capacit
         with torch.no_grad(), warnings.catch_warnings():
             warnings.simplefilter("ignore")
             evals, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, rng_device="device",
-                              max_niter=max_niter, restart=restart, basis_capacity=basis_capacity, trace=tr)
+                              max_niter=max_niter, restart=restart, basis_capacity=basis_capacity, groups=groups,
+                              trace=tr)
         torch.cuda.synchronize(); t = time.perf_counter() - t0
         if first_ms is None:
             first_ms = t * 1e3
@@ -156,7 +157,11 @@ def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000, basis_capacit
 if __name__ == "__main__":
     for name in sys.argv[1:] or ["c3", "c4", "c5"]:
         try:
-            if name.startswith("c2cap"):                  # c2cap:S2:600 -> un-restarted, basis storage for 600 vectors up front
+            if name.startswith("c2grp"):                  # c2grp:S2:3 -> un-restarted with 3 batch groups
+                _, spec, ng = name.split(":")
+                r = c2_hard(spec, None, groups=int(ng))
+                r["groups"] = int(ng)
+            elif name.startswith("c2cap"):                  # c2cap:S2:600 -> un-restarted, basis storage for 600 vectors up front
                 _, spec, cap = name.split(":")
                 r = c2_hard(spec, None, basis_capacity=int(cap))
                 r["basis_capacity"] = int(cap)
