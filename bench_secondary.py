@@ -321,7 +321,7 @@ def _config_c5(args, dev, group, world, rank, fence, p, label):
                    "orth_redo": tr.get("orth_redo")},
         "roofline": _roofline(tri_bytes if symm else full_bytes, avg, nl,
                               {"K1s": "dense_symm_tiles<float,6> (K1s)",
-                               "K1sw": "dense_symm_wide_kernel (K1sw: triangle once, v_mfma_f32_16x16x4_f32 for both "
+                               "K1sw": "dense_symm_wide7_kernel (K1sw: triangle once, v_mfma_f32_16x16x4_f32 for both "
                                        "products); its fold runs beside it on the group's stream",
                                "K1w": "dense_wide_cols<float,1,Mfma16f> (K1w, v_mfma_f32_16x16x4_f32)"}.get(
                                    tr.get("panel_kernel"), str(tr.get("panel_kernel"))), extra),

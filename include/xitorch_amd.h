@@ -106,14 +106,17 @@ int xk_dense_symm_fold_f32(float* Y, const float* ws, long ws_elems, int B, int 
  * leave as partials in `ws` (one wave = one 512-row x 256-column tile, no atomics, no block barriers) and a fold adds the
  * slots that exist in fixed order: run-to-run bit-identical.  N must be a multiple of 64; the 64 x 64 diagonal blocks are
  * read whole.  ws: xk_dense_symm_wide_workspace_elems(B, N).  _tiles / _fold: the two launches separately (the
- * eigensolver's two-group pipeline), `ws` untouched in between. */
+ * eigensolver's two-group pipeline), `ws` untouched in between.  opts: 0 = one wave per tile (above); 1 = the
+ * workgroup-cooperative form (three waves per SIMD, four 128-column strips per workgroup sharing their row sums
+ * through LDS; + 2 = raised wave priority around its MFMA block; 3 is what the Python host passes: 3.58 ms against 3.97 ms
+ * for 8 x 32768^2, profiles/r04_k1sw_forms.jsonl).  _tiles and _fold of one product take the same opts. */
 long xk_dense_symm_wide_workspace_elems(int B, int N);
 int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
-                           long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream);
+                           long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream);
 int xk_dense_symm_wide_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
-                                 long lda, long sA, long ldx, long sX, void* stream);
+                                 long lda, long sA, long ldx, long sX, int opts, void* stream);
 int xk_dense_symm_wide_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
-                                void* stream);
+                                int opts, void* stream);
 
 /* ---- K1w: wide panels on the matrix cores (MFMA) --------------------------------------------
  * Y[b,c,n] = sum_i A[b,i,n] Xrm[b,i,c]  (= A^T X; = A X for a Hermitian operator), c < P <= 32, in ONE

@@ -79,9 +79,9 @@ def _declare(L):
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
     sigs["xk_dense_symm_wide_workspace_elems"] = (Lg, [I, I])
-    sigs["xk_dense_symm_wide_f32"] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, P])
-    sigs["xk_dense_symm_wide_tiles_f32"] = (I, [P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, P])
-    sigs["xk_dense_symm_wide_fold_f32"] = (I, [P, P, Lg, I, I, I, Lg, Lg, P])
+    sigs["xk_dense_symm_wide_f32"] = (I, [P, P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, Lg, Lg, I, P])
+    sigs["xk_dense_symm_wide_tiles_f32"] = (I, [P, P, P, Lg, I, I, I, Lg, Lg, Lg, Lg, I, P])
+    sigs["xk_dense_symm_wide_fold_f32"] = (I, [P, P, Lg, I, I, I, Lg, Lg, I, P])
     sigs["xk_dense_wide_workspace_elems"] = (Lg, [I, I, I, I, I])
     sigs["xk_dense_wide_padded_width"] = (I, [I, I])
     sigs["xk_dense_rows_wide_workspace_elems"] = (Lg, [I, I, I, I, I])

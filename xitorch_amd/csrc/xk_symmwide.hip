@@ -247,6 +247,196 @@ __global__ __launch_bounds__(256) void dense_symm_wide_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup-cooperative form (opts bit 0): THREE waves per SIMD.  A workgroup owns a super-tile = TR rows x 512 columns,
+// its four waves four interleaved combs of 128 columns (4 sub-tiles each, 128 columns apart: 32 column accumulators
+// instead of 64, one register buffer, <= 168 registers).  All four walk the same bands; at the end of a band each parks its 16 row accumulators in
+// its own (free) LDS tile, the workgroup meets at a barrier and wave w adds up row block w of the four — one row partial
+// per 512 columns instead of one per 256 (and per wave), one column partial per 128 columns and TR rows.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef XK_SW_PROBE
+#define XK_SW_PROBE 0      // scripts/k1sw_probe.py builds 1 (no MFMA: traffic + LDS turn only) and 2 (no matrix loads) to time the halves
+#endif
+constexpr int SW7_NSUB = 4;
+constexpr int SW7_WS = SW7_NSUB * 32;             // 128 columns per wave
+constexpr int SW7_SS = 4 * SW7_WS;                // 512 columns per workgroup
+
+__host__ __device__ inline int sw7_tiles_of_sstrip(int S, int N, int TR) {
+  long top = (long)(S + 1) * SW7_SS;
+  if (top > N) top = N;
+  return (int)((top + TR - 1) / TR);
+}
+
+template <int PRIO>
+__global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
+    const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ rowP, float* __restrict__ colP,
+    int N, int pc, long lda, long sA, long ldx, long sX, int NSS, int NT, int TR, int tiles_per_op) {
+  typedef float T;
+  constexpr int SEG = 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / tiles_per_op));
+  int ti = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - (unsigned)b * tiles_per_op));
+  int S = 0;
+  for (;;) {
+    const int cnt = sw7_tiles_of_sstrip(S, N, TR);
+    if (ti < cnt) break;
+    ti -= cnt;
+    ++S;
+  }
+  S = __builtin_amdgcn_readfirstlane(S);
+  const int I = __builtin_amdgcn_readfirstlane(ti);
+  // this wave's columns: sub-tile t = 32 columns at sbase + 128 t + 32 wave — at any moment the four waves of the
+  // workgroup (they walk in step) read 512 contiguous bytes of each matrix row
+  const int sbase = S * SW7_SS;
+  const int col0 = sbase + wave * 32;
+  constexpr int TSTEP = 4 * 32;
+  const int colb = sbase;
+  const int r_begin = I * TR;
+  int r_end = r_begin + TR;
+  r_end = r_end < N ? r_end : N;
+  r_end = r_end < (S + 1) * SW7_SS ? r_end : (S + 1) * SW7_SS; // the same band range for the four waves
+  char* tile = smem + wave * SW_TILE_LDS;
+  const float* Ab = A + (long)b * sA;
+  const float* Xb = X + (long)b * sX;
+  const int mm = lane & 15, kq = lane >> 4;
+  const int lrow = lane >> 3, lcol = lane & 7;
+  const bool cok = mm < pc;
+  const float* Xc = Xb + (long)(cok ? mm : 0) * ldx;
+  sw_f32x4 acc_col[SW7_NSUB][2];
+#pragma unroll
+  for (int t = 0; t < SW7_NSUB; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_col[t][h][r] = 0.f;
+  const unsigned ldab = (unsigned)(lda * (long)sizeof(T));
+  const unsigned lane_off = (unsigned)lrow * ldab + (unsigned)lcol * 16u;
+  const unsigned st_off = (unsigned)lrow * SW_PITCH + (unsigned)lcol * 16u;
+  constexpr unsigned POISON = 0x7ffffff0u;
+  auto band_rsrc = [&](int row0) {
+    return sw_rsrc(Ab + (long)row0 * lda + colb, ((long)(SW_ROWS - 1) * lda + (N - colb)) * (long)sizeof(T));
+  };
+  // sub-tile (row0, t) of this wave's strip: 8 loads + its x_J (8 values per lane); the same loads on every path
+  auto issue = [&](sw_f32x4 (&a)[8], sw_f32x2 (&xj)[4], const SwRsrc& ra, int row0, int t, bool exists) {
+    const int c0 = col0 + t * TSTEP;
+    const bool live = exists && (c0 + SEG > row0) && (c0 < N);
+    const int cj = live ? c0 : colb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const sw_f32x2 v = *reinterpret_cast<const sw_f32x2*>(Xc + cj + 8 * j + 2 * kq);
+      xj[j] = sw_f32x2{(live && cok) ? v[0] : 0.f, (live && cok) ? v[1] : 0.f};
+    }
+    const unsigned base = live ? lane_off + (unsigned)(c0 - colb) * (unsigned)sizeof(T) : POISON;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const unsigned voff = live ? base + (unsigned)(tt * 8) * ldab : POISON;
+#if XK_SW_PROBE == 2
+      a[tt] = sw_f32x4{(float)voff, (float)tt, (float)row0, (float)t};      // (probe: no matrix traffic)
+#else
+      a[tt] = __builtin_bit_cast(sw_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)voff, 0, 2));
+#endif
+    }
+  };
+  sw_f32x4 abuf[8];
+  sw_f32x2 xjr[2][4];
+  {
+    const SwRsrc r0 = band_rsrc(r_begin);
+    issue(abuf, xjr[0], r0, r_begin, 0, true);
+  }
+  for (int row0 = r_begin; row0 < r_end; row0 += SW_ROWS) {
+    const SwRsrc ra = band_rsrc(row0);
+    const bool more = row0 + SW_ROWS < r_end;
+    const int rown = more ? row0 + SW_ROWS : row0;
+    const SwRsrc rn = band_rsrc(rown);
+    float xi[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float v = Xc[row0 + 4 * kk + kq];
+      xi[kk] = cok ? v : 0.f;
+    }
+    sw_f32x4 acc_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_row[i][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < SW7_NSUB; ++t) {
+      sw_f32x2(&xj)[4] = xjr[t & 1];
+      const int c0 = col0 + t * TSTEP;
+      const bool both = (c0 >= row0 + SW_ROWS) && (c0 < N);
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        char* p = tile + st_off + (unsigned)(tt * 8) * SW_PITCH;
+        *reinterpret_cast<sw_f32x2*>(p) = sw_f32x2{abuf[tt][0], abuf[tt][1]};
+        *reinterpret_cast<sw_f32x2*>(p + 8) = sw_f32x2{abuf[tt][2], abuf[tt][3]};
+      }
+      if (t + 1 < SW7_NSUB) issue(abuf, xjr[(t + 1) & 1], ra, row0, t + 1, true);
+      else issue(abuf, xjr[(t + 1) & 1], rn, rown, 0, more);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+      const char* rrow = tile + (unsigned)mm * SW_PITCH + (unsigned)(2 * kq) * 4u;
+      const char* rcol = tile + (unsigned)kq * SW_PITCH + (unsigned)(2 * mm) * 4u;
+#if XK_SW_PROBE != 1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sw_f32x2 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = *reinterpret_cast<const sw_f32x2*>(rrow + (unsigned)(16 * i) * SW_PITCH + (unsigned)(8 * j) * 4u);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc_row[i] = sw_mma(v[i][h], xj[j][h], acc_row[i]);
+      }
+      if (both) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const sw_f32x2 w0 = *reinterpret_cast<const sw_f32x2*>(rcol + (unsigned)(4 * kk) * SW_PITCH);
+          acc_col[t][0] = sw_mma(w0[0], xi[kk], acc_col[t][0]);
+          acc_col[t][1] = sw_mma(w0[1], xi[kk], acc_col[t][1]);
+        }
+      }
+#endif
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- the four waves' row sums of this band through LDS: slot of wave w = its own tile, [row block i][lane] float4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<sw_f32x4*>(tile + (unsigned)(i * 64 + lane) * 16u) = acc_row[i];
+    __syncthreads();
+    {
+      sw_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const sw_f32x4 v = *reinterpret_cast<const sw_f32x4*>(smem + w * SW_TILE_LDS + (unsigned)(wave * 64 + lane) * 16u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] += v[r];
+      }
+      if (cok) {
+        float* rp = rowP + (((long)b * NSS + S) * 16 + mm) * (long)N + row0 + 16 * wave + 4 * kq;
+        __builtin_nontemporal_store(sum, reinterpret_cast<sw_f32x4*>(rp));
+      }
+    }
+    __syncthreads();                                           // the next LDS turn overwrites the slots
+  }
+  if (cok) {
+    float* cp = colP + (((long)b * NT + I) * 16 + mm) * (long)N + col0 + 8 * kq;
+#pragma unroll
+    for (int t = 0; t < SW7_NSUB; ++t) {
+      if (col0 + t * TSTEP < N) {
+        const sw_f32x4 lo = {acc_col[t][0][0], acc_col[t][1][0], acc_col[t][0][1], acc_col[t][1][1]};
+        const sw_f32x4 hi = {acc_col[t][0][2], acc_col[t][1][2], acc_col[t][0][3], acc_col[t][1][3]};
+        __builtin_nontemporal_store(lo, reinterpret_cast<sw_f32x4*>(cp + t * TSTEP));
+        __builtin_nontemporal_store(hi, reinterpret_cast<sw_f32x4*>(cp + t * TSTEP + 4));
+      }
+    }
+  }
+}
+
 // Y[b][c][n] = sum of the row partials of the strips that hold row n (strip n / WS and every strip right of it) and of
 // the column partials of the row tiles that hold column n (tiles 0 .. n / TR), each list in ascending order
 __global__ __launch_bounds__(256) void symm_wide_fold(const float* __restrict__ rowP, const float* __restrict__ colP,
@@ -285,8 +475,43 @@ __global__ __launch_bounds__(256) void symm_wide_fold(const float* __restrict__ 
 
 static int symm_wide_tr(int N) { return N >= 4096 ? 512 : 256; }
 
+static int symm_wide7_tr(int N) { return N >= 8192 ? 1024 : (N >= 2048 ? 512 : 256); }
+
 static int symm_wide(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P, long lda,
-                     long sA, long ldx, long sX, long ldy, long sY, int phase, hipStream_t st) {
+                     long sA, long ldx, long sX, long ldy, long sY, int opts, int phase, hipStream_t st) {
+  if (opts & 1) {
+    // workgroup-cooperative form
+    if (P < 1 || P > 16) return XK_ERR_ARG;
+    if ((N % SW_ROWS) || (lda % 4) || (sA % 4) || (ldx % 2) || (sX % 2) || ((uintptr_t)A & 15) || ((uintptr_t)X & 7) ||
+        ((uintptr_t)ws & 15))
+      return XK_ERR_UNSUPPORTED;
+    if ((long)SW_ROWS * lda * 4 > 0x7fffffe0L) return XK_ERR_UNSUPPORTED;
+    const int TR = symm_wide7_tr(N);
+    const int NSS = (N + SW7_SS - 1) / SW7_SS, NT = (N + TR - 1) / TR;
+    const long nrow = (long)B * NSS * 16 * N, ncol = (long)B * NT * 16 * N;
+    if (ws == nullptr || ws_elems < nrow + ncol) return XK_ERR_ARG;
+    float* rowP = ws;
+    float* colP = ws + nrow;
+    if (phase != 2) {
+      int tiles = 0;
+      for (int S = 0; S < NSS; ++S) tiles += sw7_tiles_of_sstrip(S, N, TR);
+      const size_t lds = 4 * (size_t)SW_TILE_LDS;
+      if (opts & 2)
+        hipLaunchKernelGGL(dense_symm_wide7_kernel<1>, dim3((unsigned)((long)B * tiles)), dim3(256), lds, st, A, X, rowP,
+                           colP, N, P, lda, sA, ldx, sX, NSS, NT, TR, tiles);
+      else
+        hipLaunchKernelGGL(dense_symm_wide7_kernel<0>, dim3((unsigned)((long)B * tiles)), dim3(256), lds, st, A, X, rowP,
+                           colP, N, P, lda, sA, ldx, sX, NSS, NT, TR, tiles);
+      XK_LAUNCH_CHECK();
+    }
+    if (phase != 1) {
+      const long total = (long)B * P * N;
+      hipLaunchKernelGGL(symm_wide_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rowP, colP, Y, N, P,
+                         NSS, NT, TR, SW7_SS, ldy, sY, total);
+      XK_LAUNCH_CHECK();
+    }
+    return XK_OK;
+  }
   constexpr int WS = SW_NSUB * (SW_SEG_BYTES / 4);
   if (P < 1 || P > 16) return XK_ERR_ARG;
   if ((N % SW_ROWS) || (lda % 4) || (sA % 4) || (ldx % 2) || (sX % 2) || ((uintptr_t)A & 15) || ((uintptr_t)X & 7) ||
@@ -330,27 +555,27 @@ long xk_dense_symm_wide_workspace_elems(int B, int N) {
 }
 
 int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
-                           long lda, long sA, long ldx, long sX, long ldy, long sY, void* stream) {
-  if (B < 0 || N < 0) return XK_ERR_ARG;
+                           long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream) {
+  if (B < 0 || N < 0 || opts < 0 || opts > 3) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
-  return xk::symm_wide(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, 0, (hipStream_t)stream);
+  return xk::symm_wide(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, opts, 0, (hipStream_t)stream);
 }
 
 // the two halves as separate launches (the eigensolver's two-group pipeline: tiles on the CU-masked panel stream, the
 // fold on the group's own stream); `ws` must stay untouched in between
 int xk_dense_symm_wide_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
-                                 long lda, long sA, long ldx, long sX, void* stream) {
-  if (B < 0 || N < 0) return XK_ERR_ARG;
+                                 long lda, long sA, long ldx, long sX, int opts, void* stream) {
+  if (B < 0 || N < 0 || opts < 0 || opts > 3) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
-  return xk::symm_wide(A, X, nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, 1, (hipStream_t)stream);
+  return xk::symm_wide(A, X, nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, opts, 1, (hipStream_t)stream);
 }
 
 int xk_dense_symm_wide_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
-                                void* stream) {
-  if (B < 0 || N < 0) return XK_ERR_ARG;
+                                int opts, void* stream) {
+  if (B < 0 || N < 0 || opts < 0 || opts > 3) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
-  return xk::symm_wide((const float*)ws, (const float*)ws, Y, (float*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, 2,
-                       (hipStream_t)stream);
+  return xk::symm_wide((const float*)ws, (const float*)ws, Y, (float*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, opts,
+                       2, (hipStream_t)stream);
 }
 
 }  // extern "C"

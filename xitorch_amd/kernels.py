@@ -634,6 +634,7 @@ def dense_symm(A, X, out=None, opts=None):
 # --------------------------------------------------------------------------- K1sw symmetric storage, wide panels (MFMA)
 SYMM_WIDE_MIN_P, SYMM_WIDE_MAX_P = 9, 16
 SYMM_WIDE_MIN_N = 1024        # below this the tiles are too few to fill the chip: K1w / K1s serve
+K1SW_OPTS = 3                 # bit 0: workgroup-cooperative form (3 waves per SIMD), bit 1: s_setprio around its MFMA block; 0: one wave per tile (include/xitorch_amd.h)
 
 
 def symm_wide_ok(A, X):
@@ -672,7 +673,7 @@ def dense_symm_wide(A, X, out=None):
     B, P, N, lda, sA, ldx, sX, ldy, sY, nws = _symm_wide_args(A, X, out)
     ws = _workspace(nws, X.dtype, X.device)
     rc = fn("xk_dense_symm_wide_f32")(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, ldy, sY,
-                                      stream_ptr())
+                                      K1SW_OPTS, stream_ptr())
     check(rc, "xk_dense_symm_wide")
     return out
 
@@ -693,13 +694,14 @@ def dense_symm_wide_split(A, X, out, tiles_stream, timed=False):
         if timed:
             e0, e1 = timing_event_pair()
             e0.record(tiles_stream)
-        rc = fn("xk_dense_symm_wide_tiles_f32")(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, stream_ptr())
+        rc = fn("xk_dense_symm_wide_tiles_f32")(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, K1SW_OPTS,
+                                                stream_ptr())
         check(rc, "xk_dense_symm_wide_tiles")
         if timed:
             e1.record(tiles_stream)
         done.record(tiles_stream)
     cur.wait_event(done)
-    rc = fn("xk_dense_symm_wide_fold_f32")(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, stream_ptr())
+    rc = fn("xk_dense_symm_wide_fold_f32")(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, K1SW_OPTS, stream_ptr())
     check(rc, "xk_dense_symm_wide_fold")
     return e0, e1
 
