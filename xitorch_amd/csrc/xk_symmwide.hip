@@ -278,6 +278,8 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / tiles_per_op));
   int ti = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - (unsigned)b * tiles_per_op));
+  // strip-major: consecutive workgroups walk down one 512-column super-strip (row-tile-major order — the workgroups in
+  // flight covering whole matrix rows — measured the same: profiles/r04_k1sw_coop_pmc_probe.json)
   int S = 0;
   for (;;) {
     const int cnt = sw7_tiles_of_sstrip(S, N, TR);
@@ -285,8 +287,9 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
     ti -= cnt;
     ++S;
   }
+  int I = ti;
   S = __builtin_amdgcn_readfirstlane(S);
-  const int I = __builtin_amdgcn_readfirstlane(ti);
+  I = __builtin_amdgcn_readfirstlane(I);
   // this wave's columns: sub-tile t = 32 columns at sbase + 128 t + 32 wave — at any moment the four waves of the
   // workgroup (they walk in step) read 512 contiguous bytes of each matrix row
   const int sbase = S * SW7_SS;
@@ -496,12 +499,9 @@ static int symm_wide(const float* A, const float* X, float* Y, float* ws, long w
       int tiles = 0;
       for (int S = 0; S < NSS; ++S) tiles += sw7_tiles_of_sstrip(S, N, TR);
       const size_t lds = 4 * (size_t)SW_TILE_LDS;
-      if (opts & 2)
-        hipLaunchKernelGGL(dense_symm_wide7_kernel<1>, dim3((unsigned)((long)B * tiles)), dim3(256), lds, st, A, X, rowP,
-                           colP, N, P, lda, sA, ldx, sX, NSS, NT, TR, tiles);
-      else
-        hipLaunchKernelGGL(dense_symm_wide7_kernel<0>, dim3((unsigned)((long)B * tiles)), dim3(256), lds, st, A, X, rowP,
-                           colP, N, P, lda, sA, ldx, sX, NSS, NT, TR, tiles);
+      auto kern = (opts & 2) ? dense_symm_wide7_kernel<1> : dense_symm_wide7_kernel<0>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * tiles)), dim3(256), lds, st, A, X, rowP, colP, N, P, lda, sA,
+                         ldx, sX, NSS, NT, TR, tiles);
       XK_LAUNCH_CHECK();
     }
     if (phase != 1) {
