@@ -318,13 +318,17 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  * lam (B, p) ascending, Y (B, p, k) eigenvectors, info[b] != 0 -> redo that call on the library solver.
  * xk_small_eigh_big_batch(k, p, elem_size): shifts factorised at a time (> 0) when the problem fits the 160 KiB of
  * LDS, 0 when it does not.  8 <= k <= 768, p <= 64 (also the solver for MORE THAN 16 wanted pairs at any order: wide
- * eigen-blocks, thick restarts; the batch of vectors in work lives in LDS, finished ones in the rows of Y). */
+ * eigen-blocks, thick restarts; the batch of vectors in work lives in LDS, finished ones in the rows of Y).
+ * algo: 1 = the form above; 2 = the TWO-STAGE form (xk_eigh_band.hip: dense -> band of 16 sub-diagonals by block
+ * reflectors, two launches per 16 columns; band -> tridiagonal by bulge chasing in LDS, one workgroup per matrix, sweeps
+ * pipelined three steps apart; eigenvectors back through both stages, one workgroup per vector), XK_ERR_UNSUPPORTED when
+ * the band of order k does not fit the LDS (fp64: k <= 605); 0 = the measured choice. */
 int xk_small_eigh_big_batch(int k, int p, int elem_size);
 long xk_small_eigh_big_workspace_elems(int B, int k, int wg);
 int xk_small_eigh_big_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* info, int B, int k,
-                          int p, int uppest, long ldt, long sT, int wg, int threads, void* stream);
+                          int p, int uppest, long ldt, long sT, int wg, int threads, int algo, void* stream);
 int xk_small_eigh_big_f32(const float* T, float* lam, float* Y, float* ws, long ws_elems, int* info, int B, int k,
-                          int p, int uppest, long ldt, long sT, int wg, int threads, void* stream);
+                          int p, int uppest, long ldt, long sT, int wg, int threads, int algo, void* stream);
 
 /* ---- Davidson chain: one C call per stage of an iteration (xitorch/_impls/linalg/symeig.py:160-223) -------------
  * The stages between two operator-panel products are two to eight small launches each; issued from C++ they cost a

@@ -1,0 +1,15 @@
+#!/bin/bash
+# r04x: two-stage K3g after a change: parity, per-kernel times at order 582
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r04x; mkdir -p $O
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_k1.py -q -m gpu -k "two_stage" -x > $O/tests.txt 2>&1; echo "tests rc=$?"
+tail -5 $O/tests.txt
+for cfg in "582 32" "330 1"; do
+  set -- $cfg
+  rm -rf $O/prof
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python scripts/k3g_two_stage_one.py $1 $2 2 > /dev/null 2>$O/prof.err
+  F=$(find $O/prof -name "*kernel_stats.csv" | head -1)
+  echo "== k=$1 B=$2"; [ -n "$F" ] && python scripts/summarize_rocprof.py $F $O/k3g2_k$1_b$2.csv 10 && cut -c1-150 $O/k3g2_k$1_b$2.csv
+done
+rm -rf $O/prof

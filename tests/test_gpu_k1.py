@@ -425,6 +425,50 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
                 assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
 
 
+@pytest.mark.parametrize("B,k,p,uppest,dtype", [(2, 35, 4, False, torch.float64), (3, 130, 6, False, torch.float64),
+                                                (2, 200, 6, True, torch.float64), (2, 333, 4, False, torch.float64),
+                                                (2, 512, 6, False, torch.float64), (1, 582, 6, False, torch.float64),
+                                                (2, 600, 12, True, torch.float64), (2, 256, 16, False, torch.float32),
+                                                (2, 401, 6, False, torch.float32), (1, 768, 6, True, torch.float32),
+                                                (2, 300, 40, True, torch.float64), (33, 257, 6, False, torch.float64)])
+def test_small_eigh_big_two_stage_vs_lapack(dev, B, k, p, uppest, dtype):
+    """K3g in its two-stage form (r04: dense -> band of 16 sub-diagonals by block reflectors, band -> tridiagonal by
+    bulge chasing in LDS, vectors back through both stages) against LAPACK, like the one-stage test: eigenvalues,
+    residual, orthonormality, bit-reproducible; orders that are no multiple of the panel / strip, the largest fp64 order
+    whose band fits the LDS, more matrices than one wave of workgroups."""
+    assert K.small_eigh_big_ok(k, p, dtype)
+    g = torch.Generator().manual_seed(k + p)
+    cap = k + 5
+    for kind in ("ritz", "random"):
+        if kind == "ritz":
+            Q, _ = torch.linalg.qr(torch.randn(B, k, k, dtype=torch.float64, generator=g))
+            d = torch.cat([torch.arange(1.0, 9.0, dtype=torch.float64),
+                           50.0 + 50.0 * torch.arange(k - 8, dtype=torch.float64) / (k - 8)])
+            Tm = Q @ torch.diag_embed(d.expand(B, k)) @ Q.transpose(-2, -1)
+        else:
+            R = torch.randn(B, k, k, dtype=torch.float64, generator=g)
+            Tm = R + R.transpose(-2, -1)
+        Tm = (Tm + Tm.transpose(-2, -1)) * 0.5
+        lam_ref = torch.linalg.eigvalsh(Tm)
+        buf = torch.full((B, cap, cap), float("nan"), dtype=dtype)
+        buf[:, :k, :k] = torch.tril(Tm).to(dtype) + torch.triu(torch.full((k, k), float("nan"), dtype=dtype), 1)
+        dbuf = buf.to(dev)
+        lam, Y, info = K.small_eigh_big(dbuf, k, p, uppest=uppest, algo=2)
+        lam2, Y2, _ = K.small_eigh_big(dbuf, k, p, uppest=uppest, algo=2)
+        assert torch.equal(lam, lam2) and torch.equal(Y, Y2), kind
+        assert int(info.max()) == 0, kind
+        lam, Y = lam.cpu().double(), Y.cpu().double()
+        sl = slice(k - p, k) if uppest else slice(0, p)
+        tol = 1e-12 if dtype == torch.float64 else 3e-5
+        scale = lam_ref.abs().max().item()
+        assert (lam - lam_ref[:, sl]).abs().max().item() < tol * scale * 10, kind
+        Yc = Y.transpose(-2, -1)
+        res = torch.matmul(Tm, Yc) - Yc * lam.unsqueeze(-2)
+        assert res.abs().max().item() < tol * scale * 100, kind
+        G = torch.matmul(Yc.transpose(-2, -1), Yc)
+        assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, kind
+
+
 @pytest.mark.parametrize("B,N,P", [(2, 1024, 16), (1, 2048, 9), (3, 1088, 12), (1, 4096, 16), (2, 2304, 13),
                                    (1, 8192, 16), (2, 1472, 16)])
 @pytest.mark.parametrize("form", [0, 1, 3])

@@ -75,7 +75,7 @@ def _declare(L):
     sigs["xk_small_eigh_big_batch"] = (I, [I, I, I])
     sigs["xk_small_eigh_big_workspace_elems"] = (Lg, [I, I, I])
     for sfx in ("f64", "f32"):
-        sigs["xk_small_eigh_big_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, Lg, Lg, I, I, P])
+        sigs["xk_small_eigh_big_" + sfx] = (I, [P, P, P, P, Lg, P, I, I, I, I, Lg, Lg, I, I, I, P])
     sigs["xk_kry_max_partials"] = (I, [])
     sigs["xk_dense_symm_workspace_elems"] = (Lg, [I, I, I, I])
     sigs["xk_dense_symm_wide_workspace_elems"] = (Lg, [I, I])

@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned big_hash(unsigned x) {
 template <typename T, int NT>
 __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     T* __restrict__ Sws, const T* __restrict__ aux, long aux_stride, T* __restrict__ lam_out, T* __restrict__ Y_out,
-    int* __restrict__ info_out, int n, int p, int pb, int uppest, int stop_after) {
+    int* __restrict__ info_out, int n, int p, int pb, int uppest, int stop_after, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* dd = reinterpret_cast<T*>(smem);                 // n  diagonal of the tridiagonal matrix
   T* ee = dd + n;                                     // n  sub-diagonal
@@ -112,11 +112,16 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   {
     // the tridiagonalisation was done by the step kernels (tridiag_step_kernel below): (d, e, tau) wait in the aux block,
     // the reflectors are parked in the rows of S (row j, columns > j + 1)
+    // (mode 1, the two-stage form of xk_eigh_band.hip: (d, e) are complete in the aux block and the vectors go back
+    // through both stages in a kernel of their own)
     const T* ab = aux + (long)b * aux_stride;
     for (int i = tid; i < n; i += nt) {
-      T d = ab[i], e = ab[n + i], tv = ab[2 * n + i];
-      if (i == n - 1) { d = S[(long)(n - 1) * n + (n - 1)]; e = T(0); tv = T(0); }
-      if (i == n - 2) { e = ab[3 * n + (long)((n - 2) & 1) * n + (n - 1)]; tv = T(0); }
+      T d = ab[i], e = ab[n + i], tv = mode == 1 ? T(0) : ab[2 * n + i];
+      if (mode != 1) {
+        if (i == n - 1) { d = S[(long)(n - 1) * n + (n - 1)]; e = T(0); tv = T(0); }
+        if (i == n - 2) { e = ab[3 * n + (long)((n - 2) & 1) * n + (n - 1)]; tv = T(0); }
+      }
+      if (i == n - 1) e = T(0);
       dd[i] = d; ee[i] = e; tau[i] = tv; e2[i] = e * e;
     }
     __syncthreads();
@@ -335,6 +340,10 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   __syncthreads();
 
   if (stop_after == 5) return;
+  if (mode == 1) {                                    // the vectors of (d, e) stay in the rows of Y_out
+    for (int j = tid; j < p; j += nt) lam_out[(long)b * p + j] = lamv[j];
+    return;
+  }
   // ---- 4. back-transformation y = H_0 ... H_{n-3} z, one wave per vector, next reflector prefetched -------
   for (int j = wave; j < p; j += nw) {
     const T* zj = Yg + (long)j * n;
@@ -647,6 +656,20 @@ extern "C" int xk_debug_small_eigh_big(int what, int value) {
 #endif
 
 namespace xk {
+// the two-stage form (xk_eigh_band.hip)
+long band_ws_elems(int k);
+bool band_supported(int k, int elem_size);
+template <typename T>
+int band_tridiag(const T* Tin, T* S, T* aux, long aux_stride, T* bws, int B, int k, long ldt, long sT, hipStream_t st);
+template <typename T>
+int band_back(T* Y, T* bws, int B, int k, int p, hipStream_t st);
+
+// which form serves order k (algo: 0 = the measured choice, 1 = one launch per Householder step, 2 = two-stage)
+static bool big_two_stage(int k, int elem_size, int algo) {
+  if (algo == 1 || !band_supported(k, elem_size)) return false;
+  return algo == 2 || k >= 256;
+}
+
 static int big_pick_w(int B, int k, int wg) {
   if (wg > 0) return wg;
   // measured (scripts/k3m_sweep.py, s2_k3_variants.py): alone on the chip 8 workgroups per matrix are fastest for 32
@@ -672,25 +695,36 @@ static void big_launch_step(const T* Tin, T* S, T* aux, long aux_stride, int B, 
 
 template <typename T, int NT>
 static int big_launch_final(T* ws, const T* aux, long aux_stride, T* lam, T* Y, int* info, int B, int k, int p, int pb,
-                            int uppest, long lds, hipStream_t st) {
+                            int uppest, long lds, int mode, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute((const void*)tridiag_eigh_big_kernel<T, NT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((tridiag_eigh_big_kernel<T, NT>), dim3(B), dim3(512), (size_t)lds, st, ws, aux, aux_stride, lam, Y,
-                     info, k, p, pb, uppest, XK_BIG_STOP);
+                     info, k, p, pb, uppest, XK_BIG_STOP, mode);
   return XK_OK;
 }
 
 template <typename T>
 static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k, int p, int uppest,
-                   long ldt, long sT, int wg, int nt, hipStream_t st) {
+                   long ldt, long sT, int wg, int nt, int algo, hipStream_t st) {
   const int pb = xk_small_eigh_big_batch(k, p, (int)sizeof(T));
   if (pb == 0) return XK_ERR_UNSUPPORTED;
+  if (algo == 2 && !band_supported(k, (int)sizeof(T))) return XK_ERR_UNSUPPORTED;
   const long lds = big_lds_elems(k, p, pb) * (long)sizeof(T) + 64;
   const int W = big_pick_w(B, k, wg);
   const long aux_stride = (long)k * (7 + 2 * W);
   if (ws == nullptr || ws_elems < (long)B * k * k + (long)B * aux_stride) return XK_ERR_ARG;
   T* aux = ws + (long)B * k * k;
+  if (big_two_stage(k, (int)sizeof(T), algo)) {
+    if (ws_elems < (long)B * k * k + (long)B * aux_stride + (long)B * band_ws_elems(k)) return XK_ERR_ARG;
+    T* bws = aux + (long)B * aux_stride;
+    int rc = band_tridiag<T>(Tin, ws, aux, aux_stride, bws, B, k, ldt, sT, st);
+    if (rc != XK_OK) return rc;
+    rc = big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 1, st);
+    if (rc != XK_OK) return rc;
+    XK_LAUNCH_CHECK();
+    return band_back<T>(Y, bws, B, k, p, st);
+  }
   for (int j = -1; j <= k - 3; ++j) {                     // (column slots of 64 that are still live: 2 / 4 / 8 / 12)
     const int m2 = k - (j + 2);
     if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
@@ -698,8 +732,8 @@ static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, 
     else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
     else big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
   }
-  const int rc = k <= 512 ? big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, st)
-                          : big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, st);
+  const int rc = k <= 512 ? big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st)
+                          : big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st);
   if (rc != XK_OK) return rc;
   XK_LAUNCH_CHECK();
   return XK_OK;
@@ -719,17 +753,21 @@ int xk_small_eigh_big_batch(int k, int p, int elem_size) {
 
 long xk_small_eigh_big_workspace_elems(int B, int k, int wg) {
   const int W = xk::big_pick_w(B, k, wg);
-  return (long)B * k * k + (long)B * k * (7 + 2 * W);
+  long e = (long)B * k * k + (long)B * k * (7 + 2 * W);
+  if (xk::band_supported(k, 4)) e += (long)B * xk::band_ws_elems(k);       // (the two-stage form's blocks)
+  return e;
 }
 
 #define XK_DEFINE_EIGH_BIG(SUF, T)                                                                            \
   int xk_small_eigh_big_##SUF(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k,      \
-                              int p, int uppest, long ldt, long sT, int wg, int threads, void* stream) {      \
+                              int p, int uppest, long ldt, long sT, int wg, int threads, int algo,            \
+                              void* stream) {                                                                 \
     if (B < 0 || k < 8 || k > 768 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                   \
     if (wg < 0 || wg > 32 || (threads != 0 && threads != 256 && threads != 512)) return XK_ERR_ARG;           \
+    if (algo < 0 || algo > 2) return XK_ERR_ARG;                                                              \
     if (B == 0) return XK_OK;                                                                                 \
     return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, wg,                      \
-                          threads ? threads : 512, (hipStream_t)stream);                                      \
+                          threads ? threads : 512, algo, (hipStream_t)stream);                                \
   }
 
 XK_DEFINE_EIGH_BIG(f64, double)

@@ -303,6 +303,7 @@ SMALL_EIGH_BIG_MAX_P = 64
 # the PYTHON layer, for measurement scripts; the C ABI itself has no state
 K3G_WG = 0
 K3G_THREADS = 0
+K3G_ALGO = 0          # 0: the library's choice; 1: one launch per Householder step; 2: two-stage (band + bulge chasing)
 
 
 def small_eigh_big_ok(k, p, dtype):
@@ -312,7 +313,7 @@ def small_eigh_big_ok(k, p, dtype):
     return fn("xk_small_eigh_big_batch")(k, p, 8 if dtype == torch.float64 else 4) > 0
 
 
-def small_eigh_big(T, k, p, uppest=False, wg=None, threads=None):
+def small_eigh_big(T, k, p, uppest=False, wg=None, threads=None, algo=None):
     """K3g: lowest / uppermost p eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower triangle read) for
     orders beyond the LDS-resident kernels (129 .. 768) or more than 16 wanted pairs (p <= 64, k >= 8): lam (B, p) ascending, Y (B, p, k), failure flags (B,) int32
     (nonzero -> redo with the library).  Replaces torch.linalg.eigh + _take_eigpairs (symeig.py:174-175) on the large
@@ -330,7 +331,7 @@ def small_eigh_big(T, k, p, uppest=False, wg=None, threads=None):
     ws = _workspace(nws, T.dtype, T.device)
     rc = fn("xk_small_eigh_big_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(ws), nws, ptr(info), B, k, p,
                                                      1 if uppest else 0, T.stride(1), T.stride(0), wg, threads,
-                                                     stream_ptr())
+                                                     K3G_ALGO if algo is None else int(algo), stream_ptr())
     check(rc, "xk_small_eigh_big")
     return lam, Y, info
 
