@@ -122,6 +122,11 @@ def c5w():
     return c5(p=16, kind="S1:16")
 
 
+if os.environ.get("XK_K3G_ALGO"):                 # A/B of K3g's two forms inside the pipeline: 1 = one-stage, 2 = two-stage
+    from xitorch_amd import kernels as _K
+    _K.K3G_ALGO = int(os.environ["XK_K3G_ALGO"])
+
+
 def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000, basis_capacity=None, groups="auto"):
     """configs[1] on the slowly converging closed-form spectra S2 / S3 with the opt-in thick restart:
     eigenvalues against the closed form, share of the call spent in the operator-panel product."""

@@ -383,7 +383,8 @@ def test_group_status_kernel(dev, dtype, B):
                                                 (1, 200, 64, False, torch.float64), (2, 24, 17, False, torch.float64),
                                                 (1, 90, 33, False, torch.float32)])
 def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
-    """K3g (orders 129 .. 768, matrix in global memory) against LAPACK: eigenvalues, residual, orthonormality, on
+    """K3g in its one-launch-per-Householder-step form (algo = 1; orders 129 .. 768, matrix in global memory) against
+    LAPACK: eigenvalues, residual, orthonormality, on
     matrices shaped like a Davidson T (a few separated eigenvalues below a dense band) and on random ones; the
     matrix is handed over inside a larger allocation (ldt > k), only its lower triangle holds the data."""
     assert K.small_eigh_big_ok(k, p, dtype)
@@ -408,8 +409,8 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
             for W, threads in ((0, 512), (3, 512), (8, 256), (16, 512)):
                 tag = (kind, W, threads)
                 dbuf = buf.to(dev)
-                lam, Y, info = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, threads=threads)
-                lam2, Y2, _ = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, threads=threads)
+                lam, Y, info = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, threads=threads, algo=1)
+                lam2, Y2, _ = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, threads=threads, algo=1)
                 assert torch.equal(lam, lam2) and torch.equal(Y, Y2), tag
                 assert int(info.max()) == 0, tag
                 lam, Y = lam.cpu().double(), Y.cpu().double()

@@ -438,7 +438,7 @@ constexpr int BAND_PAD = BAND_NB - 2;
 
 template <typename T>
 struct ChaseOffs {
-  int x, x0, xr[4], xr0[4], e[4], a[4], am[4], e2[4];
+  int x, x0, xr[4], xr0[4], e[4], a[4], am[4], e2[4], src[4];
   bool low[4], first[4];
 };
 
@@ -459,15 +459,16 @@ __device__ __forceinline__ ChaseOffs<T> band_chase_offsets(int lane) {
     o.a[r] = i16 * (LD - 1) + rw;                           // diagonal block (rw, i16), stored when rw >= i16 ...
     o.am[r] = rw * (LD - 1) + i16;                          // ... else its mirror image
     o.e2[r] = rw * (LD - 1) + NB + i16;                     // block below, transposed: row lo + NB + i16, column lo + rw
+    o.src[r] = 16 * g + rw;                                 // a lane of this row that holds column rw
     o.low[r] = rw >= i16;
     o.first[r] = rw == 0;
   }
   return o;
 }
 
-template <typename T>
+template <typename T, typename FLAG>
 __device__ __forceinline__ void band_chase_step(T* __restrict__ Bw, const ChaseOffs<T>& o, T* __restrict__ cv,
-                                                T* __restrict__ ct, bool t0, int lane) {
+                                                T* __restrict__ ct, bool t0, int lane, FLAG* flag, int half_done) {
   typedef BandMma<T> MM;
   typedef typename MM::acc_t acc_t;
   const int i16 = lane & 15;
@@ -493,24 +494,18 @@ __device__ __forceinline__ void band_chase_step(T* __restrict__ Bw, const ChaseO
   if (lane < BAND_NB) cv[lane] = v;
   if (lane == 0) *ct = tau;
   if (tau == T(0)) return;
-  acc_t w = {T(0), T(0), T(0), T(0)}, pc = w, pr = w, u = w;
+  acc_t w = {T(0), T(0), T(0), T(0)}, pc = w, u = w;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w = MM::mma(vr[r], e[r], w);                            // v^T (block to the left), this lane's column
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     pc = MM::mma(vr[r], a[r], pc);                          // (D v) of this lane's column, in every register
-    pr = MM::mma(a[r], vr[r], pr);                          // (D v) of the register rows (D symmetric)
     u = MM::mma(vr[r], e2[r], u);                           // (E v) of this lane's row of the block below
-    w = MM::mma(vr[r], e[r], w);                            // v^T (block to the left), this lane's column
   }
-  // ---- both sides on the diagonal block: p = tau D v, K = tau/2 p.v, q = p - K v, D -= v q^T + q v^T
-  const T K = T(0.5) * tau * tau * row16_sum(pc[0] * v);
-  const T qc = tau * pc[0] - K * v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const T qr = tau * pr[r] - K * vr[r];
-    const T nv = a[r] - (vr[r] * qc + qr * v);
-    if (o.low[r]) Bw[o.a[r]] = nv;
-  }
-  // ---- from the left on the block to the left (its first column becomes (beta, 0, ...) exactly)
+  // ---- from the left on the block to the left (its first column becomes (beta, 0, ...) exactly).  This is the only
+  // part of the step the sweep behind waits for: it is signalled as soon as these stores have landed
   if (t0) {
     if (lane < BAND_NB) Bw[o.x0] = lane == 0 ? beta : T(0);
   } else {
@@ -521,6 +516,22 @@ __device__ __forceinline__ void band_chase_step(T* __restrict__ Bw, const ChaseO
       if (i16 == 0) ne = o.first[r] ? beta : T(0);
       Bw[o.e[r]] = ne;
     }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) *flag = half_done;
+  // ---- both sides on the diagonal block: p = tau D v, K = tau/2 p.v, q = p - K v, D -= v q^T + q v^T
+  const T K = T(0.5) * tau * tau * row16_sum(pc[0] * v);
+  const T qc = tau * pc[0] - K * v;
+  // (D v) of the register rows: from the lanes that hold it by column (a fourth chain of the fp64 matrix instruction,
+  // 64 cycles each on this chip, costs more than four exchanges through the LDS crossbar)
+  T pr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pr[r] = __shfl(pc[0], o.src[r], 64);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const T qr = tau * pr[r] - K * vr[r];
+    const T nv = a[r] - (vr[r] * qc + qr * v);
+    if (o.low[r]) Bw[o.a[r]] = nv;
   }
   // ---- from the right on the block below: the next bulge
   const T tu = tau * u[0];
@@ -570,13 +581,15 @@ __global__ __launch_bounds__(1024) void band_chase_kernel(const T* __restrict__ 
     T* ct = Ctb + (long)s * TS;
     for (int t = 0; t < ns; ++t) {
       if (s > 0) {
-        const int need = t + 3 < nprev ? t + 3 : nprev;
+        // the sweep before must have finished step t + 1 and the left part of step t + 2 (counter in half steps), or all
+        // of its steps
+        const int need = t + 3 <= nprev ? 2 * (t + 2) + 1 : 2 * nprev;
         while (prog[s - 1] < need) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
       }
-      band_chase_step<T>(Bw, offs, cv, ct, t == 0, lane);
+      band_chase_step<T>(Bw, offs, cv, ct, t == 0, lane, prog + s, 2 * t + 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this step's LDS writes have landed
-      if (lane == 0) prog[s] = t + 1;
+      if (lane == 0) prog[s] = 2 * t + 2;
       Bw += NB * LD;
       cv += NB;
       ct += 1;

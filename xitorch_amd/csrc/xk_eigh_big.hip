@@ -667,7 +667,8 @@ int band_back(T* Y, T* bws, int B, int k, int p, hipStream_t st);
 // which form serves order k (algo: 0 = the measured choice, 1 = one launch per Householder step, 2 = two-stage)
 static bool big_two_stage(int k, int elem_size, int algo) {
   if (algo == 1 || !band_supported(k, elem_size)) return false;
-  return algo == 2 || k >= 256;
+  // measured (profiles/r04_k3g_two_stage.jsonl): ahead from order 192 on for 1 .. 32 matrices, fp64 and fp32
+  return algo == 2 || k >= 192;
 }
 
 static int big_pick_w(int B, int k, int wg) {

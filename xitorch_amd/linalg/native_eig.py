@@ -279,8 +279,9 @@ class _Group:
                 k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
             # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
             # wanted pairs at any order (wide eigen-blocks, thick restarts that keep 2 neig > 16 vectors): the same
-            # tridiagonalisation route with the matrix in global memory, one launch per Householder step over several
-            # workgroups per matrix (2.4x rocSOLVER at order 582, 32 matrices; xk_eigh_big.hip); a flagged result is
+            # tridiagonalisation route with the matrix in global memory: from order 192 on (fp64 to 605) the two-stage
+            # form (band by block reflectors, bulge chasing in LDS: xk_eigh_band.hip), else one launch per Householder
+            # step over several workgroups per matrix (xk_eigh_big.hip); a flagged result is
             # redone on the library (the driver's force_jacobi re-run lands in the branch below)
             end = self._mark("k3")
             lam, Yt, tri_flag = K.small_eigh_big(self.T, k, pk, uppest=(self.mode != "lowest"))
