@@ -1,5 +1,7 @@
 // xitorch_amd :: K3g — the p wanted eigenpairs of Rayleigh–Ritz matrices of order 129 .. 768, the MATRIX in global
 // memory, the tridiagonalisation spread over several workgroups per matrix with one launch per Householder step.
+// (From order 192 on the tridiagonalisation and the back-transformation come from the two-stage form of
+// xk_eigh_band.hip where its band fits the LDS; this file's final kernel serves both.)
 //
 // The un-restarted Davidson iteration of the reference (xitorch/_impls/linalg/symeig.py:132-135: the basis grows by
 // neig vectors per iteration until convergence, :174-175: torch.linalg.eigh of the full T every iteration) reaches
@@ -746,7 +748,9 @@ extern "C" {
 /* the LU batch size (shifts factorised at a time) the kernel would use for order k, p pairs, or 0 when it does not
  * fit the 160 KiB of LDS at all (elem_size 8 / 4) */
 int xk_small_eigh_big_batch(int k, int p, int elem_size) {
-  if (k < 8 || k > 768 || p < 1 || p > xk::BIG_MAXP || p > k) return 0;
+  // orders 769 .. 1024: only where the two-stage form serves (its band must fit the LDS: fp32)
+  if (k < 8 || p < 1 || p > xk::BIG_MAXP || p > k) return 0;
+  if (k > 768 && !(k <= 1024 && xk::band_supported(k, elem_size))) return 0;
   for (int pb = p; pb >= 1; --pb)
     if (xk::big_lds_elems(k, p, pb) * elem_size + 64 <= 160 * 1024) return pb;
   return 0;
@@ -763,9 +767,10 @@ long xk_small_eigh_big_workspace_elems(int B, int k, int wg) {
   int xk_small_eigh_big_##SUF(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k,      \
                               int p, int uppest, long ldt, long sT, int wg, int threads, int algo,            \
                               void* stream) {                                                                 \
-    if (B < 0 || k < 8 || k > 768 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                   \
+    if (B < 0 || k < 8 || k > 1024 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                  \
     if (wg < 0 || wg > 32 || (threads != 0 && threads != 256 && threads != 512)) return XK_ERR_ARG;           \
     if (algo < 0 || algo > 2) return XK_ERR_ARG;                                                              \
+    if (k > 768 && (algo == 1 || !xk::band_supported(k, (int)sizeof(T)))) return XK_ERR_UNSUPPORTED;          \
     if (B == 0) return XK_OK;                                                                                 \
     return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, wg,                      \
                           threads ? threads : 512, algo, (hipStream_t)stream);                                \

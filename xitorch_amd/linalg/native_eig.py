@@ -38,7 +38,7 @@ __all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend", "native_par
 _PRELAUNCH = True          # enqueue the next group's chain early (module attribute: measurement scripts flip it for A/B)
 # largest basis the global-memory Rayleigh-Ritz solver (K3g, tridiagonalisation spread over several workgroups per
 # matrix: xk_eigh_big.hip) serves before the library takes over (>= 16 matrices per group, fewer): its limit of 768
-K3G_MAX_K = [768, 768]
+K3G_MAX_K = [1024, 1024]      # (the library decides per dtype: 768 in fp64, 1024 in fp32 — small_eigh_big_ok)
 
 
 def take_eigpairs(evals, evecs, neig, mode):
@@ -292,7 +292,7 @@ class _Group:
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)
         else:
-            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 64 pairs, > 768
+            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 64 pairs, > 768 (fp32: > 1024)
             if due:
                 lk, Yk = take_eigpairs(lam_all, Y_all, pk, self.mode)
                 self._compress = (Yk.transpose(1, 2).contiguous(), lk.contiguous())
