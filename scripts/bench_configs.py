@@ -143,7 +143,8 @@ def c2_hard(spectrum, restart, B=64, N=16384, p=6, max_niter=3000, basis_capacit
             warnings.simplefilter("ignore")
             evals, X = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, rng_device="device",
                               max_niter=max_niter, restart=restart, basis_capacity=basis_capacity, groups=groups,
-                              trace=tr)
+                              trace=tr, **({"reserve_cus": int(os.environ["XK_RESERVE_CUS"])}
+                                           if os.environ.get("XK_RESERVE_CUS") else {}))
         torch.cuda.synchronize(); t = time.perf_counter() - t0
         if first_ms is None:
             first_ms = t * 1e3

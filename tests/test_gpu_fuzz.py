@@ -200,3 +200,46 @@ def test_krylov_random_cases_vs_dense(dev, seed):
                 Xs = getattr(nk, name)(Aop, Bm, E=E, **kw)
             err = ((Xs - Xref).norm() / Xref.norm()).item()
             assert err <= 1e-6, (seed, case, name, N, B, nc, sym, useE, err)
+
+
+def test_two_stage_rayleigh_ritz_solver_random_orders(dev):
+    """K3g's two-stage form (band reduction + bulge chasing, csrc/xk_eigh_band.hip) on 40 random (order, batch, pairs,
+    precision, end) draws — orders on both sides of every 16 / 64 boundary, up to the largest its band fits — against
+    torch.linalg.eigh on the CPU in fp64 (the call it replaces: symeig.py:174-175)."""
+    from xitorch_amd import kernels as K
+    g = torch.Generator().manual_seed(20240927)
+    done = 0
+    for case in range(40):
+        dtype = torch.float64 if case % 3 else torch.float32
+        kmax = 605 if dtype == torch.float64 else 900
+        k = int(torch.randint(35, kmax + 1, (1,), generator=g))
+        if case % 5 == 0:
+            k = (k // 16) * 16 + (case % 3)                  # right at / after a panel boundary
+        k = max(35, min(k, kmax))
+        B = int(torch.randint(1, 5, (1,), generator=g))
+        p = int(torch.randint(1, 13, (1,), generator=g))
+        uppest = bool(case % 2)
+        if not K.small_eigh_big_ok(k, p, dtype):
+            continue
+        R = torch.randn(B, k, k, dtype=torch.float64, generator=g)
+        Tm = (R + R.transpose(-2, -1)) * 0.5
+        if case % 4 == 0:                                    # a Ritz-like spectrum: a few separated values below a band
+            Q, _ = torch.linalg.qr(R)
+            d = torch.cat([torch.arange(1.0, 7.0, dtype=torch.float64), 40.0 + torch.rand(k - 6, dtype=torch.float64, generator=g)])
+            Tm = Q @ torch.diag_embed(d.expand(B, k)) @ Q.transpose(-2, -1)
+            Tm = (Tm + Tm.transpose(-2, -1)) * 0.5
+        lam_ref = torch.linalg.eigvalsh(Tm)
+        lam, Y, info = K.small_eigh_big(torch.tril(Tm).to(dtype).to(dev), k, p, uppest=uppest, algo=2)
+        tag = (case, str(dtype), k, B, p, uppest)
+        assert int(info.max()) == 0, tag
+        lam, Y = lam.cpu().double(), Y.cpu().double()
+        sl = slice(k - p, k) if uppest else slice(0, p)
+        tol = 1e-12 if dtype == torch.float64 else 3e-5
+        scale = lam_ref.abs().max().item()
+        assert (lam - lam_ref[:, sl]).abs().max().item() < tol * scale * 10, tag
+        Yc = Y.transpose(-2, -1)
+        assert (torch.matmul(Tm, Yc) - Yc * lam.unsqueeze(-2)).abs().max().item() < tol * scale * 100, tag
+        G = torch.matmul(Yc.transpose(-2, -1), Yc)
+        assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
+        done += 1
+    assert done >= 35
