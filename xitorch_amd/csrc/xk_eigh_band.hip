@@ -97,9 +97,9 @@ __global__ __launch_bounds__(256) void band_copy_kernel(const T* __restrict__ Ti
 // Vg[b][j][row][16] (absolute rows, explicit unit diagonal / zeros), Tg[b][j][16][16], Rg[b][j][16][16] (rows of R: the
 // band entries A[r0 + i][c0 + c], i <= c).
 // Everything here is latency of one workgroup (a lone wave issues an instruction every 5-8 cycles; a barrier costs a few
-// hundred): one pass and one barrier pair per column for the norm, v^T (columns to the right) and v^T v_a (columns to the
-// left, for T) together; the T factor from those dots after the loop, by one wave, beside the pass that turns the panel
-// into V.
+// hundred): one pass and one barrier pair per column — it applies reflector c and gathers, for column c + 1, the norm,
+// v^T (columns to the right) and v^T v_a (columns to the left, for T) together; the T factor from those dots after the
+// loop, by one wave, beside the pass that turns the panel into V.
 template <typename T>
 __global__ __launch_bounds__(1024) void band_qr_kernel(const T* __restrict__ Sws, T* __restrict__ Vg,
                                                        T* __restrict__ Tg, T* __restrict__ Rg, int n, int j, int np) {
@@ -129,19 +129,24 @@ __global__ __launch_bounds__(1024) void band_qr_kernel(const T* __restrict__ Sws
   __syncthreads();
 
   const int cc = tid % NB, rg = tid / NB;
-  for (int c = 0; c < nref; ++c) {
-    // dots of column c (rows below its diagonal) with all 16 columns, in one pass: the norm (cc == c), v^T column
-    // (cc > c) and v_a^T v_c of the T factor (cc < c)
+  // dots of column c (rows below its diagonal) with all 16 columns in one pass: the norm (cc == c), v^T column
+  // (cc > c) and v_a^T v_c of the T factor (cc < c).  For column 0 here; for column c + 1 in the same pass that applies
+  // reflector c (every thread repeats the update of column c + 1 for its rows: a read of Pl[i][c + 1] and the write
+  // of the thread that owns that column are the same two instructions of ONE wave — rows are dealt by tid / 16 — so the
+  // read comes first): two barriers per column, not three
+  if (nref > 0) {
     T p0 = T(0), p1 = T(0);
-    int i = c + 1 + rg;
+    int i = 1 + rg;
     for (; i + RG < m; i += 2 * RG) {
-      const T a0 = Pl[i * LP + c], b0 = Pl[i * LP + cc];
-      const T a1 = Pl[(i + RG) * LP + c], b1 = Pl[(i + RG) * LP + cc];
+      const T a0 = Pl[i * LP], b0 = Pl[i * LP + cc];
+      const T a1 = Pl[(i + RG) * LP], b1 = Pl[(i + RG) * LP + cc];
       p0 += a0 * b0;
       p1 += a1 * b1;
     }
-    if (i < m) p0 += Pl[i * LP + c] * Pl[i * LP + cc];
+    if (i < m) p0 += Pl[i * LP] * Pl[i * LP + cc];
     red[rg * NB + cc] = p0 + p1;
+  }
+  for (int c = 0; c < nref; ++c) {
     __syncthreads();
     if (wave == 0) {
       const int c2 = lane & (NB - 1), qt = lane >> 4;
@@ -165,20 +170,37 @@ __global__ __launch_bounds__(1024) void band_qr_kernel(const T* __restrict__ Sws
       }
     }
     __syncthreads();
-    if (cc > c) {
-      const T twc = tw[cc], sc = scal[c];
-      int i2 = c + rg;
-      if (i2 == c) { Pl[c * LP + cc] -= twc; i2 += RG; }      // v_c(c) = 1
-      for (; i2 + RG < m; i2 += 2 * RG) {
-        const T a0 = Pl[i2 * LP + c], a1 = Pl[(i2 + RG) * LP + c];
-        const T b0 = Pl[i2 * LP + cc], b1 = Pl[(i2 + RG) * LP + cc];
-        Pl[i2 * LP + cc] = b0 - a0 * sc * twc;
-        Pl[(i2 + RG) * LP + cc] = b1 - a1 * sc * twc;
+    {
+      const bool nextc = c + 1 < nref;
+      const int cn = c + 1 < NB ? c + 1 : NB - 1;
+      const bool mine = cc > c;
+      const T twc = mine ? tw[cc] : T(0);
+      const T twn = nextc ? tw[cn] : T(0);
+      const T sc = scal[c];
+      T p0 = T(0), p1 = T(0);
+      int i = c + rg;
+      for (; i + RG < m; i += 2 * RG) {
+        const T a0 = Pl[i * LP + c], a1 = Pl[(i + RG) * LP + c];
+        const T b0 = Pl[i * LP + cc], b1 = Pl[(i + RG) * LP + cc];
+        const T d0 = Pl[i * LP + cn], d1 = Pl[(i + RG) * LP + cn];
+        const T v0 = i == c ? T(1) : a0 * sc, v1 = a1 * sc;
+        const T nb0 = b0 - v0 * twc, nb1 = b1 - v1 * twc;     // (twc = 0 for the columns that stay)
+        const T nd0 = d0 - v0 * twn, nd1 = d1 - v1 * twn;
+        if (mine) { Pl[i * LP + cc] = nb0; Pl[(i + RG) * LP + cc] = nb1; }
+        if (i > c + 1) p0 += nd0 * nb0;
+        p1 += nd1 * nb1;                                      // i + RG > c + 1 always
       }
-      if (i2 < m) Pl[i2 * LP + cc] -= Pl[i2 * LP + c] * sc * twc;
+      if (i < m) {
+        const T a0 = Pl[i * LP + c], b0 = Pl[i * LP + cc], d0 = Pl[i * LP + cn];
+        const T v0 = i == c ? T(1) : a0 * sc;
+        const T nb0 = b0 - v0 * twc, nd0 = d0 - v0 * twn;
+        if (mine) Pl[i * LP + cc] = nb0;
+        if (i > c + 1) p0 += nd0 * nb0;
+      }
+      if (nextc) red[rg * NB + cc] = p0 + p1;
     }
-    __syncthreads();
   }
+  __syncthreads();
   // R out, V out: unit diagonal, zeros above, scaled below (columns without a reflector: zero); wave 0 meanwhile turns the
   // dots v_a^T v_c into T: column c = -tau_c T[0:c, 0:c] (V^T v_c), lane a keeps row a of T in registers
   T* Vb = Vg + ((long)b * np + j) * n * NB;
