@@ -618,10 +618,11 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         (extension) ``"native"`` (default): the wanted eigenpairs of the Rayleigh–Ritz matrix come from native
         kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
         iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
-        flags a result; from 129 to 768 vectors, or 17 to 64 wanted / kept pairs at any order, the same route with
-        the matrix in global memory (K3g, one launch per Householder step over several workgroups per matrix: 2.4x
-        the library at order 582, measured; fallback: the library);
-        ``torch.linalg.eigh`` beyond 768 vectors or 64 pairs; ``"jacobi"`` / ``"tri"`` force one of
+        flags a result; from 129 to 768 vectors (fp32: 1024), or 17 to 64 wanted / kept pairs at any order, the same
+        route with the matrix in global memory (K3g: from order 192 on — fp64 to 605 — a two-stage reduction, band by
+        block reflectors then bulge chasing in LDS; else one launch per Householder step over several workgroups per
+        matrix; 3.5x / 2.4x the library at order 582, measured; fallback: the library);
+        ``torch.linalg.eigh`` beyond 768 (fp32: 1024) vectors or 64 pairs; ``"jacobi"`` / ``"tri"`` force one of
         the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
