@@ -305,10 +305,29 @@ def _config_c5(args, dev, group, world, rank, fence, p, label):
         extra["priced_on"] = "the bytes the kernel must move: upper triangle + panels (the operator is exactly symmetric)"
     if tr.get("panel_kernel") == "K1sw":
         extra["note"] = ("K1sw streams half the bytes of K1w for the same flops (16 flop / B at P = 16 fp32, just under the "
-                         "ridge): it is bound by MFMA issue per wave (matrix pipe ~0.55 busy, profiles/r04_k1sw_variants.jsonl), "
-                         "not by HBM; `frac` stays priced on HBM as SURVEY 8d defines it, `frac_of_fp32_matrix_peak` is the "
-                         "other roofline; the full-matrix kernel K1w reaches 0.76 of HBM peak on twice the bytes and is "
-                         "20-25 % slower per call")
+                         "ridge): matrix pipe 0.54 busy at the clock the chip holds, the traffic half alone 5.9 TB/s, the MFMA "
+                         "half alone 75 % of the pipe (profiles/r04_k1sw_coop_pmc_probe.json); `frac` stays priced on HBM as "
+                         "SURVEY 8d defines it, `frac_of_fp32_matrix_peak` is the other roofline; the full-matrix kernel K1w "
+                         "reaches 0.76 of HBM peak on twice the bytes and is 25-30 % slower per call")
+        # HBM bytes from the PMC counters (separate rocprofv3 --pmc passes over scripts/k1sw_bench.py), only from a record
+        # measured on the kernel source in the tree
+        try:
+            import hashlib
+            import json as _json
+            root = os.path.dirname(os.path.abspath(__file__))
+            rec = _json.load(open(os.path.join(root, "profiles", "k1sw_pmc_traffic.json")))
+            h = hashlib.sha256()
+            for name in rec["kernel_source_files"]:
+                h.update(open(os.path.join(root, "xitorch_amd", "csrc", name), "rb").read())
+            if h.hexdigest() == rec["kernel_source_sha256"] and rec.get("B"):
+                extra["traffic"] = rec["hbm_bytes_per_launch"] * nbl / rec["B"]
+                extra["traffic_note"] = ("PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of a standalone launch of the same "
+                                         "kernel source over %d operators, scaled to this launch's (profiles/"
+                                         "k1sw_pmc_traffic.json)" % rec["B"])
+            else:
+                extra["traffic_note"] = "PMC record is stale (kernel source changed since it was measured): not reported"
+        except Exception:                                   # noqa: no record -> traffic stays null
+            pass
     return {
         "metric": "eigpairs/s of symeig(davidson) fp32 N=32768 (per-GPU shard of batch 128) + panel-product GB/s",
         "value": B * world * p * args.steps / elapsed, "unit": "eigpairs/s", "ms_per_step": elapsed / args.steps * 1e3,

@@ -3,7 +3,7 @@ WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md) -> a JSON record stamped wi
 Corrections as the guide's HBM section prescribes: FETCH_SIZE x2 on gfx950 for 16 B/lane streaming reads, KB -> bytes
 x1024, WRITE_SIZE as reported.
     python scripts/pmc_collect.py <kernel-name substring> <algorithmic bytes per launch> <source files, comma separated>
-                                  <out.json> FETCH=<csv> WRITE=<csv> [MFMA=<csv>] [note=...]"""
+                                  <out.json> FETCH=<csv> WRITE=<csv> [MFMA=<csv>] [B=<operators per launch>] [note=...]"""
 import csv, collections, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +28,8 @@ def per_kernel(path, pat):
 if __name__ == "__main__":
     pat, abytes, srcs, out = sys.argv[1], float(sys.argv[2]), sys.argv[3].split(","), sys.argv[4]
     kv = dict(a.split("=", 1) for a in sys.argv[5:])
-    rec = {"kernel": pat, "algorithmic_bytes_per_launch": abytes, "kernel_source_files": srcs,
+    rec = {"kernel": pat, "B": int(kv["B"]) if "B" in kv else None, "algorithmic_bytes_per_launch": abytes,
+           "kernel_source_files": srcs,
            "kernel_source_sha256": source_hash(srcs), "note": kv.get("note", "")}
     f = per_kernel(kv["FETCH"], pat)
     w = per_kernel(kv["WRITE"], pat)
