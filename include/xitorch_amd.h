@@ -322,7 +322,7 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  * algo: 1 = the form above; 2 = the TWO-STAGE form (xk_eigh_band.hip: dense -> band of 16 sub-diagonals by block
  * reflectors, two launches per 16 columns; band -> tridiagonal by bulge chasing in LDS, one workgroup per matrix, sweeps
  * pipelined three steps apart; eigenvectors back through both stages, one workgroup per vector), XK_ERR_UNSUPPORTED when
- * the band of order k does not fit the LDS (fp64: k <= 605); 0 = the measured choice. */
+ * the band of order k does not fit the LDS (fp64: k <= 614); 0 = the measured choice. */
 int xk_small_eigh_big_batch(int k, int p, int elem_size);
 long xk_small_eigh_big_workspace_elems(int B, int k, int wg);
 int xk_small_eigh_big_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* info, int B, int k,

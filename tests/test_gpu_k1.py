@@ -429,7 +429,7 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
 @pytest.mark.parametrize("B,k,p,uppest,dtype", [(2, 35, 4, False, torch.float64), (3, 130, 6, False, torch.float64),
                                                 (2, 200, 6, True, torch.float64), (2, 333, 4, False, torch.float64),
                                                 (2, 512, 6, False, torch.float64), (1, 582, 6, False, torch.float64),
-                                                (2, 600, 12, True, torch.float64), (2, 256, 16, False, torch.float32),
+                                                (2, 600, 12, True, torch.float64), (1, 614, 5, False, torch.float64), (2, 256, 16, False, torch.float32),
                                                 (2, 401, 6, False, torch.float32), (1, 768, 6, True, torch.float32),
                                                 (1, 1000, 8, False, torch.float32),
                                                 (2, 300, 40, True, torch.float64), (33, 257, 6, False, torch.float64)])

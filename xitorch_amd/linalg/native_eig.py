@@ -279,7 +279,7 @@ class _Group:
                 k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
             # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
             # wanted pairs at any order (wide eigen-blocks, thick restarts that keep 2 neig > 16 vectors): the same
-            # tridiagonalisation route with the matrix in global memory: from order 192 on (fp64 to 605) the two-stage
+            # tridiagonalisation route with the matrix in global memory: from order 192 on (fp64 to 614) the two-stage
             # form (band by block reflectors, bulge chasing in LDS: xk_eigh_band.hip), else one launch per Householder
             # step over several workgroups per matrix (xk_eigh_big.hip); a flagged result is
             # redone on the library (the driver's force_jacobi re-run lands in the branch below)
@@ -619,7 +619,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
         iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
         flags a result; from 129 to 768 vectors (fp32: 1024), or 17 to 64 wanted / kept pairs at any order, the same
-        route with the matrix in global memory (K3g: from order 192 on — fp64 to 605 — a two-stage reduction, band by
+        route with the matrix in global memory (K3g: from order 192 on — fp64 to 614 — a two-stage reduction, band by
         block reflectors then bulge chasing in LDS; else one launch per Householder step over several workgroups per
         matrix; 3.5x / 2.4x the library at order 582, measured; fallback: the library);
         ``torch.linalg.eigh`` beyond 768 (fp32: 1024) vectors or 64 pairs; ``"jacobi"`` / ``"tri"`` force one of
