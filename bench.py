@@ -63,6 +63,9 @@ def parse():
                     help="auto: upper-triangle kernel when the storage is exactly symmetric; general: full matrix")
     ap.add_argument("--k1s-run", type=int, default=0,
                     help="measurement: column slabs per workgroup run of the upper-triangle kernel (0 = library default)")
+    ap.add_argument("--k1s-opts", type=int, default=-1,
+                    help="measurement: low bits of the `opts` argument of the upper-triangle kernel (include/xitorch_amd.h), "
+                         "-1 = what the package ships")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run the launcher / process-group / timing / JSON plumbing of the N > 1 path on CPU "
                          "ranks over gloo with a tiny sharded stand-in step (no performance numbers)")
@@ -382,9 +385,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if args.k1s_run > 0:
+    if args.k1s_run > 0 or args.k1s_opts >= 0:
         from xitorch_amd import kernels as _XK
-        _XK.K1S_OPTS = int(args.k1s_run) << 8       # column slabs per workgroup run (an argument of the K1s entry points)
+        low = _XK.K1S_OPTS & 0xff if args.k1s_opts < 0 else args.k1s_opts & 0xff
+        _XK.K1S_OPTS = (int(args.k1s_run) << 8) | low   # column slabs per workgroup run | flag bits (arguments of K1s)
     group, backend, rccl_world = None, None, 1
     # XITORCH_BENCH_FORCE_PG=1: create the RCCL process group even for one rank (smoke test of the N > 1 plumbing —
     # init, barrier, all-reduce of the timing — on a single-GPU box; the solver's own all-reduces need >= 2 ranks)
