@@ -81,7 +81,9 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size);
  * order (phase rotation with barriers), partial slots are folded in a fixed order.
  * opts (measurements; 0 = the shipped behaviour; results do not depend on it): bit 0 plain instead of non-temporal
  * stores of the row / column partials, bit 1 plain instead of non-temporal loads in the fold, bits 8..15 column slabs
- * per workgroup run (0 = 1; row partials per row tile = ceil(slabs / run), at most 64). */
+ * per workgroup run (0 = 1; row partials per row tile = ceil(slabs / run), at most 64); bit 2: 512-row tiles (fp64),
+ * bit 3: 1024-row tiles — without either the library picks 512 rows for fp64 launches of fewer than 2200 workgroups
+ * (<= 16 operators of order 16384: +1 %). */
 int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, long ws_elems, int B,
                       int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream);
 int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,

@@ -112,8 +112,8 @@ def symm_run():
     layer's K1S_OPTS); restored afterwards"""
     prev = K.K1S_OPTS
 
-    def select(v):
-        K.K1S_OPTS = int(v) << 8
+    def select(v, tile=0):
+        K.K1S_OPTS = (int(v) << 8) | {0: 0, 512: 4, 1024: 8}[tile]     # bit 2 / 3: force 512- / 1024-row tiles
     yield select
     K.K1S_OPTS = prev
 
@@ -123,11 +123,12 @@ def symm_run():
                                          (2, 130, 3, torch.float64), (1, 3072, 7, torch.float64),
                                          (2, 2, 2, torch.float64), (2, 4096, 6, torch.float32),
                                          (1, 1100, 5, torch.float32), (1, 5000, 6, torch.float64)])
-@pytest.mark.parametrize("run", [1, 2, 3])
-def test_dense_symm_vs_oracle(dev, B, N, P, dtype, run, symm_run):
+@pytest.mark.parametrize("run,tile", [(1, 1024), (2, 1024), (3, 1024), (1, 512), (2, 512), (3, 0)])
+def test_dense_symm_vs_oracle(dev, B, N, P, dtype, run, tile, symm_run):
     # symmetric-storage K1s (upper triangle only) against the oracle's full dense product, for workgroup runs of 1, 2
-    # and 3 column slabs (the row accumulator lives across a run; ragged last runs included)
-    symm_run(run)
+    # and 3 column slabs (the row accumulator lives across a run; ragged last runs included) and for both tile heights
+    # (512 rows: the small-launch form of fp64, r04; 0 = the library's choice)
+    symm_run(run, tile)
     g = torch.Generator().manual_seed(N + P)
     R = torch.randn(B, N, N, dtype=dtype, generator=g)
     A = R + R.transpose(-2, -1)                                   # exactly symmetric

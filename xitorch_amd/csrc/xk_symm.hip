@@ -53,8 +53,9 @@
 
 namespace xk {
 
-constexpr int SYMM_TRH = 1024;   // rows per tile
-constexpr int SYMM_QR = 256;     // rows per quarter (phase granularity of the deterministic accumulation)
+constexpr int SYMM_TRH = 1024;   // rows per tile (template parameter TRH of the kernel: 1024, or 512 for small launches)
+// rows per quarter (phase granularity of the deterministic accumulation): TRH / 4
+constexpr long SYMM_SMALL_LAUNCH = 2200;   // workgroups (of 1024 rows) below which an fp64 launch uses 512-row tiles: +0.7 .. 1.3 % up to 16 operators of order 16384 per launch, -5 % at 32 (profiles/r04_k1s_tile_rows.jsonl)
 constexpr int SYMM_NU = 2;       // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
 constexpr int SYMM_R = 8;        // rows per chunk == ring depth
 
@@ -260,8 +261,9 @@ struct SymmRun {
 };
 
 // Rows [rb, re) wave `wave` handles in phase q of tile j of the run, and whether they reach the diagonal.
-template <typename T>
+template <typename T, int TRH>
 __device__ __forceinline__ bool symm_range(const SymmRun& run, int j, int q, int& rb, int& re, int& col0, int& diag) {
+  constexpr int SYMM_QR = TRH / 4;
   constexpr int VN = Vec16<T>::n;
   constexpr int WCOLS = SYMM_NU * 64 * VN, SLAB = 4 * WCOLS;
   col0 = (run.J0 + j) * SLAB;
@@ -278,7 +280,7 @@ __device__ __forceinline__ bool symm_range(const SymmRun& run, int j, int q, int
 }
 
 // first non-empty range after (j, q) in the wave's sequence; nx.row < 0 when there is none
-template <typename T>
+template <typename T, int TRH>
 __device__ __forceinline__ SymmNext symm_next_range(const SymmRun& run, int j, int q) {
   SymmNext nx;
   nx.row = -1; nx.last = 0; nx.col0 = 0; nx.diag = 0;
@@ -287,7 +289,7 @@ __device__ __forceinline__ SymmNext symm_next_range(const SymmRun& run, int j, i
     if (++q == 4) { q = 0; ++j; }
     if (j >= run.ntile) break;
     int rb, re, c0, dg;
-    if (symm_range<T>(run, j, q, rb, re, c0, dg)) {
+    if (symm_range<T, TRH>(run, j, q, rb, re, c0, dg)) {
       nx.row = rb; nx.last = re - 1; nx.col0 = c0; nx.diag = dg;
       break;
     }
@@ -351,7 +353,7 @@ __device__ __forceinline__ void symm_tile_setup(const T* __restrict__ Xb, int ld
   __builtin_amdgcn_s_waitcnt(0x0f70);
 }
 
-template <typename T, int P>
+template <typename T, int P, int TRH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
     const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int nruns,
     int N, long lda, long sA, long ldx, long sX, int NS, int NT, int NSL, int L, int flags) {
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   constexpr int NU = SYMM_NU;
   constexpr int WCOLS = NU * 64 * VN;          // columns per wave
   constexpr int SLAB = 4 * WCOLS;              // columns per tile
+  constexpr int SYMM_TRH = TRH, SYMM_QR = TRH / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
   // run list in row-tile-major order: row tile I owns the slabs J >= (I*TRH)/SLAB, cut into runs of L
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   // through the out-of-range offset) — issued BEFORE the LDS set-up so that the set-up runs under the loads
   VT a[SYMM_R][NU];
   {
-    SymmNext first = symm_next_range<T>(run, 0, -1);
+    SymmNext first = symm_next_range<T, TRH>(run, 0, -1);
     const int ncols = first.row >= 0 ? N : 0;          // no range at all: every lane fills through the OOR offset
     if (first.row < 0) { first.row = run.row0; first.last = run.row0; }
     unsigned floff[NU];
@@ -438,8 +441,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll 1
     for (; q < WCOLS / SYMM_QR; ++q) {
       int rb, re, c0, dg;
-      if (symm_range<T>(run, 0, q, rb, re, c0, dg)) {
-        SymmNext after = symm_next_range<T>(run, 0, q);
+      if (symm_range<T, TRH>(run, 0, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T, TRH>(run, 0, q);
         if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
         symm_rows<T, P, true>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
                               rowacc, lane);
@@ -453,8 +456,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll 1
     for (; q < 4; ++q) {
       int rb, re, c0, dg;
-      if (symm_range<T>(run, j, q, rb, re, c0, dg)) {
-        SymmNext after = symm_next_range<T>(run, j, q);
+      if (symm_range<T, TRH>(run, j, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T, TRH>(run, j, q);
         // no successor (end of the run for this wave): refill through the out-of-range offset (a tile starting at
         // column N: every lane is beyond the last column), so that every chunk issues the same loads
         if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 template <typename T>
 __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, const T* __restrict__ colP,
                                                   T* __restrict__ Y, int N, int P, int NS, int NT, int NSL, int L,
-                                                  int slab, long ldy, long sY, long total, int flags) {
+                                                  int slab, long ldy, long sY, long total, int flags, int trh) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*P*N
   if (idx >= total) return;
   const long per_b = (long)P * N;
@@ -511,11 +514,11 @@ __global__ __launch_bounds__(256) void symm_fold(const T* __restrict__ rowP, con
   const long rem = idx - b * per_b;
   const int c = (int)(rem / N);
   const int n = (int)(rem - (long)c * N);
-  const int It = n / SYMM_TRH;                 // row tile of n
-  const int jmin = (It * SYMM_TRH) / slab;     // first column slab that owns a tile with row tile It
+  const int It = n / trh;                      // row tile of n
+  const int jmin = (It * trh) / slab;          // first column slab that owns a tile with row tile It
   const int nslot = (NS - jmin + L - 1) / L;   // runs (= row partial slots) of that row tile
   T s = T(0);
-  const int Imax = ((n / slab) * slab + slab - 1) / SYMM_TRH;   // row tiles I with I*TRH <= last column of n's slab
+  const int Imax = ((n / slab) * slab + slab - 1) / trh;        // row tiles I with I*TRH <= last column of n's slab
   if (flags & 2) {                                              // the partials are read exactly once
     for (int r = 0; r < nslot; ++r) s += __builtin_nontemporal_load(&rowP[(((long)b * NSL + r) * P + c) * (long)N + n]);
     for (int I = 0; I <= Imax && I < NT; ++I)
@@ -535,7 +538,9 @@ extern "C" {
 //   bit 0: the row / column partials leave with PLAIN stores instead of non-temporal ones, bit 1: the fold reads them
 //          with plain loads (written once, read once, milliseconds apart: keeping them out of L2's way was worth 1.2 %
 //          of the eigensolver call in round 2);
-//   bits 8..15: L, column slabs per workgroup run (0 = 1; row partials per row tile = ceil(slabs / L)).
+//   bits 8..15: L, column slabs per workgroup run (0 = 1; row partials per row tile = ceil(slabs / L));
+//   bit 2 / bit 3: force 512- / 1024-row tiles (fp64; default: 512 rows for launches of fewer than SYMM_SMALL_LAUNCH
+//          workgroups).
 // Results do not depend on either (the run length changes the summation order of the row partials — still a fixed
 // order); both exist for measurements.
 
@@ -543,7 +548,7 @@ extern "C" {
 long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
   const int vn = 16 / elem_size;
   const long slab = 256L * vn * xk::SYMM_NU;
-  const long NS = (N + slab - 1) / slab, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;
+  const long NS = (N + slab - 1) / slab, NT = (N + 511) / 512;   // (column partials per 512-row tile: the small-launch form)
   const long pc = P > 6 ? 6 : P;
   return (long)B * (NS + NT) * pc * N;
 }
@@ -564,10 +569,22 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
     hipStream_t st = (hipStream_t)stream;                                                                   \
     const int L = ((opts >> 8) & 0xff) ? ((opts >> 8) & 0xff) : 1, fl = 3 & ~opts;                          \
     if (L > 64) return XK_ERR_ARG;                                                                          \
-    const int NS = (N + SLAB - 1) / SLAB, NT = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;                       \
+    const int NS = (N + SLAB - 1) / SLAB;                                                                   \
     const int NSL = (NS + L - 1) / L;                                                                       \
+    /* rows per tile: 1024; 512 (fp64) when the launch would be a few rounds of workgroups only — a 4-operator   \
+     * launch of the 8-operator shard is 544 workgroups of 1024 rows on 384 slots: 1.4 rounds, run as 2 */     \
+    int trh = xk::SYMM_TRH;                                                                                 \
+    {                                                                                                       \
+      const int nt1 = (N + xk::SYMM_TRH - 1) / xk::SYMM_TRH;                                                \
+      long nr1 = 0;                                                                                         \
+      for (int I = 0; I < nt1; ++I) nr1 += (NS - (I * xk::SYMM_TRH) / SLAB + L - 1) / L;                    \
+      if (sizeof(T) == 8 && (long)B * nr1 < xk::SYMM_SMALL_LAUNCH) trh = 512;                               \
+      if (sizeof(T) == 8 && (opts & 4)) trh = 512;                                                          \
+      if (opts & 8) trh = xk::SYMM_TRH;                                                                     \
+    }                                                                                                       \
+    const int NT = (N + trh - 1) / trh;                                                                     \
     int nruns = 0;                                                                                          \
-    for (int I = 0; I < NT; ++I) nruns += (NS - (I * xk::SYMM_TRH) / SLAB + L - 1) / L;                     \
+    for (int I = 0; I < NT; ++I) nruns += (NS - (I * trh) / SLAB + L - 1) / L;                              \
     int c0 = 0;                                                                                             \
     while (c0 < P) {                                                                                        \
       const int pc = (P - c0) >= 6 ? 6 : (P - c0);                                                          \
@@ -575,7 +592,7 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
       if (ws_elems < nrow + ncol) return XK_ERR_ARG;                                                        \
       T* rowP = ws;                                                                                         \
       T* colP = ws + nrow;                                                                                  \
-      const size_t lds = (size_t)xk::SYMM_TRH * pc * sizeof(T);                                             \
+      const size_t lds = (size_t)trh * pc * sizeof(T);                                                      \
       const dim3 grid((unsigned)((long)B * nruns));                                                         \
       const T* Xc = X + (long)c0 * ldx;                                                                     \
       if (phase != 2) {                                                                                     \
@@ -588,7 +605,7 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
         const long total = (long)B * pc * N;                                                                \
         hipLaunchKernelGGL((xk::symm_fold<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,     \
                            rowP, colP, Y + (long)c0 * ldy, N, pc, NS, NT, NSL, L, SLAB, ldy, sY, total,     \
-                           fl);                                                                             \
+                           fl, trh);                                                                        \
         XK_LAUNCH_CHECK();                                                                                  \
       }                                                                                                     \
       c0 += pc;                                                                                             \
@@ -613,8 +630,12 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
 
 #define XK_SYMM_CASE(PP)                                                                                  \
   case PP:                                                                                                \
-    hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP>), grid, dim3(256), lds, st, A, Xc, rowP, colP,       \
-                       nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl);                                   \
+    if (trh == 512)                                                                                       \
+      hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP, 512>), grid, dim3(256), lds, st, A, Xc, rowP, colP, \
+                         nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl);                                 \
+    else                                                                                                  \
+      hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP, 1024>), grid, dim3(256), lds, st, A, Xc, rowP, colP, \
+                         nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl);                                 \
     break;
 
 #define TT double
