@@ -766,9 +766,8 @@ int band_tridiag(const T* Tin, T* S, T* aux, long aux_stride, T* bws, int B, int
   const long total = (long)B * k * k;
   hipLaunchKernelGGL(band_copy_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Tin, S, k, ldt, sT,
                      total);
-  static bool attr_done[2] = {false, false};
-  constexpr int which = sizeof(T) == 8 ? 0 : 1;
-  if (!attr_done[which]) {
+  // (set on every call: cheap, per device, and the library keeps no state of its own)
+  {
     hipError_t e = hipFuncSetAttribute((const void*)band_qr_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
@@ -778,7 +777,6 @@ int band_tridiag(const T* Tin, T* S, T* aux, long aux_stride, T* bws, int B, int
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)band_back_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_done[which] = true;
   }
   for (int j = 0; j < P.np; ++j) {
     const int m = k - (j + 1) * BAND_NB;
