@@ -28,6 +28,7 @@ def t_of(f, n=10):
 
 tri = B * N * (N + 1) // 2 * 4 + 2 * B * N * P * 4
 full = B * N * N * 4 + 2 * B * N * P * 4
+K.K1SW_OPTS = 0
 t_sw = t_of(lambda: K.dense_symm_wide(A, X, out=Y))
 Ysw = Y.clone()
 K.K1SW_OPTS = 1
@@ -35,7 +36,6 @@ t_sw1 = t_of(lambda: K.dense_symm_wide(A, X, out=Y))
 Ysw1 = Y.clone()
 K.K1SW_OPTS = 3
 t_sw3 = t_of(lambda: K.dense_symm_wide(A, X, out=Y))
-K.K1SW_OPTS = 0
 t_w = t_of(lambda: K.dense_mm(A, X, out=Y, trans=True))
 err = ((Ysw - Y).abs().max() / Y.abs().max()).item()
 t_s = t_of(lambda: K.dense_symm(A, X, out=Y))
