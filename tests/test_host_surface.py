@@ -501,3 +501,24 @@ def test_davidson_orthonormalisation_pass_policy():
     assert _Group.current_passes(group(passes_now=1, opM=object()), 6) == 2
     assert _Group.current_passes(group(adaptive=False, orth_passes=1), 6) == 1
     assert _Group.current_passes(group(adaptive=False, orth_passes=3), 6) == 3
+
+
+def test_rayleigh_ritz_solver_limits_by_order_and_precision():
+    """Host-side queries of K3g (no device needed): which orders the one-launch-per-step form and the two-stage form of
+    r04 serve — fp64 to 768 (the two-stage form inside it to 614: its band + bulges must fit 160 KB of LDS), fp32 to
+    1024 through the two-stage form — and that the workspace query covers the two-stage blocks
+    (torch.linalg.eigh of the whole T in the reference: xitorch/_impls/linalg/symeig.py:174-175)."""
+    batch = _capi.fn("xk_small_eigh_big_batch")
+    ws = _capi.fn("xk_small_eigh_big_workspace_elems")
+    for k in (8, 129, 614, 615, 768):
+        assert batch(k, 6, 8) > 0, k
+    assert batch(769, 6, 8) == 0 and batch(1024, 6, 8) == 0          # fp64: the band of order > 614 does not fit the LDS
+    for k in (8, 600, 768, 769, 1024):
+        assert batch(k, 6, 4) > 0, k
+    assert batch(1025, 6, 4) == 0 and batch(7, 6, 4) == 0
+    assert batch(100, 65, 8) == 0 and batch(100, 64, 8) > 0           # at most 64 wanted pairs
+    # work copy + hand-over blocks of the one-stage form + the two-stage form's V / T / R / W / Z / reflector blocks
+    k, B = 582, 32
+    assert ws(B, k, 0) > B * k * k * 3
+    assert ws(B, 24, 0) >= B * 24 * 24                                # below order 35 there is no two-stage form
+    assert ws(2 * B, k, 0) == 2 * ws(B, k, 0) or ws(2 * B, k, 0) > ws(B, k, 0)
