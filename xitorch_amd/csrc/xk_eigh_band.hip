@@ -521,11 +521,9 @@ __device__ __forceinline__ void band_chase_step(T* __restrict__ Bw, const ChaseO
   for (int r = 0; r < 4; ++r) {
     w = MM::mma(vr[r], e[r], w);                            // v^T (block to the left), this lane's column
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    pc = MM::mma(vr[r], a[r], pc);                          // (D v) of this lane's column, in every register
-    u = MM::mma(vr[r], e2[r], u);                           // (E v) of this lane's row of the block below
-  }
+  // (the other two chains are ISSUED after the left block is stored and signalled: a wave issues its matrix instructions in
+  // order, 65 cycles apiece in fp64, and the sweep behind waits for that signal)
+  __builtin_amdgcn_sched_barrier(0);
   // ---- from the left on the block to the left (its first column becomes (beta, 0, ...) exactly).  This is the only
   // part of the step the sweep behind waits for: it is signalled as soon as these stores have landed
   if (t0) {
@@ -541,6 +539,12 @@ __device__ __forceinline__ void band_chase_step(T* __restrict__ Bw, const ChaseO
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) *flag = half_done;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    pc = MM::mma(vr[r], a[r], pc);                          // (D v) of this lane's column, in every register
+    u = MM::mma(vr[r], e2[r], u);                           // (E v) of this lane's row of the block below
+  }
   // ---- both sides on the diagonal block: p = tau D v, K = tau/2 p.v, q = p - K v, D -= v q^T + q v^T
   const T K = T(0.5) * tau * tau * row16_sum(pc[0] * v);
   const T qc = tau * pc[0] - K * v;
