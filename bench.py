@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--k1s-opts", type=int, default=-1,
                     help="measurement: low bits of the `opts` argument of the upper-triangle kernel (include/xitorch_amd.h), "
                          "-1 = what the package ships")
+    ap.add_argument("--k1-streams", default="auto", choices=["auto", "1", "2"],
+                    help="measurement: panel products of the two batch groups on one CU-masked stream (1) or one each (2); "
+                         "auto = one each when the resident K1s launch is on")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run the launcher / process-group / timing / JSON plumbing of the N > 1 path on CPU "
                          "ranks over gloo with a tiny sharded stand-in step (no performance numbers)")
@@ -227,10 +230,38 @@ def _k1s_source_hash(names=("xk_symm.hip", "xk_common.h")):
     return h.hexdigest()
 
 
+def _k1_periods(k1_events, p):
+    """Per-launch busy time of the panel-product launches of the timed region.
+
+    Every launch carries HIP events (e0 before, e1 after) on the stream it ran on.  With every launch on ONE stream the
+    launches are disjoint and a launch's time is e1 - e0.  With the resident launches of the two batch groups on two
+    streams, a launch is enqueued while the previous one still holds the machine and moves into the workgroup slots its
+    tail frees, so the [e0, e1] intervals overlap: what one launch costs the step is its COMPLETION PERIOD
+    e1_i - max(e0_i, e1_{i-1}) (launches ordered by completion), i.e. the union of the busy intervals split at the
+    completions.  Both forms sum to the time during which a panel product was running or waiting for slots held by
+    one; for disjoint launches the two definitions coincide."""
+    sel = [(e0, e1, nb) for (e0, e1, pc, nb) in k1_events if pc == p]
+    if not sel:
+        return [], [], None
+    base = sel[0][0]
+    iv = sorted(((base.elapsed_time(e0) * 1e-3, base.elapsed_time(e1) * 1e-3) for (e0, e1, nb) in sel),
+                key=lambda t: t[1])
+    raw = [e - s for s, e in iv]
+    periods, prev_end = [], None
+    for s0, e0_ in iv:
+        periods.append(e0_ - (s0 if prev_end is None or s0 > prev_end else prev_end))
+        prev_end = e0_
+    return periods, raw, sel[0][2]
+
+
+def _pct(vals, q):
+    v = sorted(vals)
+    return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))] if v else None
+
+
 def _k1_roofline(k1_events, N, p, esize, symm, b_local):
-    launches = [(e0.elapsed_time(e1) * 1e-3, nb) for (e0, e1, pc, nb) in k1_events if pc == p]
-    durs = [d for d, _ in launches]
-    nb_launch = launches[0][1] if launches else b_local
+    durs, raw, nb0 = _k1_periods(k1_events, p)
+    nb_launch = nb0 if nb0 is not None else b_local
     k1_avg = sum(durs) / max(len(durs), 1)
     need = _panel_bytes(nb_launch, N, p, esize, symm)
     full = _panel_bytes(nb_launch, N, p, esize, False)
@@ -262,6 +293,11 @@ def _k1_roofline(k1_events, N, p, esize, symm, b_local):
             traffic = None
     roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel, "launches_timed": len(durs), "avg_launch_ms": k1_avg * 1e3,
+            "launch_ms_p10_p50_p90": [round(_pct(durs, q) * 1e3, 3) for q in (0.1, 0.5, 0.9)] if durs else None,
+            "launch_ms_own_interval_avg": (sum(raw) / len(raw) * 1e3) if raw else None,
+            "launch_time_definition": "completion period e1_i - max(e0_i, e1_{i-1}) over the HIP events of the launches "
+                                      "(== e1 - e0 when the launches do not overlap); own_interval = plain e1 - e0, which "
+                                      "includes waiting for slots when two resident launches overlap",
             "algorithmic_bytes_per_launch": need, "batch_members_per_launch": nb_launch,
             "bytes_formula": ("B*N*(N+1)/2*s + 2*B*N*p*s (triangle incl. diagonal + panel in + panel out)" if symm
                               else "B*N^2*s + 2*B*N*p*s (SURVEY 8d)")}
@@ -476,6 +512,7 @@ def main():
                 evals, evecs = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=args.min_eps,
                                       v_init="randn", rng_device="device", max_niter=args.max_niter,
                                       overlap=(False if args.no_overlap else "auto"), reserve_cus=args.reserve_cus,
+                                      k1_streams=({"auto": "auto", "1": False, "2": True}[args.k1_streams]),
                                       process_group=group, trace=tr)
             if timed:
                 traces.append(tr)
@@ -631,6 +668,10 @@ def main():
             "check": {"ok": bool(ok), "max_eval_err_vs_exact": eval_err, "max_resid": resid},
             "step_ms": step_ms,
             "k1_ms_first_last": [round(durs[0] * 1e3, 3), round(durs[-1] * 1e3, 3)] if durs else None,
+            "k1_ms_last_step": [round(d * 1e3, 2) for d in durs[-2 * traces[-1]["niter"]:]] if durs else None,
+            "k1_ms_last_step_note": "completion periods of the last step's panel launches in completion order (the two "
+                                    "batch groups alternate; the basis grows by 6 vectors per pair, and with it the bytes "
+                                    "the other group's chain moves beside the launch)",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -167,6 +167,29 @@ def test_dense_symm_is_bit_reproducible(dev, B, N, P, dtype):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("B,N,P,dtype", [(3, 4096, 6, torch.float64), (2, 5000, 5, torch.float64), (2, 130, 3, torch.float64),
+                                         (2, 6144, 6, torch.float32), (1, 3072, 7, torch.float64), (2, 2, 2, torch.float64)])
+@pytest.mark.parametrize("slots", [0, 1, 3, 8])
+@pytest.mark.parametrize("run,tile", [(1, 1024), (2, 512), (3, 0)])
+def test_dense_symm_resident_launch_is_bit_identical(dev, B, N, P, dtype, slots, run, tile):
+    # the resident form of K1s (opts bit 4: `slots` workgroups — 0 = two per compute unit — take the runs from a queue)
+    # must give the bits of the one-workgroup-per-run launch whatever workgroup serves which run and however many
+    # runs one workgroup walks through (1 slot: all of them, in order; the queue word is reset by every launch)
+    g = torch.Generator().manual_seed(11 * N + P)
+    R = torch.randn(B, N, N, dtype=dtype, generator=g)
+    A = (R + R.transpose(-2, -1)).to(dev)
+    X = torch.randn(B, P, N, dtype=dtype, generator=g).to(dev)
+    low = (int(run) << 8) | {0: 0, 512: 4, 1024: 8}[tile]
+    Y0 = K.dense_symm(A, X, opts=low).clone()
+    ref = oops.DenseOp(A.cpu().double(), True)._mm(X.cpu().double().transpose(-2, -1)).transpose(-2, -1)
+    tol = 1e-13 if dtype == torch.float64 else 3e-6
+    assert (Y0.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < tol * N ** 0.5
+    for rep in range(3):
+        Y = K.dense_symm(A, X, opts=low | K.K1S_PERSIST | (slots << 16))
+        assert torch.equal(Y, Y0), "resident launch differs (repetition %d)" % rep
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("B,M,N,P,dtype", [(2, 512, 256, 32, torch.float32), (1, 300, 128, 17, torch.float32),
                                            (2, 256, 384, 12, torch.float32), (2, 512, 64, 16, torch.float64),
                                            (1, 130, 96, 32, torch.float64), (2, 77, 32, 25, torch.float64),

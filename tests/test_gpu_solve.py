@@ -288,3 +288,31 @@ def test_gmres_restarted_cycles_reach_a_tight_tolerance(dev):
     assert abs(r3 - tr3["best_resid"]) <= 1e-9 * max(1.0, r3)
     with pytest.raises(Exception):
         nk.gmres(A, rhs, restart=0)
+
+
+def test_gmres_default_max_niter_on_a_large_order(dev):
+    """(r05) The reference's default ``max_niter=None`` means the operator's order (solve.py:366-367); an
+    order beyond the 8192-vector cycle limit of the native least-squares kernel must not be refused up front — the run
+    below converges in a few dozen steps.  Also through the ``solve(..., method="gmres")`` front end; an explicit
+    restart length beyond the limit is refused."""
+    from xitorch_amd.linalg import solve
+    N, hb = 9000, 2
+    g = torch.Generator().manual_seed(3)
+    band = torch.zeros(1, 2 * hb + 1, N, dtype=torch.float64)
+    band[:, hb] = 4.0 + torch.rand(1, N, dtype=torch.float64, generator=g)
+    band[:, hb - 1] = -1.0
+    band[:, hb + 1] = -0.8
+    band[:, 0] = 0.1
+    A = xa.BandedLinearOperator(band.to(dev))
+    xs = torch.rand(1, N, 1, dtype=torch.float64, generator=g).to(dev)
+    with torch.no_grad():
+        rhs = A.mm(xs)
+    tr = {}
+    x = nk.gmres(A, rhs, rtol=1e-10, atol=1e-12, trace=tr)
+    assert tr["converged"] and tr["arnoldi_steps"] < 200
+    assert (x - xs).abs().max().item() < 1e-8
+    x2 = solve(A, rhs, method="gmres", rtol=1e-10, atol=1e-12)
+    assert (x2 - xs).abs().max().item() < 1e-8
+    from xitorch_amd._capi import NativeLibraryError
+    with pytest.raises(NativeLibraryError):
+        nk.gmres(A, rhs, restart=9000, max_niter=20000)

@@ -403,8 +403,8 @@ int main(int argc, char** argv) {
     out = subprocess.check_output([str(exe), _capi.LIB_PATH]).decode().split()
     assert int(out[0]) >= 1
     # (NS + NT) slots of P x N per batch member: 2048 / 1024 column slabs + 2048 / 512 row tiles (sized for the
-    # 512-row tiles small fp64 launches use)
-    assert int(out[1]) == 2 * (2 + 4) * 6 * 2048
+    # 512-row tiles small fp64 launches use), + 16 elements for the run queue of the resident launch (r05)
+    assert int(out[1]) == 2 * (2 + 4) * 6 * 2048 + 16
 
 
 def test_symmetric_storage_promise_follows_the_tensor():

@@ -58,6 +58,7 @@ constexpr int SYMM_TRH = 1024;   // rows per tile (template parameter TRH of the
 constexpr long SYMM_SMALL_LAUNCH = 2200;   // workgroups (of 1024 rows) below which an fp64 launch uses 512-row tiles: +0.7 .. 1.3 % up to 16 operators of order 16384 per launch, -5 % at 32 (profiles/r04_k1s_tile_rows.jsonl)
 constexpr int SYMM_NU = 2;       // 16 B vectors per lane per row: a wave spans NU x 64 x VN columns
 constexpr int SYMM_R = 8;        // rows per chunk == ring depth
+constexpr long SYMM_QUEUE_ELEMS = 16;   // workspace elements kept for the run queue of the resident launch (>= 64 B, at the end)
 
 // The operator rows of a run are read through ONE buffer descriptor (base = first row of the row tile,
 // wave-uniform): every load is  descriptor + per-lane column offset (one VGPR, loop-invariant) + scalar
@@ -353,10 +354,20 @@ __device__ __forceinline__ void symm_tile_setup(const T* __restrict__ Xb, int ld
   __builtin_amdgcn_s_waitcnt(0x0f70);
 }
 
-template <typename T, int P, int TRH>
+// PERSIST (round 5): the launch is `gridDim.x` resident workgroups (two per compute unit of the stream's CU mask) that
+// take runs from a queue in global memory (one atomic per run, fetched one run ahead so that its latency lies under
+// the current run) until it is empty, instead of one workgroup per run.  Which workgroup serves a run does not enter
+// the result: partial slots are indexed by the run, the order inside a run is fixed (bit-identical to the
+// one-workgroup-per-run launch).  What the resident form is for: a second launch on ANOTHER stream (the other batch
+// group's panel product) cannot place a workgroup before this launch's workgroups retire, i.e. before its queue is
+// empty — the older launch keeps the whole machine, the younger one fills the slots its tail frees.  Two
+// one-workgroup-per-run launches on two streams would share the slots evenly and finish together, which is the one
+// thing the two-group pipeline must not do.
+template <typename T, int P, int TRH, bool PERSIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
     const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int nruns,
-    int N, long lda, long sA, long ldx, long sX, int NS, int NT, int NSL, int L, int flags) {
+    int N, long lda, long sA, long ldx, long sX, int NS, int NT, int NSL, int L, int flags,
+    unsigned* __restrict__ queue, int nitems) {
   typedef typename Vec16<T>::type VT;
   constexpr int VN = Vec16<T>::n;
   constexpr int NU = SYMM_NU;
@@ -365,11 +376,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   constexpr int SYMM_TRH = TRH, SYMM_QR = TRH / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
+  __shared__ int s_next[2];            // two slots, written alternately: a slot is rewritten two runs after it was read
+  int item = blockIdx.x, par = 0;
+  if (PERSIST) {
+    if (threadIdx.x == 0) s_next[1] = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(s_next[1]);
+  }
+#pragma unroll 1
+  for (;;) {
+  if (PERSIST) {
+    if (item >= nitems) break;
+    if (threadIdx.x == 0) s_next[par] = (int)atomicAdd(queue, 1u);   // the run after this one: read at the end of the body
+  }
   // run list in row-tile-major order: row tile I owns the slabs J >= (I*TRH)/SLAB, cut into runs of L
-  int b = blockIdx.x / nruns;
+  int b = item / nruns;
   int I = 0, slot = 0, jmin = 0, cnt = 0;
   {
-    int rem = blockIdx.x - b * nruns;
+    int rem = item - b * nruns;
     for (;; ++I) {
       jmin = (I * SYMM_TRH) / SLAB;
       cnt = NS - jmin;
@@ -501,6 +525,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       else rp[(long)c * N + fb + lr] = v;
     }
   }
+  if (!PERSIST) break;
+  __syncthreads();                      // every wave has read its quarter of the row accumulator; s_next is visible
+  item = __builtin_amdgcn_readfirstlane(s_next[par]);
+  par ^= 1;
+  }
+}
+
+// compute units of the current device (cached per device): the resident launch's default is two workgroups per unit
+static int symm_device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
 }
 
 template <typename T>
@@ -550,14 +592,14 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
   const long slab = 256L * vn * xk::SYMM_NU;
   const long NS = (N + slab - 1) / slab, NT = (N + 511) / 512;   // (column partials per 512-row tile: the small-launch form)
   const long pc = P > 6 ? 6 : P;
-  return (long)B * (NS + NT) * pc * N;
+  return (long)B * (NS + NT) * pc * N + xk::SYMM_QUEUE_ELEMS;   // + the run queue of the resident form (last 64 bytes)
 }
 
 #define XK_DEFINE_SYMM(SUF, T)                                                                              \
   static int symm_launch_##SUF(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B, int N, int P,     \
                                long lda, long sA, long ldx, long sX, long ldy, long sY, int opts,           \
                                void* stream, int phase) {                                                   \
-    if (B < 0 || N < 0 || P < 0 || opts < 0 || opts > 0xffff) return XK_ERR_ARG;                            \
+    if (B < 0 || N < 0 || P < 0 || opts < 0 || opts > 0x0fffffff) return XK_ERR_ARG;                        \
     if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
     if (phase != 0 && P > 6) return XK_ERR_UNSUPPORTED;   /* split phases: one column chunk only */         \
     constexpr int VN = xk::Vec16<T>::n;                                                                     \
@@ -568,6 +610,12 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
     if ((long)xk::SYMM_TRH * lda * (long)sizeof(T) > 0x7fffffe0L) return XK_ERR_UNSUPPORTED;               \
     hipStream_t st = (hipStream_t)stream;                                                                   \
     const int L = ((opts >> 8) & 0xff) ? ((opts >> 8) & 0xff) : 1, fl = 3 & ~opts;                          \
+    const bool persist = (opts & 16) != 0;                                                                  \
+    int nslots = (opts >> 16) & 0xfff;                                                                      \
+    if (persist && nslots == 0) nslots = 2 * xk::symm_device_cus();                                         \
+    if (persist && (nslots <= 0 || ws_elems < xk::SYMM_QUEUE_ELEMS)) return XK_ERR_ARG;                     \
+    unsigned* queue = persist ? reinterpret_cast<unsigned*>(ws + (ws_elems - xk::SYMM_QUEUE_ELEMS)) : nullptr; \
+    if (persist) ws_elems -= xk::SYMM_QUEUE_ELEMS;                                                          \
     if (L > 64) return XK_ERR_ARG;                                                                          \
     const int NS = (N + SLAB - 1) / SLAB;                                                                   \
     const int NSL = (NS + L - 1) / L;                                                                       \
@@ -593,9 +641,16 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
       T* rowP = ws;                                                                                         \
       T* colP = ws + nrow;                                                                                  \
       const size_t lds = (size_t)trh * pc * sizeof(T);                                                      \
-      const dim3 grid((unsigned)((long)B * nruns));                                                         \
+      const long nitems_l = (long)B * nruns;                                                                \
+      if (nitems_l > 0x7fffffffL) return XK_ERR_UNSUPPORTED;                                                \
+      const int nitems = (int)nitems_l;                                                                     \
+      const dim3 grid((unsigned)(persist ? (nitems < nslots ? nitems : nslots) : nitems));                  \
       const T* Xc = X + (long)c0 * ldx;                                                                     \
       if (phase != 2) {                                                                                     \
+        if (persist) {                                                                                      \
+          hipError_t me = hipMemsetAsync(queue, 0, 64, st);                                                 \
+          if (me != hipSuccess) return (int)me;                                                             \
+        }                                                                                                   \
         switch (pc) {                                                                                       \
           XK_SYMM_CASE(1) XK_SYMM_CASE(2) XK_SYMM_CASE(3) XK_SYMM_CASE(4) XK_SYMM_CASE(5) XK_SYMM_CASE(6)   \
         }                                                                                                   \
@@ -628,14 +683,16 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
                              opts, stream, 2);                                                              \
   }
 
+#define XK_SYMM_LAUNCH(PP, RR, PERS)                                                                      \
+  hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP, RR, PERS>), grid, dim3(256), lds, st, A, Xc, rowP, colP, \
+                     nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl, queue, nitems)
 #define XK_SYMM_CASE(PP)                                                                                  \
   case PP:                                                                                                \
-    if (trh == 512)                                                                                       \
-      hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP, 512>), grid, dim3(256), lds, st, A, Xc, rowP, colP, \
-                         nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl);                                 \
-    else                                                                                                  \
-      hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP, 1024>), grid, dim3(256), lds, st, A, Xc, rowP, colP, \
-                         nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl);                                 \
+    if (trh == 512) {                                                                                     \
+      if (persist) XK_SYMM_LAUNCH(PP, 512, true); else XK_SYMM_LAUNCH(PP, 512, false);                    \
+    } else {                                                                                              \
+      if (persist) XK_SYMM_LAUNCH(PP, 1024, true); else XK_SYMM_LAUNCH(PP, 1024, false);                  \
+    }                                                                                                     \
     break;
 
 #define TT double

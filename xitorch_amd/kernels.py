@@ -588,7 +588,19 @@ def masked_stream(device, reserve_cus=64, slot=0):
             import atexit
             atexit.register(_destroy_masked_streams)
         _MASKED_STREAMS[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key[0]))
+        total = torch.cuda.get_device_properties(key[0]).multi_processor_count
+        _STREAM_CUS[(key[0], out.value)] = max(1, total - key[1])
     return _MASKED_STREAMS[key]
+
+
+_STREAM_CUS = {}             # (device index, stream handle) -> compute units the stream's mask leaves it
+
+
+def stream_cus(stream):
+    """compute units a stream may use: what its CU mask leaves (streams made by `masked_stream`), else all of them"""
+    dev = stream.device.index if stream.device.index is not None else torch.cuda.current_device()
+    n = _STREAM_CUS.get((dev, stream.cuda_stream))
+    return n if n is not None else torch.cuda.get_device_properties(dev).multi_processor_count
 
 
 def _destroy_masked_streams():
@@ -604,7 +616,17 @@ def _destroy_masked_streams():
 
 
 # --------------------------------------------------------------------------- K1s symmetric storage
-K1S_OPTS = 0          # `opts` of the K1s entry points handed to every call (measurement scripts; 0 = shipped behaviour)
+K1S_OPTS = 0          # low 16 bits of the `opts` of the K1s entry points handed to every call (include/xitorch_amd.h)
+K1S_PERSIST = 16      # opts bit 4: resident workgroups taking runs from a queue (two per compute unit of the stream)
+
+
+def _k1s_opts(stream, opts=None):
+    """`opts` of one K1s launch on `stream`: the module's flag bits, plus — for the resident form — the workgroup
+    count (bits 16..27) that fills the compute units `stream` may use, two workgroups each."""
+    o = K1S_OPTS if opts is None else int(opts)
+    if (o & K1S_PERSIST) and not (o >> 16):
+        o |= min(0xfff, 2 * stream_cus(stream)) << 16
+    return o
 
 
 def dense_symm(A, X, out=None, opts=None):
@@ -627,7 +649,8 @@ def dense_symm(A, X, out=None, opts=None):
     nws = fn("xk_dense_symm_workspace_elems")(B, N, P, esize)
     ws = _workspace(nws, X.dtype, X.device)
     rc = fn("xk_dense_symm_" + suffix(X.dtype))(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA,
-                                                 ldx, sX, ldy, sY, K1S_OPTS if opts is None else int(opts), stream_ptr())
+                                                 ldx, sX, ldy, sY, _k1s_opts(torch.cuda.current_stream(), opts),
+                                                 stream_ptr())
     check(rc, "xk_dense_symm")
     return out
 
@@ -771,14 +794,15 @@ def dense_symm_split(A, X, out, tiles_stream, timed=False):
         if timed:
             e0, e1 = timing_event_pair()
             e0.record(tiles_stream)
-        rc = fn("xk_dense_symm_tiles_" + sfx)(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, K1S_OPTS,
-                                              stream_ptr())
+        rc = fn("xk_dense_symm_tiles_" + sfx)(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX,
+                                              _k1s_opts(tiles_stream), stream_ptr())
         check(rc, "xk_dense_symm_tiles")
         if timed:
             e1.record(tiles_stream)
         done.record(tiles_stream)
     cur.wait_event(done)
-    rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, K1S_OPTS, stream_ptr())
+    rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, _k1s_opts(tiles_stream),
+                                         stream_ptr())
     check(rc, "xk_dense_symm_fold")
     return e0, e1
 

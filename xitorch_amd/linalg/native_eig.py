@@ -589,7 +589,7 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
 def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
               min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
               rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus="auto", restart=None,
-              groups="auto", chain="calls", basis_capacity=None, **unused):
+              groups="auto", chain="calls", basis_capacity=None, k1_streams="auto", **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -688,6 +688,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         uses the all-reduced (MAX) residual, so all ranks iterate in lock step (RCCL over xGMI)
     """
     na = A.shape[-1]
+    k1_streams_opt = k1_streams
     if nguess is None:
         nguess = neig
     bdims = list(A.shape[:-2]) if M is None else bcast_shape(A.shape[:-2], M.shape[:-2])
@@ -741,6 +742,20 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         try:
             grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
             k1_stream = K.masked_stream(device, reserve_cus)
+            # Resident K1s launches (kernels.K1S_PERSIST): every group's panel product gets its own CU-masked stream.
+            # A resident launch holds every workgroup slot of the masked units until its run queue is empty, so the
+            # next group's launch — already enqueued on its stream — moves into the slots the tail frees instead of
+            # waiting for the last workgroup (one stream: a kernel boundary per launch, the tail of a launch of 8.5
+            # workgroup rounds leaves slots idle).  One-workgroup-per-run launches on two streams would share the slots
+            # evenly and finish together: they stay on one stream.
+            k1_streams = [k1_stream] * ngrp
+            if k1_streams_opt == "auto":
+                split_k1 = bool(K.K1S_OPTS & K.K1S_PERSIST) and whole.kind == "dense" and whole.symm \
+                    and whole.symm_narrow and p <= 6
+            else:
+                split_k1 = bool(k1_streams_opt)
+            if split_k1:
+                k1_streams = [K.masked_stream(device, reserve_cus, slot=64 + g) for g in range(ngrp)]
         except NativeLibraryError as err:            # no CU-mask support: same kernels, one group, one stream
             import warnings
             warnings.warn("xitorch_amd davidson: CU-masked streams unavailable (%s); running one batch group" % err)
@@ -754,10 +769,10 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         # stream is not used for a group: it usually is the legacy null stream, which synchronises implicitly
         # with every blocking stream and serialises the pipeline (measured: 280 instead of 224 ms)
         streams = grp_streams
-        for st in streams + [k1_stream]:
+        for st in streams + list(set(k1_streams)):
             st.wait_stream(cur)
     else:
-        spans, ops, streams, k1_stream = [(0, B)], [whole], [torch.cuda.current_stream()], None
+        spans, ops, streams, k1_stream, k1_streams = [(0, B)], [whole], [torch.cuda.current_stream()], None, [None]
     for op in ops:
         op.events = events                       # bench.py: per-launch HIP events of the panel product
     G = len(spans)
@@ -799,7 +814,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
             opM = _PanelOperator(M, bdims, B, N) if M is not None else None
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
                          precond=_pc_slice(b0, b1), restart=restart, capacity=basis_capacity)
-            grp.k1_stream = k1_stream
+            grp.k1_stream = k1_streams[g]
             grp.adaptive = adaptive
             # (panels wider than 32 need the chunked orthonormalisation of xk_davidson_orth)
             grp.fast = (chain != "kernels") or p > 32 or nguess > 32
@@ -929,7 +944,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         raise RuntimeError("xitorch_amd davidson: no finite residual was produced")
     if two:
         cur = torch.cuda.current_stream()
-        for st in streams + [k1_stream]:
+        for st in streams + list(set(k1_streams)):
             cur.wait_stream(st)
         evals = torch.cat([grp.best_evals for grp in groups], dim=0)
         Xall = torch.cat([grp.Xbuf[grp.best_slot] for grp in groups], dim=0)

@@ -611,11 +611,16 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
             raise ValueError("gmres: restart must be a positive number of Arnoldi steps, got %d" % restart)
         msteps = max_niter - 1 if max_niter > 1 else 0      # (restarted: the total is not bounded by the order)
     mcyc = msteps if restart is None else min(restart, max(msteps, 1))     # Arnoldi steps per cycle
+    lazy_limit = None
     if mcyc > 8192:
-        # (xk_gmres_solve keeps the least-squares solution of a system in LDS: at most 8192 basis vectors; the dense
-        #  Hessenberg of an un-restarted run would be 8 S k^2 bytes long before that)
-        raise NativeLibraryError("xitorch_amd gmres: a Krylov basis of %d vectors per system is not supported (limit "
-                                 "8192); pass max_niter <= 8193 or restart=m" % mcyc)
+        # xk_gmres_solve keeps the least-squares solution of a system in LDS: at most 8192 basis vectors per cycle (the
+        # dense Hessenberg of such a run is 8 S k^2 bytes long before that).  An explicit restart length beyond it is
+        # refused here; the un-restarted default (max_niter = None -> the operator's order, solve.py:389) only fails if
+        # a run really gets that far — almost every run converges in a few dozen steps whatever the order
+        if restart is not None:
+            raise NativeLibraryError("xitorch_amd gmres: restart=%d exceeds the supported cycle length (8192 basis "
+                                     "vectors per system)" % restart)
+        lazy_limit, mcyc = 8192, 8192
     rhs = prob.rhs.reshape(S, ld)
     beta = rhs.norm(dim=-1)                                                      # (S,)
     best = float(allreduce_max_(beta.max().double().reshape(1), process_group).item())      # solve.py:380-381
@@ -655,8 +660,12 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
 
         cyc0 = 0                              # global index of the current cycle's first Arnoldi step
         for k in range(msteps):
-            nsteps = k + 1
             j = k - cyc0                                              # step index inside the cycle
+            if lazy_limit is not None and j >= lazy_limit:
+                raise NativeLibraryError("xitorch_amd gmres: the un-restarted Krylov basis reached %d vectors per system "
+                                         "without converging (best residual %.3e); pass restart=m (GMRES(m)) or a "
+                                         "max_niter <= %d" % (lazy_limit, best, lazy_limit + 1))
+            nsteps = k + 1
             if j + 2 > cap:                                           # grow the basis storage
                 newcap = min(mcyc + 1, 2 * cap)
                 Qn = torch.zeros((S, newcap, ld), dtype=dtype, device=dev)
