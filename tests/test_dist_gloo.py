@@ -208,6 +208,21 @@ def _worker_rows(rank, world, port, results):
         full = mat.clone().requires_grad_()
         gf, = torch.autograd.grad(((full @ x) ** 2).sum(), (full,))
         out["grad"] = (gl - gf[..., lo:hi, :]).abs().max().item()
+        # (r05) gradients w.r.t. the replicated INPUT: the dual collectives (all-reduce SUM for A x, all-gather
+        # for A^H x) must make them complete and identical on every rank — also through a chain of both products, and
+        # the row-block gradient must survive an x that itself depends on the block
+        xg = x.clone().requires_grad_()
+        xf = x.clone().requires_grad_()
+        w = torch.linspace(0.5, 1.5, N, dtype=torch.float64).reshape(N, 1)
+        gx_mm, = torch.autograd.grad((A.mm(xg) ** 2 * w).sum(), (xg,))
+        gx_mm_f, = torch.autograd.grad(((mat @ xf) ** 2 * w).sum(), (xf,))
+        gx_rmm, = torch.autograd.grad((A.rmm(xg) ** 2 * w).sum(), (xg,))
+        gx_rmm_f, = torch.autograd.grad(((mat.transpose(-2, -1) @ xf) ** 2 * w).sum(), (xf,))
+        gx_ch, gl_ch = torch.autograd.grad((Ag.rmm(torch.tanh(Ag.mm(xg))) * w).sum(), (xg, loc))
+        gx_ch_f, gf_ch = torch.autograd.grad(((full.transpose(-2, -1) @ torch.tanh(full @ xf)) * w).sum(), (xf, full))
+        out["grad_x"] = max((gx_mm - gx_mm_f).abs().max().item(), (gx_rmm - gx_rmm_f).abs().max().item(),
+                            (gx_ch - gx_ch_f).abs().max().item(), (gl_ch - gf_ch[..., lo:hi, :]).abs().max().item())
+        out["grad_x_bits"] = gx_ch.sum().item()
         # one symmetric operator (B = 1 < G), eigensolver replicated on every rank, operator stream split by rows
         S = synthetic.dense_symmetric(1, 96, "S1")
         As = xa.RowShardedMatrixLinearOperator.from_full(S, grp, is_hermitian=True)
@@ -239,6 +254,8 @@ def test_row_block_sharded_operator_gloo(world):
         assert r["rows"][2] == (2, r["rows"][1] - r["rows"][0], 101)
         for key in ("mm", "rmm", "mv", "full", "grad"):
             assert r[key] < 1e-12, (key, r[key])
+        assert r["grad_x"] < 1e-10, r["grad_x"]
+        assert r["grad_x_bits"] == results[0]["grad_x_bits"]  # replicated parameters cannot drift apart
         err, it_s, it_f, resid = r["eig"]
         assert err < 1e-11 and abs(it_s - it_f) <= 1 and resid < 1e-7, r["eig"]
         assert r["evals"] == results[0]["evals"]             # every rank holds the same replicated answer

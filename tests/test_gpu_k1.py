@@ -170,7 +170,7 @@ def test_dense_symm_is_bit_reproducible(dev, B, N, P, dtype):
 @pytest.mark.parametrize("B,N,P,dtype", [(3, 4096, 6, torch.float64), (2, 5000, 5, torch.float64), (2, 130, 3, torch.float64),
                                          (2, 6144, 6, torch.float32), (1, 3072, 7, torch.float64), (2, 2, 2, torch.float64)])
 @pytest.mark.parametrize("slots", [0, 1, 3, 8])
-@pytest.mark.parametrize("run,tile", [(1, 1024), (2, 512), (3, 0)])
+@pytest.mark.parametrize("run,tile", [(1, 1024), (2, 512), (3, 0), (1, 2048), (2, 2048), (8, 2048)])
 def test_dense_symm_resident_launch_is_bit_identical(dev, B, N, P, dtype, slots, run, tile):
     # the resident form of K1s (opts bit 4: `slots` workgroups — 0 = two per compute unit — take the runs from a queue)
     # must give the bits of the one-workgroup-per-run launch whatever workgroup serves which run and however many
@@ -179,7 +179,8 @@ def test_dense_symm_resident_launch_is_bit_identical(dev, B, N, P, dtype, slots,
     R = torch.randn(B, N, N, dtype=dtype, generator=g)
     A = (R + R.transpose(-2, -1)).to(dev)
     X = torch.randn(B, P, N, dtype=dtype, generator=g).to(dev)
-    low = (int(run) << 8) | {0: 0, 512: 4, 1024: 8}[tile]
+    # (tile 2048: the 8-wave form of fp64 — opts bit 5: 2048 x 2048 tiles, one workgroup per compute unit)
+    low = (int(run) << 8) | {0: 0, 512: 4, 1024: 8, 2048: 32}[tile]
     Y0 = K.dense_symm(A, X, opts=low).clone()
     ref = oops.DenseOp(A.cpu().double(), True)._mm(X.cpu().double().transpose(-2, -1)).transpose(-2, -1)
     tol = 1e-13 if dtype == torch.float64 else 3e-6

@@ -16,6 +16,7 @@
 #include "xk_common.h"
 #include <dlfcn.h>
 #include <string.h>
+#include <mutex>
 
 namespace xk {
 
@@ -36,13 +37,9 @@ struct Rccl {
   fn_comm_destroy comm_destroy = nullptr;
   fn_comm_count comm_count = nullptr, comm_user_rank = nullptr;
   fn_all_reduce all_reduce = nullptr;
-  bool tried = false;
 };
 
-static Rccl& rccl() {
-  static Rccl r;                                               // (C++11: initialised once, thread-safe)
-  if (r.tried) return r;
-  r.tried = true;
+static void rccl_load(Rccl& r) {
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (int pass = 0; pass < 2 && !r.lib; ++pass)               // pass 0: only a copy that is already mapped
     for (const char* n : names) {
@@ -50,7 +47,7 @@ static Rccl& rccl() {
       if (r.lib) break;
     }
   if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!r.lib) return r;
+  if (!r.lib) return;
   r.get_unique_id = (fn_get_unique_id)dlsym(r.lib, "ncclGetUniqueId");
   r.comm_init_rank = (fn_comm_init_rank)dlsym(r.lib, "ncclCommInitRank");
   r.comm_init_all = (fn_comm_init_all)dlsym(r.lib, "ncclCommInitAll");
@@ -59,6 +56,12 @@ static Rccl& rccl() {
   r.comm_user_rank = (fn_comm_count)dlsym(r.lib, "ncclCommUserRank");
   r.all_reduce = (fn_all_reduce)dlsym(r.lib, "ncclAllReduce");
   if (!r.get_unique_id || !r.comm_init_rank || !r.comm_init_all || !r.comm_destroy || !r.all_reduce) r.lib = nullptr;
+}
+
+static Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;                                  // the look-up runs once; concurrent first callers wait for it
+  std::call_once(once, rccl_load, std::ref(r));
   return r;
 }
 
@@ -95,12 +98,17 @@ int xk_comm_init_rank(const void* id128, int nranks, int rank, int device, void*
   xk::Rccl& r = xk::rccl();
   if (!r.lib) return XK_ERR_UNSUPPORTED;
   if (!id128 || !comm || nranks < 1 || rank < 0 || rank >= nranks || device < 0) return XK_ERR_ARG;
-  hipError_t e = hipSetDevice(device);
+  int prev = -1;
+  hipError_t e = hipGetDevice(&prev);
+  if (e != hipSuccess) return (int)e;
+  e = hipSetDevice(device);
   if (e != hipSuccess) return (int)e;
   xk::XkNcclId id;
   memcpy(id.internal, id128, 128);
   *comm = nullptr;
-  return xk::rc_of(r.comm_init_rank(comm, nranks, id, rank));
+  const int rc = xk::rc_of(r.comm_init_rank(comm, nranks, id, rank));
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);   // the caller's current device is not ours to change
+  return rc;
 }
 
 int xk_comm_init_all(int ndev, const int* devs, void** comms) {

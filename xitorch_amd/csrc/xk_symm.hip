@@ -262,11 +262,11 @@ struct SymmRun {
 };
 
 // Rows [rb, re) wave `wave` handles in phase q of tile j of the run, and whether they reach the diagonal.
-template <typename T, int TRH>
+template <typename T, int TRH, int NW>
 __device__ __forceinline__ bool symm_range(const SymmRun& run, int j, int q, int& rb, int& re, int& col0, int& diag) {
-  constexpr int SYMM_QR = TRH / 4;
+  constexpr int SYMM_QR = TRH / NW;
   constexpr int VN = Vec16<T>::n;
-  constexpr int WCOLS = SYMM_NU * 64 * VN, SLAB = 4 * WCOLS;
+  constexpr int WCOLS = SYMM_NU * 64 * VN, SLAB = NW * WCOLS;
   col0 = (run.J0 + j) * SLAB;
   const int wc0 = col0 + run.wave * WCOLS, wc1 = wc0 + WCOLS;
   // rows that can hold an element on/above the diagonal for this wave: row <= its last column
@@ -281,16 +281,16 @@ __device__ __forceinline__ bool symm_range(const SymmRun& run, int j, int q, int
 }
 
 // first non-empty range after (j, q) in the wave's sequence; nx.row < 0 when there is none
-template <typename T, int TRH>
+template <typename T, int TRH, int NW>
 __device__ __forceinline__ SymmNext symm_next_range(const SymmRun& run, int j, int q) {
   SymmNext nx;
   nx.row = -1; nx.last = 0; nx.col0 = 0; nx.diag = 0;
 #pragma unroll 1
-  for (int s = 0; s < 8; ++s) {
-    if (++q == 4) { q = 0; ++j; }
+  for (int s = 0; s < 2 * NW; ++s) {
+    if (++q == NW) { q = 0; ++j; }
     if (j >= run.ntile) break;
     int rb, re, c0, dg;
-    if (symm_range<T, TRH>(run, j, q, rb, re, c0, dg)) {
+    if (symm_range<T, TRH, NW>(run, j, q, rb, re, c0, dg)) {
       nx.row = rb; nx.last = re - 1; nx.col0 = c0; nx.diag = dg;
       break;
     }
@@ -363,8 +363,14 @@ __device__ __forceinline__ void symm_tile_setup(const T* __restrict__ Xb, int ld
 // empty — the older launch keeps the whole machine, the younger one fills the slots its tail frees.  Two
 // one-workgroup-per-run launches on two streams would share the slots evenly and finish together, which is the one
 // thing the two-group pipeline must not do.
-template <typename T, int P, int TRH, bool PERSIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
+//
+// NW (round 5): waves per workgroup = row ranges ("quarters" in the comments: NW of them) per tile = phases per tile.
+// 4 waves: 1024 (fp64) / 2048 (fp32) columns per workgroup, two workgroups per compute unit.  8 waves (fp64, TRH = 2048):
+// ONE workgroup per compute unit owns 2048 x 2048 tiles — per tile the same two partials (row sums, column sums: TRH + SLAB
+// values per panel column) for four times the elements, i.e. half the partial bytes written here and read by the fold;
+// the row accumulator is 96 KB of LDS.
+template <typename T, int P, int TRH, bool PERSIST, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void dense_symm_tiles(
     const T* __restrict__ A, const T* __restrict__ X, T* __restrict__ rowP, T* __restrict__ colP, int nruns,
     int N, long lda, long sA, long ldx, long sX, int NS, int NT, int NSL, int L, int flags,
     unsigned* __restrict__ queue, int nitems) {
@@ -372,8 +378,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   constexpr int VN = Vec16<T>::n;
   constexpr int NU = SYMM_NU;
   constexpr int WCOLS = NU * 64 * VN;          // columns per wave
-  constexpr int SLAB = 4 * WCOLS;              // columns per tile
-  constexpr int SYMM_TRH = TRH, SYMM_QR = TRH / 4;
+  constexpr int SLAB = NW * WCOLS;             // columns per tile
+  constexpr int SYMM_TRH = TRH, SYMM_QR = TRH / NW;
+  static_assert(NW == 4 || WCOLS == TRH / NW, "more than four waves: a wave's columns span exactly one row range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* rowacc = reinterpret_cast<T*>(smem);                   // SYMM_TRH x P
   __shared__ int s_next[2];            // two slots, written alternately: a slot is rewritten two runs after it was read
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   run.N = N;
   // phase -> quarter map q ^ sig: sig = wave when a wave's columns span one quarter of rows (fp64); with two quarters
   // per wave (fp32) waves 1 and 2 swap, so that both quarters of a wave's diagonal block come in phases 0 and 1
-  run.sig = (WCOLS == SYMM_QR) ? run.wave : ((run.wave & 1) << 1 | (run.wave >> 1));
+  run.sig = (WCOLS == SYMM_QR) ? run.wave : ((run.wave & 1) << 1 | (run.wave >> 1));   // (the second form: NW == 4 only)
   const int wave = run.wave;
   int lanecol[NU];
 #pragma unroll
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   // through the out-of-range offset) — issued BEFORE the LDS set-up so that the set-up runs under the loads
   VT a[SYMM_R][NU];
   {
-    SymmNext first = symm_next_range<T, TRH>(run, 0, -1);
+    SymmNext first = symm_next_range<T, TRH, NW>(run, 0, -1);
     const int ncols = first.row >= 0 ? N : 0;          // no range at all: every lane fills through the OOR offset
     if (first.row < 0) { first.row = run.row0; first.last = run.row0; }
     unsigned floff[NU];
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       for (int u = 0; u < NU; ++u) a[r][u] = ld_tile<VT>(tile, lanecol[u] >= thr ? floff[u] : SYMM_OOR, soff);
     }
   }
-  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += 256) rowacc[idx] = T(0);
+  for (int idx = threadIdx.x; idx < SYMM_TRH * P; idx += NW * 64) rowacc[idx] = T(0);
   __syncthreads();
 
   VT acc_col[NU][P], xJ[NU][P];
@@ -465,8 +472,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll 1
     for (; q < WCOLS / SYMM_QR; ++q) {
       int rb, re, c0, dg;
-      if (symm_range<T, TRH>(run, 0, q, rb, re, c0, dg)) {
-        SymmNext after = symm_next_range<T, TRH>(run, 0, q);
+      if (symm_range<T, TRH, NW>(run, 0, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T, TRH, NW>(run, 0, q);
         if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
         symm_rows<T, P, true>(a, tile, Xb, ldab, ldx, rb, re, run.row0, col0, N, jj, after, acc_col, xJ,
                               rowacc, lane);
@@ -478,10 +485,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll 1
   for (;;) {
 #pragma unroll 1
-    for (; q < 4; ++q) {
+    for (; q < NW; ++q) {
       int rb, re, c0, dg;
-      if (symm_range<T, TRH>(run, j, q, rb, re, c0, dg)) {
-        SymmNext after = symm_next_range<T, TRH>(run, j, q);
+      if (symm_range<T, TRH, NW>(run, j, q, rb, re, c0, dg)) {
+        SymmNext after = symm_next_range<T, TRH, NW>(run, j, q);
         // no successor (end of the run for this wave): refill through the out-of-range offset (a tile starting at
         // column N: every lane is beyond the last column), so that every chunk issues the same loads
         if (after.row < 0) { after.row = run.row0; after.last = run.row0; after.col0 = N; }
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     // the run's row sums of quarter 3 ^ sig are complete: the other three waves added theirs in the earlier
     // phases (barriers), this wave just added the last ones (LDS operations of one wave execute in order).
     // Row partial slot `slot` of this row tile.
-    const int k3 = 3 ^ run.sig;
+    const int k3 = (NW - 1) ^ run.sig;
     const int fb = run.row0 + k3 * SYMM_QR;
     int fe = fb + SYMM_QR;
     fe = fe < run.tile_end ? fe : run.tile_end;
@@ -529,6 +536,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   __syncthreads();                      // every wave has read its quarter of the row accumulator; s_next is visible
   item = __builtin_amdgcn_readfirstlane(s_next[par]);
   par ^= 1;
+  }
+}
+
+// the 8-wave form (fp64 only) keeps TRH x P row sums in LDS: 96 KB at P = 6, beyond the 64 KB a kernel gets without asking
+template <typename T, int PP, bool PERS>
+static int symm_launch_wide8(dim3 grid, size_t lds, hipStream_t st, const T* A, const T* Xc, T* rowP, T* colP,
+                             int nruns, int N, long lda, long sA, long ldx, long sX, int NS, int NT, int NSL, int L,
+                             int fl, unsigned* queue, int nitems) {
+  if constexpr (sizeof(T) == 8) {
+    auto kfn = dense_symm_tiles<T, PP, 2048, PERS, 8>;
+    if (lds > 65536) {
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (ae != hipSuccess) return (int)ae;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, A, Xc, rowP, colP, nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L,
+                       fl, queue, nitems);
+    return XK_OK;
+  } else {
+    return XK_ERR_UNSUPPORTED;
   }
 }
 
@@ -603,16 +630,20 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
     if (B == 0 || N == 0 || P == 0) return XK_OK;                                                           \
     if (phase != 0 && P > 6) return XK_ERR_UNSUPPORTED;   /* split phases: one column chunk only */         \
     constexpr int VN = xk::Vec16<T>::n;                                                                     \
-    constexpr int SLAB = 256 * VN * xk::SYMM_NU;                                                            \
+    /* opts bit 5 (fp64): 8-wave workgroups on 2048 x 2048 tiles, one per compute unit */                   \
+    const bool wide8 = sizeof(T) == 8 && (opts & 32) != 0;                                                  \
+    const int NWV = wide8 ? 8 : 4;                                                                          \
+    const int SLAB = NWV * 64 * VN * xk::SYMM_NU;                                                           \
     if ((N % VN) || (lda % VN) || (sA % VN) || (ldx % VN) || (sX % VN) || ((uintptr_t)A & 15) ||             \
         ((uintptr_t)X & 15) || ((uintptr_t)ws & 15))                                                        \
       return XK_ERR_UNSUPPORTED;                                                                            \
-    if ((long)xk::SYMM_TRH * lda * (long)sizeof(T) > 0x7fffffe0L) return XK_ERR_UNSUPPORTED;               \
+    if ((long)(wide8 ? 2048 : xk::SYMM_TRH) * lda * (long)sizeof(T) > 0x7fffffe0L) return XK_ERR_UNSUPPORTED; \
     hipStream_t st = (hipStream_t)stream;                                                                   \
     const int L = ((opts >> 8) & 0xff) ? ((opts >> 8) & 0xff) : 1, fl = 3 & ~opts;                          \
     const bool persist = (opts & 16) != 0;                                                                  \
     int nslots = (opts >> 16) & 0xfff;                                                                      \
     if (persist && nslots == 0) nslots = 2 * xk::symm_device_cus();                                         \
+    if (persist && wide8) nslots = (nslots + 1) / 2;              /* one 8-wave workgroup per compute unit */ \
     if (persist && (nslots <= 0 || ws_elems < xk::SYMM_QUEUE_ELEMS)) return XK_ERR_ARG;                     \
     unsigned* queue = persist ? reinterpret_cast<unsigned*>(ws + (ws_elems - xk::SYMM_QUEUE_ELEMS)) : nullptr; \
     if (persist) ws_elems -= xk::SYMM_QUEUE_ELEMS;                                                          \
@@ -629,6 +660,7 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
       if (sizeof(T) == 8 && (long)B * nr1 < xk::SYMM_SMALL_LAUNCH) trh = 512;                               \
       if (sizeof(T) == 8 && (opts & 4)) trh = 512;                                                          \
       if (opts & 8) trh = xk::SYMM_TRH;                                                                     \
+      if (wide8) trh = 2048;                                                                                \
     }                                                                                                       \
     const int NT = (N + trh - 1) / trh;                                                                     \
     int nruns = 0;                                                                                          \
@@ -684,11 +716,19 @@ long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size) {
   }
 
 #define XK_SYMM_LAUNCH(PP, RR, PERS)                                                                      \
-  hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP, RR, PERS>), grid, dim3(256), lds, st, A, Xc, rowP, colP, \
+  hipLaunchKernelGGL((xk::dense_symm_tiles<TT, PP, RR, PERS, 4>), grid, dim3(256), lds, st, A, Xc, rowP, colP, \
                      nruns, N, lda, sA, ldx, sX, NS, NT, NSL, L, fl, queue, nitems)
+#define XK_SYMM_WIDE8(PP, PERS)                                                                           \
+  do {                                                                                                    \
+    const int wrc = xk::symm_launch_wide8<TT, PP, PERS>(grid, lds, st, A, Xc, rowP, colP, nruns, N, lda, sA, ldx, \
+                                                        sX, NS, NT, NSL, L, fl, queue, nitems);           \
+    if (wrc != XK_OK) return wrc;                                                                         \
+  } while (0)
 #define XK_SYMM_CASE(PP)                                                                                  \
   case PP:                                                                                                \
-    if (trh == 512) {                                                                                     \
+    if (wide8) {                                                                                          \
+      if (persist) XK_SYMM_WIDE8(PP, true); else XK_SYMM_WIDE8(PP, false);                                \
+    } else if (trh == 512) {                                                                              \
       if (persist) XK_SYMM_LAUNCH(PP, 512, true); else XK_SYMM_LAUNCH(PP, 512, false);                    \
     } else {                                                                                              \
       if (persist) XK_SYMM_LAUNCH(PP, 1024, true); else XK_SYMM_LAUNCH(PP, 1024, false);                  \

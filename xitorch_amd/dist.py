@@ -98,8 +98,31 @@ class DeviceComm:
             self.handle = None
 
 
-_COMMS = {}            # (id(group), device index, stream handle) -> DeviceComm
-_NO_DEVICE_COMM = set()   # id(group) of groups that stay on c10d
+# Both caches hold the group OBJECT next to what they cache: while an entry exists the object is alive, so its id()
+# cannot be handed to a later group (destroy_process_group() + init_process_group() in one process — tests, elastic
+# restarts — used to be able to pick up a communicator of the old membership).  Entries of groups that c10d no longer
+# knows are closed and dropped whenever a new communicator is about to be made.
+_COMMS = {}            # (id(group), device index, stream handle) -> (group, DeviceComm)
+_NO_DEVICE_COMM = {}   # id(group) -> group, for groups that stay on c10d
+
+
+def _group_alive(group):
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        return group in c10d._world.pg_map
+    except Exception:                                      # noqa: private registry moved — keep the entry
+        return True
+
+
+def _purge_dead_groups():
+    for key in [k for k, (g, _) in _COMMS.items() if not _group_alive(g)]:
+        _, comm = _COMMS.pop(key)
+        try:
+            comm.close()
+        except Exception:                                  # noqa
+            pass
+    for gid in [i for i, g in _NO_DEVICE_COMM.items() if not _group_alive(g)]:
+        _NO_DEVICE_COMM.pop(gid)
 
 
 def device_comm(group, device):
@@ -114,13 +137,15 @@ def device_comm(group, device):
     dist = torch.distributed
     device = torch.device(device)
     if device.type != "cuda" or dist.get_backend(group) != "nccl":
-        _NO_DEVICE_COMM.add(gid)
+        _purge_dead_groups()
+        _NO_DEVICE_COMM[gid] = group
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (gid, idx, torch.cuda.current_stream(device).cuda_stream)
-    comm = _COMMS.get(key)
-    if comm is not None:
-        return comm
+    hit = _COMMS.get(key)
+    if hit is not None:
+        return hit[1]
+    _purge_dead_groups()
     # Every rank executes the same c10d collectives here whatever fails locally: one broadcast, one agreement before the
     # RCCL calls, one after.  The self-test compares with the known answers (SUM of rank + 1, MAX of -rank).
     comm, ok = None, False
@@ -151,21 +176,22 @@ def device_comm(group, device):
                 comm.close()
             except Exception:                          # noqa
                 pass
-        _NO_DEVICE_COMM.add(gid)
+        _NO_DEVICE_COMM[gid] = group
         import warnings
         warnings.warn("xitorch_amd: device-side collectives unavailable for this process group; using c10d all-reduce")
         return None
-    _COMMS[key] = comm
+    _COMMS[key] = (group, comm)
     return comm
 
 
 def close_device_comms():
-    for comm in _COMMS.values():
+    for _, comm in _COMMS.values():
         try:
             comm.close()
         except Exception:                              # noqa
             pass
     _COMMS.clear()
+    _NO_DEVICE_COMM.clear()
 
 
 def _allreduce_(t, group, name):

@@ -760,6 +760,22 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
             import warnings
             warnings.warn("xitorch_amd davidson: CU-masked streams unavailable (%s); running one batch group" % err)
             two = False
+    distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
+    if distributed:
+        # Sharded run: every batch group issues one status all-reduce per iteration (`_Group.small`), so the ranks must
+        # run the SAME number of groups.  What a rank would pick depends on its local shard (B >= 2, the 8 GiB
+        # threshold, whether CU-masked streams came up): the ranks agree on the minimum before any group exists.
+        g_local = ngrp if two else 1
+        g_all = torch.tensor([-float(g_local)], dtype=torch.float64, device=device)
+        # (through c10d: a one-off on the caller's stream is not worth a communicator of its own)
+        torch.distributed.all_reduce(g_all, op=torch.distributed.ReduceOp.MAX, group=process_group)
+        g_common = int(round(-g_all.item()))
+        if g_common < g_local:
+            if g_common <= 1:
+                two = False
+            else:
+                ngrp = g_common
+                grp_streams, k1_streams = grp_streams[:ngrp], k1_streams[:ngrp]
     if two:
         cuts = [(B * g) // ngrp for g in range(ngrp + 1)]
         spans = [(cuts[g], cuts[g + 1]) for g in range(ngrp)]
@@ -827,7 +843,6 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
     history = []
     stop_reason = "max_niter"
     niter = 0
-    distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
     for grp in groups:
         grp.pg = process_group if distributed else None
     n_fallback = [0]

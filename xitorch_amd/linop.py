@@ -602,25 +602,79 @@ class MatrixLinearOperator(LinearOperator):
 
 
 # ------------------------------------------------------------------------ row-block sharded dense operator
+def _all_gather_rows(y_loc, bounds, rank, group):
+    """concatenation over the ranks of their row blocks (blocks of unequal height are padded for the collective)"""
+    import torch.distributed as dist
+    world = len(bounds) - 1
+    nmax = max(bounds[r + 1] - bounds[r] for r in range(world))
+    pad = torch.zeros((*y_loc.shape[:-2], nmax, y_loc.shape[-1]), dtype=y_loc.dtype, device=y_loc.device)
+    pad[..., :bounds[rank + 1] - bounds[rank], :] = y_loc
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad.contiguous(), group=group)
+    return torch.cat([parts[r][..., :bounds[r + 1] - bounds[r], :] for r in range(world)], dim=-2)
+
+
+# The four autograd pieces of the row-sharded products.  Everything outside the operator is REPLICATED: every rank holds
+# the same x, computes the same y and the same loss, so the gradient of a replicated tensor is the sum (or the
+# concatenation) of what the ranks' local graphs produce, and each collective's backward is its dual collective.  The
+# backward collectives run in the same order on every rank because the ranks differentiate the same replicated graph.
 class _GatherRows(torch.autograd.Function):
-    """y = concatenation over the ranks of their row blocks (all-gather); every rank continues with the same replicated
-    y, so the gradient of the (replicated) loss w.r.t. this rank's block is its own slice of grad y."""
+    """y = all-gather of the ranks' row blocks; every rank continues with the same replicated y, so the gradient
+    w.r.t. this rank's block is its own slice of grad y."""
 
     @staticmethod
     def forward(ctx, y_loc, bounds, rank, group):
-        import torch.distributed as dist
-        world = len(bounds) - 1
-        nmax = max(bounds[r + 1] - bounds[r] for r in range(world))
         ctx.lo, ctx.hi = bounds[rank], bounds[rank + 1]
-        pad = torch.zeros((*y_loc.shape[:-2], nmax, y_loc.shape[-1]), dtype=y_loc.dtype, device=y_loc.device)
-        pad[..., :ctx.hi - ctx.lo, :] = y_loc
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad.contiguous(), group=group)
-        return torch.cat([parts[r][..., :bounds[r + 1] - bounds[r], :] for r in range(world)], dim=-2)
+        return _all_gather_rows(y_loc, bounds, rank, group)
 
     @staticmethod
     def backward(ctx, gy):
         return gy[..., ctx.lo:ctx.hi, :], None, None, None
+
+
+class _ReplicatedIn(torch.autograd.Function):
+    """identity on a replicated input whose consumers are rank-local (this rank's row block times x): the gradient of
+    the replicated x is the SUM over the ranks of the local contributions local_r^H gy[lo_r:hi_r]."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gx):
+        import torch.distributed as dist
+        gx = gx.contiguous().clone()
+        dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=ctx.group)
+        return gx, None
+
+
+class _SumOverRanks(torch.autograd.Function):
+    """y = all-reduce(SUM) of the ranks' partial results; y is replicated, so every partial receives grad y as it is."""
+
+    @staticmethod
+    def forward(ctx, y_part, group):
+        import torch.distributed as dist
+        y = y_part.contiguous().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, None
+
+
+class _OwnRows(torch.autograd.Function):
+    """this rank's row slice of a replicated x; the gradient of the replicated x is the all-gather of the slices'."""
+
+    @staticmethod
+    def forward(ctx, x, bounds, rank, group):
+        ctx.bounds, ctx.rank, ctx.group = bounds, rank, group
+        return x[..., bounds[rank]:bounds[rank + 1], :]
+
+    @staticmethod
+    def backward(ctx, gs):
+        return _all_gather_rows(gs, ctx.bounds, ctx.rank, ctx.group), None, None, None
 
 
 class RowShardedMatrixLinearOperator(LinearOperator):
@@ -671,19 +725,22 @@ class RowShardedMatrixLinearOperator(LinearOperator):
         return _GatherRows.apply(y_loc, self.bounds, self.rank, self.group)
 
     def _mm(self, x):
+        if self.world > 1 and x.requires_grad and torch.is_grad_enabled():
+            x = _ReplicatedIn.apply(x, self.group)            # grad x = sum over the ranks of local^H gy[own rows]
         return self._gather(_dense_mm(self.local, x, False))
 
     def _mv(self, x):
         return self._mm(x.unsqueeze(-1)).squeeze(-1)
 
     def _rmm(self, x):
-        import torch.distributed as dist
         lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        y = _dense_mm(self.local, x[..., lo:hi, :], True)
-        if self.world > 1:
-            y = y.contiguous()
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
-        return y
+        if self.world == 1:
+            return _dense_mm(self.local, x[..., lo:hi, :], True)
+        if x.requires_grad and torch.is_grad_enabled():
+            xs = _OwnRows.apply(x, self.bounds, self.rank, self.group)     # grad x = all-gather of the slices' gradients
+        else:
+            xs = x[..., lo:hi, :]
+        return _SumOverRanks.apply(_dense_mm(self.local, xs, True), self.group)
 
     def _rmv(self, x):
         return self._rmm(x.unsqueeze(-1)).squeeze(-1)
