@@ -78,6 +78,11 @@ def parse():
                          "implicit backward, c5 / c5w the fp32 N=32768 shard with a 6- / 16-column block")
     ap.add_argument("--cfg-batch", type=int, default=0, help="--config: operators / systems per GPU (0 = the config's own)")
     ap.add_argument("--gmres-restart", type=int, default=0, help="--config c3g: restarted GMRES(m) (0 = un-restarted)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (the other BASELINE.json configs, measured after the headline: c0 N=512 "
+                         "symeig, c3 BiCGStab fwd+bwd, c4 Broyden shard, c5w fp32 16-column shard; each with its roofline and "
+                         "a CPU baseline)")
+    ap.add_argument("--cfg-steps", type=int, default=5, help="timed steps of every entry of the `configs` block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="4x4096", help="BxN of the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -200,6 +205,146 @@ def cpu_baseline(args):
     except Exception as err:
         out["k1_product_cpu"] = {"error": repr(err)}
     return out
+
+
+def _config0(args, dev, cpu):
+    """BASELINE configs[0] on the GPU: symeig lowest-6 of ONE dense symmetric 512 x 512 fp64 operator (the reference's
+    benchmarks_solve.py shape), `davidson` and the reference's default `exacteig`, as a bench record."""
+    from tests import cases as _cases
+    from xitorch_amd import LinearOperator as _LO
+    from xitorch_amd.linalg import symeig as _symeig
+    m1 = _cases.random_symmetric(512, -1.0, 1.0, 123)
+    Ag = _LO.m(m1.to(dev), is_hermitian=True)
+    ref = torch.linalg.eigvalsh(m1)[:6]
+
+    def timed(method, steps):
+        def call():
+            tr = {}
+            with torch.no_grad():
+                kw = dict(method="davidson", min_eps=1e-8, trace=tr) if method == "davidson" else {}
+                ev, _ = _symeig(Ag, neig=6, mode="lowest", **kw)
+            torch.cuda.synchronize()
+            return ev, tr
+        call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ev, tr = call()
+        return (time.perf_counter() - t0) / steps, ev, tr
+    t_d, ev_d, tr_d = timed("davidson", max(args.cfg_steps, 5))
+    t_x, ev_x, _ = timed("exacteig", max(args.cfg_steps, 5))
+    napply = tr_d.get("napply") or tr_d.get("niter") or 1
+    by = 512 * 512 * 8 + 2 * 512 * 6 * 8
+    rec = {"metric": "eigpairs/s of symeig lowest-6, dense symmetric N=512 batch=1 fp64",
+           "value": 6 / t_d, "unit": "eigpairs/s", "ms_per_step": t_d * 1e3, "steps": max(args.cfg_steps, 5), "dtype": "f64",
+           "config": {"workload": "BASELINE configs[0]: linalg.symeig lowest-6 of one dense symmetric 512 x 512 fp64 operator "
+                                  "(benchmarks_solve.py shape), method=davidson, min_eps=1e-8",
+                      "iterations_per_step": tr_d.get("niter"), "basis_size": tr_d.get("basis_size")},
+           "exacteig": {"value": 6 / t_x, "unit": "eigpairs/s", "ms_per_step": t_x * 1e3,
+                        "note": "the reference's default method (symeig method=None) on the native dense eigensolver",
+                        "max_abs_err_vs_lapack": (ev_x.cpu() - ref).abs().max().item()},
+           "roofline": {"bound": "latency", "kernel": "panel product of ONE 2 MB operator (xk_dense_mm)", "peak": 8000.0,
+                        "unit": "GB/s", "algorithmic_bytes_per_launch": by, "launches_per_step": napply,
+                        "achieved": by * napply / t_d / 1e9, "frac": by * napply / t_d / 1e9 / 8000.0, "traffic": None,
+                        "avg_launch_ms": None,
+                        "note": "one 512 x 512 operator is 2 MB: the call is a chain of a few hundred small launches, "
+                                "bound by launch latency, not by HBM; achieved = all panel bytes of the call / the call"},
+           "check": {"ok": bool((ev_d.cpu() - ref).abs().max().item() < 1e-9),
+                     "max_abs_err_vs_lapack": (ev_d.cpu() - ref).abs().max().item()}}
+    if cpu and "config1_n512_b1" in cpu and "cpu_davidson_ms" in cpu["config1_n512_b1"]:
+        c1 = cpu["config1_n512_b1"]
+        rec["cpu_baseline"] = {"value": c1["cpu_davidson_eigpairs_per_s"], "unit": "eigpairs/s", "cores": cpu.get("cores"),
+                               "kind": "port", "sample": "the config itself (oracle davidson, %d threads): %.1f ms per call; "
+                               "oracle exacteig: %.1f ms per call" % (cpu.get("cores", 0), c1["cpu_davidson_ms"],
+                                                                     c1["cpu_exacteig_ms"]),
+                               "exacteig_value": c1["cpu_exacteig_eigpairs_per_s"]}
+    return rec
+
+
+def _configs_block(args, dev, cpu):
+    """The other BASELINE.json configs, measured in this process after the headline (rank 0 of a one-GPU run): same
+    fences and event timing as their own bench lines (`--config c3|c4|c5w`, bench_secondary.py), `--cfg-steps` timed
+    steps each, every record with its roofline and a CPU baseline (oracle on a bounded sample)."""
+    import copy
+    import bench_secondary as bs
+    out = {}
+
+    def fence():
+        torch.cuda.synchronize()
+    sub = copy.copy(args)
+    sub.steps, sub.warmup, sub.no_general_extra, sub.cfg_batch = args.cfg_steps, 1, True, 0
+    keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_note",
+                 "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_timed", "TFLOPs", "frac_of_fp32_matrix_peak")
+    try:
+        out["c0"] = _config0(args, dev, cpu)
+    except Exception as err:
+        out["c0"] = {"error": repr(err)}
+    plan = [("c3", bs.config_c3, lambda: bs.cpu_baseline_c3(args.cpu_threads)),
+            ("c4", bs.config_c4, lambda: bs.cpu_baseline_c4(args.cpu_threads)),
+            ("c5w", bs.config_c5w, lambda: bs.cpu_baseline_c5(args.cpu_threads, 16))]
+    for name, fnc, cpufn in plan:
+        try:
+            torch.cuda.empty_cache()
+            line = fnc(sub, dev, None, 1, 0, fence)
+            rec = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "check") if k in line}
+            rec["steps"], rec["warmup"] = sub.steps, sub.warmup
+            rec["config"] = {k: v for k, v in line["config"].items()
+                             if k in ("workload", "global_batch", "batch_per_gpu", "forward_ms", "backward_ms",
+                                      "iterations_per_step", "niter_forward", "niter_backward", "nfev", "panel_kernel")}
+            rec["roofline"] = {k: line["roofline"].get(k) for k in keep_roof if k in line["roofline"]}
+            if not args.no_cpu_baseline:
+                try:
+                    rec["cpu_baseline"] = cpufn()
+                except Exception as err:
+                    rec["cpu_baseline"] = {"error": repr(err)}
+            out[name] = rec
+        except Exception as err:            # a secondary record never costs the headline line
+            out[name] = {"error": repr(err)}
+        torch.cuda.empty_cache()
+    return out
+
+
+def _multi_gpu_diag(group, dev, elapsed_local, k1_avg_local, steps):
+    """What makes the first real N-GPU run diagnosable from its one line: every rank's own wall time of the timed region
+    and its own panel-launch average (all-gathered), the spread between the ranks, and the latency of the solver's
+    per-iteration status all-reduce — the same call the eigensolver makes (`xitorch_amd.dist.allreduce_max_`: in-stream
+    RCCL through the C ABI on HIP tensors, c10d otherwise), timed back to back on the current stream after the run."""
+    import torch.distributed as dist
+    from xitorch_amd import dist as xd
+    world = dist.get_world_size(group)
+    mine = torch.tensor([elapsed_local * 1e3 / max(steps, 1), (k1_avg_local or 0.0) * 1e3], dtype=torch.float64, device=dev)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    per_step = [round(v[0].item(), 3) for v in allv]
+    per_k1 = [round(v[1].item(), 4) for v in allv]
+    st = torch.zeros(5, dtype=torch.float64, device=dev)
+    reps = 50
+    for _ in range(5):
+        xd.allreduce_max_(st, group)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            xd.allreduce_max_(st, group)
+        e1.record()
+        torch.cuda.synchronize()
+        lat_us = e0.elapsed_time(e1) * 1e3 / reps
+        how = "HIP events around %d back-to-back in-stream all-reduces of the 5-double status vector" % reps
+    else:
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            xd.allreduce_max_(st, group)
+        lat_us = (time.perf_counter() - t0) * 1e6 / reps
+        how = "host clock around %d back-to-back all-reduces of the 5-double status vector (CPU ranks)" % reps
+    lat = torch.tensor([lat_us], dtype=torch.float64, device=dev)
+    dist.all_reduce(lat, op=dist.ReduceOp.MAX, group=group)
+    return {"per_rank_ms_per_step": per_step, "per_rank_k1_avg_launch_ms": per_k1,
+            "rank_skew_ms_per_step": round(max(per_step) - min(per_step), 3),
+            "status_allreduce_latency_us": round(lat.item(), 2), "status_allreduce_timing": how,
+            "status_allreduce_backend": ("device RCCL communicator (C ABI, in stream)"
+                                         if (dev.type == "cuda" and xd.device_comm(group, dev) is not None)
+                                         else "c10d " + str(dist.get_backend(group)))}
 
 
 def _respawn(args):
@@ -363,6 +508,7 @@ def main_dry(args):
         if group is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        run.local_elapsed = elapsed
         if group is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -377,6 +523,7 @@ def main_dry(args):
 
     b_local, b_total, offset = shard(args.scaling)
     elapsed, fmax, tr = run(b_local, offset, args.steps, args.warmup)
+    multi_gpu = _multi_gpu_diag(group, torch.device("cpu"), run.local_elapsed, None, args.steps) if group is not None else None
     weak_extra = None
     if world > 1 and args.scaling == "strong" and not args.no_weak_extra:
         wl, wt, woff = shard("weak")
@@ -399,7 +546,7 @@ def main_dry(args):
                        "parallelism": "batch-sharded x%d (%s)" % (world, args.scaling),
                        "comm_backend": dist.get_backend(group) if group is not None else None,
                        "comm_world_size": dist.get_world_size(group) if group is not None else 1},
-            "roofline": None, "weak_extra": weak_extra,
+            "roofline": None, "weak_extra": weak_extra, "multi_gpu": multi_gpu,
             "check": {"ok": bool(fmax < 1e-8 and nit[0].item() == -nit[1].item()), "max_abs_f": fmax,
                       "iterations": int(nit[0].item())}}), flush=True)
     if group is not None:
@@ -423,7 +570,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if args.k1s_run > 0 or args.k1s_opts >= 0:
         from xitorch_amd import kernels as _XK
-        low = _XK.K1S_OPTS & 0xff if args.k1s_opts < 0 else args.k1s_opts & 0xff
+        low = ((_XK.K1S_OPTS or 0) & 0xff) if args.k1s_opts < 0 else args.k1s_opts & 0xff
         _XK.K1S_OPTS = (int(args.k1s_run) << 8) | low   # column slabs per workgroup run | flag bits (arguments of K1s)
     group, backend, rccl_world = None, None, 1
     # XITORCH_BENCH_FORCE_PG=1: create the RCCL process group even for one rank (smoke test of the N > 1 plumbing —
@@ -525,8 +672,10 @@ def main():
         for _ in range(steps):
             evals, evecs = step(True)
             marks.append(time.perf_counter())     # host clock only (davidson returns after its last status read)
+        t_own = (marks[-1] - t0) if marks else 0.0      # this rank's own steps, before the closing fence
         fence()
         elapsed = time.perf_counter() - t0
+        run.local_elapsed = t_own
         if group is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -553,6 +702,9 @@ def main():
     resid = traces[-1]["best_resid"]
     ok = eval_err <= tol * 100.0 and resid < args.min_eps
     roofline, durs = _k1_roofline(k1_events, N, p, esize, symm, b_local)
+    multi_gpu = None
+    if group is not None:
+        multi_gpu = _multi_gpu_diag(group, dev, run.local_elapsed, (sum(durs) / len(durs)) if durs else None, args.steps)
 
     # ---------------- extra: the timed kernel alone on the GPU (no other batch group beside it) ----------------
     # inside the two-group pipeline the panel product shares HBM with the other group's small kernels (that is the
@@ -611,6 +763,15 @@ def main():
                    "steps": len(g_ms), "iterations_per_step": g_tr[-1]["niter"], "roofline": g_roof,
                    "max_eval_err_vs_exact": (g_evals.double() - exact).abs().max().item(),
                    "note": "same workload, full-matrix panel kernel (operators whose storage is not exactly symmetric)"}
+        gr = g_roof
+        roofline["survey_8d"] = {
+            "kernel": gr["kernel"], "frac": gr["frac"], "achieved": gr["achieved"], "avg_launch_ms": gr["avg_launch_ms"],
+            "algorithmic_bytes_per_launch": gr["algorithmic_bytes_per_launch"], "traffic": gr["traffic"],
+            "launches_timed": gr["launches_timed"], "eigpairs_per_s": general["value"], "ms_per_step": general["ms_per_step"],
+            "note": "SURVEY 8d prices the panel product on A read once IN FULL (no credit for symmetry): this is the same "
+                    "workload on the full-matrix kernel K1 (what an operator whose storage is not exactly symmetric gets), "
+                    "timed the same way after the headline's timed region; `frac` above prices the upper-triangle kernel "
+                    "on the bytes IT must move"}
     elif not symm:
         # one whole-batch launch of the general kernel, timed alone (untimed region), bytes of the WHOLE batch
         Xg = torch.randn((b_local, p, N), dtype=dtype, device=dev)
@@ -664,6 +825,7 @@ def main():
             "roofline": roofline,
             "general_k1": general,
             "weak_extra": weak_extra,
+            "multi_gpu": multi_gpu,
             "matvec_fraction_of_step": sum(durs) / elapsed if elapsed > 0 else None,
             "check": {"ok": bool(ok), "max_eval_err_vs_exact": eval_err, "max_resid": resid},
             "step_ms": step_ms,
@@ -675,6 +837,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not args.no_configs:
+            try:
+                del A, mat
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            out["configs"] = _configs_block(args, dev, out.get("cpu_baseline"))
         import ctypes
         ctypes.CDLL(None).fflush(None)          # nothing buffered by native libraries may follow the line
         print(json.dumps(out), flush=True)

@@ -376,3 +376,94 @@ def run(args, dev, group, world, rank, fence, backend):
 
 if __name__ == "__main__":
     sys.exit("run through bench.py: python bench.py --config c3|c3g|c4|c5|c5w")
+
+
+# ------------------------------------------------------------------------------------------------- CPU baselines
+# The oracle (CPU restatement of the reference's loops, oracle/*.py — test infrastructure) timed on the host cores on a
+# BOUNDED sample of each config's workload.  Only bench.py's cpu_baseline leg calls these (rank 0, one GPU).
+def _cpu_median(fn, budget_s, nmin=2, nmax=20):
+    ts, t_all, last = [], time.time(), None
+    while len(ts) < nmin or (time.time() - t_all < budget_s and len(ts) < nmax):
+        t0 = time.time()
+        last = fn()
+        ts.append(time.time() - t0)
+    return sorted(ts)[len(ts) // 2], len(ts), last
+
+
+def cpu_baseline_c3(threads, B=8, N=65536, hb=63, budget_s=8.0):
+    """configs[2] on the CPU: oracle BiCGStab on the banded operator, forward solve + the adjoint solve of the implicit
+    backward (xitorch/linalg/solve.py:186-195: one more solve with A^H), same tolerances as the GPU step."""
+    from oracle import ops as oops, solve as osolve
+    from xitorch_amd import synthetic as syn
+    torch.set_num_threads(threads)
+    band = syn.banded(B, N, hb)
+    xs = syn.banded_rhs_solution(B, N)
+    op = oops.BandedOp(band)
+    rhs = op._mm(xs)
+    opH = oops.FuncOp(op.shape, op.dtype, mm=op._rmm, rmm=op._mm)
+    tr = {}
+
+    def step():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x = osolve.bicgstab(op, rhs, rtol=1e-10, atol=1e-12, posdef=True, trace=tr)
+            g = osolve.bicgstab(opH, torch.ones_like(x), rtol=1e-10, atol=1e-12, posdef=True)
+        return x, g
+    t, n, (x, _) = _cpu_median(step, budget_s)
+    return {"value": B / t, "unit": "systems/s (forward + backward)", "cores": threads, "kind": "port",
+            "sample": "oracle bicgstab (torch-CPU restatement of solve.py:192-324) on the banded operator bw=%d N=%d, "
+                      "batch=%d of the config's 256: forward solve + adjoint solve of the implicit backward, rtol=1e-10; "
+                      "median of %d runs (%.2f s each, %d iterations forward)" % (2 * hb + 1, N, B, n, t, tr.get("niter", -1)),
+            "seconds": t, "max_err_vs_manufactured_solution": (x - xs).abs().max().item()}
+
+
+def cpu_baseline_c4(threads, B=2, N=8192, budget_s=8.0):
+    """configs[3] on the CPU: oracle Broyden (rootsolver.py:15-206) on tanh(A y + 0.1) + y/2, then the implicit
+    backward's linear solve with J^H (optimize/rootfinder.py backward -> linalg.solve), J applied in closed form."""
+    from oracle import ops as oops, solve as osolve, rootfinder as oroot
+    from xitorch_amd import synthetic as syn
+    torch.set_num_threads(threads)
+    A = syn.root_matrix(B, N) * 2.0
+    y0 = torch.zeros(B, N, dtype=torch.float64)
+
+    def fcn(y, A_):
+        return torch.tanh(torch.matmul(A_, y.unsqueeze(-1)).squeeze(-1) + 0.1) + y / 2.0
+    tr = {}
+
+    def step():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = oroot.broyden1(fcn, y0, (A,), alpha=-1.0, max_rank=32, f_tol=1e-8, trace=tr)
+            t_ = torch.tanh(torch.matmul(A, y.unsqueeze(-1)) + 0.1)                  # (B, N, 1)
+            d = 1.0 - t_ * t_
+            JH = oops.FuncOp((B, N, N), torch.float64, mm=lambda v: torch.matmul(A.transpose(-2, -1), d * v) + v / 2.0,
+                             rmm=lambda v: d * torch.matmul(A, v) + v / 2.0)
+            g = osolve.bicgstab(JH, torch.ones(B, N, 1, dtype=torch.float64), rtol=1e-10, atol=1e-12, posdef=True)
+        return y, g
+    t, n, (y, _) = _cpu_median(step, budget_s)
+    return {"value": B / t, "unit": "members/s (forward + backward)", "cores": threads, "kind": "port",
+            "sample": "oracle broyden1 (alpha=-1, max_rank=32, f_tol=1e-8) on tanh(A y + 0.1) + y/2, N=%d batch=%d of the "
+                      "shard's 64, + the implicit backward's J^H solve (oracle bicgstab rtol=1e-10, J in closed form); "
+                      "median of %d runs (%.2f s each, nfev=%s)" % (N, B, n, t, tr.get("nfev")),
+            "seconds": t, "fnorm_at_returned_root": fcn(y, A).norm().item()}
+
+
+def cpu_baseline_c5(threads, p, B=1, N=8192, budget_s=8.0):
+    """configs[4] on the CPU: oracle davidson in fp32 with the config's block width on a smaller operator."""
+    from oracle import ops as oops, symeig as osym
+    from xitorch_amd import synthetic as syn
+    torch.set_num_threads(threads)
+    kind = "S1" if p <= 6 else "S1:%d" % p
+    mat = syn.dense_symmetric(B, N, kind, dtype=torch.float32)
+    op = oops.DenseOp(mat, True)
+    tr = {}
+
+    def step():
+        return osym.davidson(op, p, "lowest", min_eps=2e-3, max_niter=60, trace=tr)
+    t, n, (ev, _) = _cpu_median(step, budget_s)
+    exact = syn.spectrum(kind, N)[:p]
+    return {"value": B * p / t, "unit": "eigpairs/s", "cores": threads, "kind": "port",
+            "sample": "oracle davidson (torch-CPU restatement of symeig.py:100-227) fp32 lowest-%d, dense symmetric %s "
+                      "N=%d batch=%d (the shard is 16 x 32768^2: 68.7 GB), min_eps=2e-3; median of %d runs (%.2f s each, "
+                      "%s iterations)" % (p, kind, N, B, n, t, tr.get("niter")),
+            "seconds": t, "max_eval_err_vs_closed_form": (ev.double() - exact).abs().max().item()}

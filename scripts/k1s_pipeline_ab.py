@@ -38,7 +38,8 @@ tri = lambda nb: nb * N * (N + 1) // 2 * 8 + 2 * nb * N * p * 8
 def parse(spec):
     name, rest = spec.split("=", 1)
     f = rest.split(":")
-    return {"name": name, "opts": int(f[0]), "streams": int(f[1]) if len(f) > 1 else 1,
+    return {"name": name, "opts": None if f[0] == "auto" else int(f[0]),
+            "streams": ("auto" if f[1] == "auto" else int(f[1])) if len(f) > 1 else 1,
             "reserve": int(f[2]) if len(f) > 2 else "auto"}
 
 
@@ -51,7 +52,8 @@ def call(v, events):
     tr = {"k1_events": events}
     with torch.no_grad():
         ev, _ = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, v_init="randn", rng_device="device",
-                       max_niter=200, reserve_cus=v["reserve"], k1_streams=(v["streams"] == 2), trace=tr)
+                       max_niter=200, reserve_cus=v["reserve"],
+                       k1_streams=("auto" if v["streams"] == "auto" else v["streams"] == 2), trace=tr)
     return ev, tr
 
 
@@ -90,7 +92,7 @@ for v in variants:
                       "niter": r["niter"], "max_eval_err": r["err"]}), flush=True)
 
 if args.alone:
-    forms = sorted(set(v["opts"] for v in variants) | {0})
+    forms = sorted(set(v["opts"] for v in variants if v["opts"] is not None) | {0})
     for nb in (B // 2, B):
         X = torch.randn((nb, p, N), dtype=torch.float64, device=dev)
         Y = torch.empty_like(X)

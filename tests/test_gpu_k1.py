@@ -113,7 +113,9 @@ def symm_run():
     prev = K.K1S_OPTS
 
     def select(v, tile=0):
-        K.K1S_OPTS = (int(v) << 8) | {0: 0, 512: 4, 1024: 8}[tile]     # bit 2 / 3: force 512- / 1024-row tiles
+        # bit 2 / 3: force 512- / 1024-row tiles; forced opts = the one-workgroup-per-run launch (the resident and 8-wave
+        # forms have their own test below)
+        K.K1S_OPTS = (int(v) << 8) | {0: 0, 512: 4, 1024: 8}[tile]
     yield select
     K.K1S_OPTS = prev
 

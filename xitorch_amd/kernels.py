@@ -616,14 +616,42 @@ def _destroy_masked_streams():
 
 
 # --------------------------------------------------------------------------- K1s symmetric storage
-K1S_OPTS = 0          # low 16 bits of the `opts` of the K1s entry points handed to every call (include/xitorch_amd.h)
+K1S_OPTS = None       # None = the shipped choice per launch (`k1s_auto_opts`); an int = low 16 bits of the `opts` of the K1s
+                      # entry points handed to every call (measurement scripts, tests; include/xitorch_amd.h)
 K1S_PERSIST = 16      # opts bit 4: resident workgroups taking runs from a queue (two per compute unit of the stream)
+K1S_WIDE8 = 32        # opts bit 5 (fp64): 8-wave workgroups on 2048 x 2048 tiles, one per compute unit
 
 
-def _k1s_opts(stream, opts=None):
-    """`opts` of one K1s launch on `stream`: the module's flag bits, plus — for the resident form — the workgroup
-    count (bits 16..27) that fills the compute units `stream` may use, two workgroups each."""
+def k1s_auto_opts(B, N, dtype, cus, pipelined=False):
+    """The form of one K1s launch over B operators of order N on `cus` compute units (r05, profiles/r05_k1s_*):
+      * resident launch (workgroups take runs from a queue) from two rounds of workgroups on — below that the launch is
+        one wave of workgroups either way; inside the eigensolver's two-group pipeline this is what lets the other
+        group's launch, on its own stream, move into the slots the tail frees (217.6 -> 211.9 ms per configs[1] call);
+      * fp64: 8-wave workgroups on 2048 x 2048 tiles (half the partial-sum bytes written and folded) once the launch has
+        enough of them: a tile is 32 MB, so alone on the GPU it needs ~8 per compute unit to beat the 4-wave form
+        (64 x 16384^2: 10.91 vs 11.31 ms; 32 x 16384^2: 5.55 vs 5.45), inside the pipeline — tails overlapped — about 4
+        (32 operators per launch: 216.7 -> 209.9 ms per call)."""
+    if B <= 0 or N <= 0:
+        return 0
+    f64 = dtype == torch.float64
+    slab = 1024 if f64 else 2048
+    ns = (N + slab - 1) // slab
+    runs4 = B * sum(ns - (i * 1024) // slab for i in range((N + 1023) // 1024))
+    o = K1S_PERSIST if runs4 >= 4 * cus else 0
+    if f64 and (o & K1S_PERSIST):
+        n8 = (N + 2047) // 2048
+        if B * n8 * (n8 + 1) // 2 >= (4 if pipelined else 8) * cus:
+            o |= K1S_WIDE8
+    return o
+
+
+def _k1s_opts(stream, opts=None, shape=None, pipelined=False):
+    """`opts` of one K1s launch on `stream`: the forced flag bits (argument or module) or the shipped choice for the
+    launch's `shape` = (B, N, dtype), plus — for the resident form — the workgroup count (bits 16..27) that fills the
+    compute units `stream` may use, two workgroups each."""
     o = K1S_OPTS if opts is None else int(opts)
+    if o is None:
+        o = k1s_auto_opts(shape[0], shape[1], shape[2], stream_cus(stream), pipelined) if shape is not None else 0
     if (o & K1S_PERSIST) and not (o >> 16):
         o |= min(0xfff, 2 * stream_cus(stream)) << 16
     return o
@@ -649,7 +677,8 @@ def dense_symm(A, X, out=None, opts=None):
     nws = fn("xk_dense_symm_workspace_elems")(B, N, P, esize)
     ws = _workspace(nws, X.dtype, X.device)
     rc = fn("xk_dense_symm_" + suffix(X.dtype))(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA,
-                                                 ldx, sX, ldy, sY, _k1s_opts(torch.cuda.current_stream(), opts),
+                                                 ldx, sX, ldy, sY,
+                                                 _k1s_opts(torch.cuda.current_stream(), opts, (B, N, X.dtype)),
                                                  stream_ptr())
     check(rc, "xk_dense_symm")
     return out
@@ -788,6 +817,7 @@ def dense_symm_split(A, X, out, tiles_stream, timed=False):
     ready, done = sync_events(cur)                          # re-recorded on every launch: no event is created here
     ready.record(cur)
     sfx = suffix(X.dtype)
+    kopts = _k1s_opts(tiles_stream, None, (B, N, X.dtype), pipelined=True)
     e0 = e1 = None
     with torch.cuda.stream(tiles_stream):
         tiles_stream.wait_event(ready)
@@ -795,14 +825,13 @@ def dense_symm_split(A, X, out, tiles_stream, timed=False):
             e0, e1 = timing_event_pair()
             e0.record(tiles_stream)
         rc = fn("xk_dense_symm_tiles_" + sfx)(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX,
-                                              _k1s_opts(tiles_stream), stream_ptr())
+                                              kopts, stream_ptr())
         check(rc, "xk_dense_symm_tiles")
         if timed:
             e1.record(tiles_stream)
         done.record(tiles_stream)
     cur.wait_event(done)
-    rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, _k1s_opts(tiles_stream),
-                                         stream_ptr())
+    rc = fn("xk_dense_symm_fold_" + sfx)(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, kopts, stream_ptr())
     check(rc, "xk_dense_symm_fold")
     return e0, e1
 

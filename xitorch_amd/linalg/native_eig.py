@@ -750,7 +750,9 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
             # evenly and finish together: they stay on one stream.
             k1_streams = [k1_stream] * ngrp
             if k1_streams_opt == "auto":
-                split_k1 = bool(K.K1S_OPTS & K.K1S_PERSIST) and whole.kind == "dense" and whole.symm \
+                k1o = K.K1S_OPTS if K.K1S_OPTS is not None else \
+                    K.k1s_auto_opts(B // ngrp, N, dtype, K.stream_cus(k1_stream), pipelined=True)
+                split_k1 = bool(k1o & K.K1S_PERSIST) and whole.kind == "dense" and whole.symm \
                     and whole.symm_narrow and p <= 6
             else:
                 split_k1 = bool(k1_streams_opt)
