@@ -83,6 +83,9 @@ def parse():
                          "symeig, c3 BiCGStab fwd+bwd, c4 Broyden shard, c5w fp32 16-column shard; each with its roofline and "
                          "a CPU baseline)")
     ap.add_argument("--cfg-steps", type=int, default=5, help="timed steps of every entry of the `configs` block")
+    ap.add_argument("--no-standalone", action="store_true",
+                    help="skip the stream-read / standalone whole-batch launches after the timed region (profiled runs: the "
+                         "trace then holds the timed region's panel launches only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="4x4096", help="BxN of the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -712,6 +715,8 @@ def main():
     # what the operator batch streams at with no arithmetic at all (3 read-only passes, idle GPU): the practical
     # ceiling of any panel kernel on this box and this placement of the batch
     try:
+        if args.no_standalone:
+            raise RuntimeError("skipped (--no-standalone)")
         XK.stream_read(mat)
         re_ = []
         for _ in range(3):
@@ -728,7 +733,7 @@ def main():
         roofline["frac_of_stream_read"] = roofline["achieved"] / roofline["stream_read"]["GBps"]
     except Exception as err:        # a measurement extra never costs the headline line
         roofline["stream_read"] = {"error": repr(err)}
-    if symm:
+    if symm and not args.no_standalone:
         Xs = torch.randn((b_local, p, N), dtype=dtype, device=dev)
         Ys = torch.empty_like(Xs)
         XK.dense_symm(mat, Xs, out=Ys)

@@ -64,6 +64,28 @@ def _roofline(bytes_per_launch, avg_ms, nlaunch, kernel, extra=None):
     return r
 
 
+def _pmc_traffic(name, units_per_launch):
+    """HBM bytes per launch from a committed PMC record (profiles/<name>_pmc_traffic.json, scripts/pmc_collect.py:
+    FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 passes), scaled to this launch's batch members; only when the
+    record was measured on the kernel source in the tree."""
+    try:
+        import hashlib
+        root = os.path.dirname(os.path.abspath(__file__))
+        rec = json.load(open(os.path.join(root, "profiles", name + "_pmc_traffic.json")))
+        h = hashlib.sha256()
+        for src in rec["kernel_source_files"]:
+            h.update(open(os.path.join(root, "xitorch_amd", "csrc", src), "rb").read())
+        if h.hexdigest() != rec["kernel_source_sha256"] or not rec.get("B"):
+            return {"traffic": None, "traffic_note": "PMC record is stale (kernel source changed since it was measured): "
+                                                     "not reported"}
+        return {"traffic": rec["hbm_bytes_per_launch"] * units_per_launch / rec["B"],
+                "traffic_note": "PMC (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of a standalone launch of the "
+                                "same kernel source over %d batch members, scaled to this launch's (profiles/%s_pmc_traffic.json)"
+                                % (rec["B"], name)}
+    except Exception:                                   # noqa: no record -> traffic stays null
+        return {}
+
+
 # ------------------------------------------------------------------------------------------------- c3 / c3g
 def _banded_problem(dev, B, N, hb, offset):
     from xitorch_amd import synthetic as syn
@@ -123,6 +145,7 @@ def config_c3(args, dev, group, world, rank, fence):
                    "applies_forward": tr["napply"], "applies_backward": btr.get("napply"),
                    "forward_only_systems_per_s": B * world / (fwd_ms * 1e-3)},
         "roofline": _roofline(apply_bytes, avg, nl, "banded_mm_kernel (xk_banded_mm: A x and A^T x)", {
+            **_pmc_traffic("c3", B),
             "bicgstab_iteration": {"algorithmic_bytes": it_bytes, "achieved_GBps_forward":
                                    it_bytes * niter_f / (fwd_ms * 1e-3) / 1e9,
                                    "frac_forward": it_bytes * niter_f / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM,
@@ -238,7 +261,8 @@ def config_c4(args, dev, group, world, rank, fence):
                    "nfev": tr.get("nfev"), "niter": tr.get("niter"), "rank": r,
                    "host_syncs_forward": tr.get("host_syncs", tr.get("nfev")),
                    "Gm_mv_algorithmic_bytes_at_final_rank": 2 * r * L * s + 2 * L * s},
-        "roofline": _roofline(fcn_bytes, avg, nl, "dense_mm_rows<double,1> (xk_dense_mm: the evaluation's A_b y_b)"),
+        "roofline": _roofline(fcn_bytes, avg, nl, "dense_mm_rows<double,1> (xk_dense_mm: the evaluation's A_b y_b)",
+                              _pmc_traffic("c4", B)),
         "check": {"ok": bool(fn < 1e-6 * (B ** 0.5)), "fnorm_at_returned_root": fn,
                   "note": "the returned iterate is the one BEFORE the converged one (quirk Q1): |f| slightly above f_tol"},
         "step_ms": step_ms,

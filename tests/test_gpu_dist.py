@@ -46,6 +46,18 @@ def _worker(rank, world, port, results):
             out[overlap] = dict(niter=(tr_s["niter"], tr_f["niter"]), groups=tr_s["groups"],
                                 err=(ev_s - ev_f[lo:hi]).abs().max().item(), resid=R.abs().max().item(),
                                 hist=max(abs(a - b) for a, b in zip(tr_s["resid_history"], tr_f["resid_history"])))
+        # ---- (r05) uneven shards: 3 operators over 2 ranks = 2 + 1.  With overlap=True rank 0 could run two
+        # batch groups and rank 1 only one — one status all-reduce per group and iteration would pair up collectives of
+        # different steps (or hang).  The ranks agree on the number of groups before any group exists.
+        B3 = 3
+        l3, h3 = xd.shard_range(B3, world, rank)
+        tr_u, tr_uf = {}, {}
+        ev_uf, _ = davidson(xa.LinearOperator.m(mat[:B3].contiguous(), True), neig, "lowest", min_eps=1e-8, trace=tr_uf,
+                            overlap=False, V0=V0[:B3])
+        ev_u, _ = davidson(xa.LinearOperator.m(mat[l3:h3].contiguous(), True), neig, "lowest", min_eps=1e-8, trace=tr_u,
+                           overlap=True, process_group=dist.group.WORLD, V0=V0[l3:h3])
+        out["uneven"] = dict(niter=(tr_u["niter"], tr_uf["niter"]), groups=tr_u["groups"], local=h3 - l3,
+                             err=(ev_u - ev_uf[l3:h3]).abs().max().item())
         # ---- sharded Krylov solves and the sharded Broyden driver (same process group) ----------------
         from xitorch_amd.linalg import native_krylov as nk
         from xitorch_amd.optimize import native_root as nr
@@ -135,6 +147,8 @@ def test_sharded_davidson_two_ranks_one_gpu():
             assert r["groups"] == (2 if overlap else 1)
             assert r["err"] < 1e-10 * 160 and r["resid"] < 1e-7, r
             assert r["hist"] < 1e-6, r                           # the all-reduced residual IS the global one
+        r = results[rank]["uneven"]
+        assert r["groups"] == 1 and r["niter"][0] == r["niter"][1] and r["err"] < 1e-10 * 160, r
         for meth, r in results[rank]["krylov"].items():
             assert r["niter"][0] == r["niter"][1], (meth, r)      # global stopping / best-iterate decisions
             assert r["err"] < 1e-9, (meth, r)

@@ -36,6 +36,7 @@ constexpr int SW_TILE_LDS = SW_ROWS * SW_PITCH;  // 8704 B per wave
 constexpr int SW_XI_LDS = 16 * 64 * 4;           // the band's x_I in the column part's B-operand layout (4096 B)
 constexpr int SW_WAVE_LDS = SW_TILE_LDS;                         // 8704 B per wave
 constexpr int SW_NSUB = 8;                       // sub-tiles per strip
+constexpr long SW_QUEUE_ELEMS = 16;              // workspace elements kept for the queue of the resident launch (64 B, at the end)
 
 typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
 typedef float sw_f32x2 __attribute__((ext_vector_type(2)));
@@ -267,17 +268,35 @@ __host__ __device__ inline int sw7_tiles_of_sstrip(int S, int N, int TR) {
   return (int)((top + TR - 1) / TR);
 }
 
-template <int PRIO>
+// PERSIST (round 5, opts bit 2): `gridDim.x` resident workgroups (three per compute unit of the stream's CU mask) take the
+// super-tiles from a queue in global memory until it is empty, like the resident K1s launch (xk_symm.hip): the other batch
+// group's launch, on its own stream, moves into the slots this launch's tail frees.  Partial slots are indexed by the
+// super-tile, so which workgroup serves it does not enter the result.
+template <int PRIO, bool PERSIST>
 __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
     const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ rowP, float* __restrict__ colP,
-    int N, int pc, long lda, long sA, long ldx, long sX, int NSS, int NT, int TR, int tiles_per_op) {
+    int N, int pc, long lda, long sA, long ldx, long sX, int NSS, int NT, int TR, int tiles_per_op,
+    unsigned* __restrict__ queue, int nitems) {
   typedef float T;
   constexpr int SEG = 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_next[2];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / tiles_per_op));
-  int ti = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - (unsigned)b * tiles_per_op));
+  int item = blockIdx.x, par = 0;
+  if (PERSIST) {
+    if (threadIdx.x == 0) s_next[1] = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(s_next[1]);
+  }
+#pragma unroll 1
+  for (;;) {
+  if (PERSIST) {
+    if (item >= nitems) break;
+    if (threadIdx.x == 0) s_next[par] = (int)atomicAdd(queue, 1u);     // the super-tile after this one
+  }
+  const int b = __builtin_amdgcn_readfirstlane((int)((unsigned)item / (unsigned)tiles_per_op));
+  int ti = __builtin_amdgcn_readfirstlane((int)((unsigned)item - (unsigned)b * tiles_per_op));
   // strip-major: consecutive workgroups walk down one 512-column super-strip (row-tile-major order — the workgroups in
   // flight covering whole matrix rows — measured the same: profiles/r04_k1sw_coop_pmc_probe.json)
   int S = 0;
@@ -438,6 +457,11 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
       }
     }
   }
+  if (!PERSIST) break;
+  __syncthreads();                                             // s_next[par] is visible; LDS tiles are free again
+  item = __builtin_amdgcn_readfirstlane(s_next[par]);
+  par ^= 1;
+  }
 }
 
 // Y[b][c][n] = sum of the row partials of the strips that hold row n (strip n / WS and every strip right of it) and of
@@ -499,9 +523,29 @@ static int symm_wide(const float* A, const float* X, float* Y, float* ws, long w
       int tiles = 0;
       for (int S = 0; S < NSS; ++S) tiles += sw7_tiles_of_sstrip(S, N, TR);
       const size_t lds = 4 * (size_t)SW_TILE_LDS;
-      auto kern = (opts & 2) ? dense_symm_wide7_kernel<1> : dense_symm_wide7_kernel<0>;
-      hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * tiles)), dim3(256), lds, st, A, X, rowP, colP, N, P, lda, sA,
-                         ldx, sX, NSS, NT, TR, tiles);
+      const long nitems_l = (long)B * tiles;
+      if (nitems_l > 0x7fffffffL) return XK_ERR_UNSUPPORTED;
+      const int nitems = (int)nitems_l;
+      if (opts & 4) {
+        // resident launch: queue word in the last 64 bytes of the workspace, reset in stream order before the launch
+        if (ws_elems < nrow + ncol + SW_QUEUE_ELEMS) return XK_ERR_ARG;
+        unsigned* queue = reinterpret_cast<unsigned*>(ws + (ws_elems - SW_QUEUE_ELEMS));
+        int nslots = (opts >> 16) & 0xfff;
+        if (nslots == 0) {
+          int dev = 0, cus = 256;
+          if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          nslots = 3 * (cus > 0 ? cus : 256);
+        }
+        hipError_t me = hipMemsetAsync(queue, 0, 64, st);
+        if (me != hipSuccess) return (int)me;
+        auto kern = (opts & 2) ? dense_symm_wide7_kernel<1, true> : dense_symm_wide7_kernel<0, true>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nitems < nslots ? nitems : nslots)), dim3(256), lds, st, A, X, rowP, colP,
+                           N, P, lda, sA, ldx, sX, NSS, NT, TR, tiles, queue, nitems);
+      } else {
+        auto kern = (opts & 2) ? dense_symm_wide7_kernel<1, false> : dense_symm_wide7_kernel<0, false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nitems), dim3(256), lds, st, A, X, rowP, colP, N, P, lda, sA,
+                           ldx, sX, NSS, NT, TR, tiles, (unsigned*)nullptr, nitems);
+      }
       XK_LAUNCH_CHECK();
     }
     if (phase != 1) {
@@ -551,12 +595,12 @@ long xk_dense_symm_wide_workspace_elems(int B, int N) {
   constexpr int WS = xk::SW_NSUB * (xk::SW_SEG_BYTES / 4);
   const int TR = xk::symm_wide_tr(N);
   const long NS = (N + WS - 1) / WS, NT = (N + TR - 1) / TR;
-  return (long)B * (NS + NT) * 16 * N;
+  return (long)B * (NS + NT) * 16 * N + xk::SW_QUEUE_ELEMS;     // + the queue of the resident launch (last 64 bytes)
 }
 
 int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
                            long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream) {
-  if (B < 0 || N < 0 || opts < 0 || opts > 3) return XK_ERR_ARG;
+  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfffc) > 4 || opts > 0x0fffffff || ((opts & 4) && !(opts & 1))) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
   return xk::symm_wide(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, opts, 0, (hipStream_t)stream);
 }
@@ -565,14 +609,14 @@ int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, 
 // fold on the group's own stream); `ws` must stay untouched in between
 int xk_dense_symm_wide_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
                                  long lda, long sA, long ldx, long sX, int opts, void* stream) {
-  if (B < 0 || N < 0 || opts < 0 || opts > 3) return XK_ERR_ARG;
+  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfffc) > 4 || opts > 0x0fffffff || ((opts & 4) && !(opts & 1))) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
   return xk::symm_wide(A, X, nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, opts, 1, (hipStream_t)stream);
 }
 
 int xk_dense_symm_wide_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
                                 int opts, void* stream) {
-  if (B < 0 || N < 0 || opts < 0 || opts > 3) return XK_ERR_ARG;
+  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfffc) > 4 || opts > 0x0fffffff || ((opts & 4) && !(opts & 1))) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
   return xk::symm_wide((const float*)ws, (const float*)ws, Y, (float*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, opts,
                        2, (hipStream_t)stream);

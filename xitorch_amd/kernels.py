@@ -224,11 +224,11 @@ def panel_transform(Tp, W, P):
 
 
 # --------------------------------------------------------------------------- Davidson chain (one C call per stage)
-def davidson_ritz(V, AV, Y, lam, X, Tn, rmax, info, flag, status, k, P, cond=None, orth=None, n_true=None):
+def davidson_ritz(V, AV, Y, lam, X, Tn, rmax, info, flag, status, k, P, cond=None, orth=None):
     """ritz_residual + (guard of the Ritz block) + group status in one C call (xk_davidson_ritz): X = Y^T V,
     Tn = -(Y^T AV - lam X), status = {max|resid| (NaN-propagating), max info, max flag[, max cond[, max orth]]}; rmax
     (and cond, orth) are left zeroed for the next step (symeig.py:178-197).  orth (B,): switches the a-posteriori guard
-    on (see `ritz_guard`; n_true = the unpadded vector length)."""
+    on (see `ritz_guard`)."""
     B, N = V.shape[0], V.shape[2]
     if lam.stride(-1) != 1 and P > 1:
         raise _capi.NativeLibraryError("lam must have unit stride along its last dim")
@@ -629,7 +629,7 @@ def k1s_auto_opts(B, N, dtype, cus, pipelined=False):
         group's launch, on its own stream, move into the slots the tail frees (217.6 -> 211.9 ms per configs[1] call);
       * fp64: 8-wave workgroups on 2048 x 2048 tiles (half the partial-sum bytes written and folded) once the launch has
         enough of them: a tile is 32 MB, so alone on the GPU it needs ~8 per compute unit to beat the 4-wave form
-        (64 x 16384^2: 10.91 vs 11.31 ms; 32 x 16384^2: 5.55 vs 5.45), inside the pipeline — tails overlapped — about 4
+        (64 x 16384^2: 10.91 vs 11.31 ms; 32 x 16384^2: 5.55 vs 5.45), inside the pipeline — tails overlapped — about 2
         (32 operators per launch: 216.7 -> 209.9 ms per call)."""
     if B <= 0 or N <= 0:
         return 0
@@ -637,10 +637,13 @@ def k1s_auto_opts(B, N, dtype, cus, pipelined=False):
     slab = 1024 if f64 else 2048
     ns = (N + slab - 1) // slab
     runs4 = B * sum(ns - (i * 1024) // slab for i in range((N + 1023) // 1024))
-    o = K1S_PERSIST if runs4 >= 4 * cus else 0
+    # (inside the pipeline a launch of 8 operators of order 16384 — 1088 runs, 1.4 ms — is shorter than the other group's
+    #  chain: nothing to overlap, the resident form costs 0.5 %; 16 operators: 112.0 -> 108.9 ms per call)
+    o = K1S_PERSIST if runs4 >= (8 if pipelined else 4) * cus else 0
     if f64 and (o & K1S_PERSIST):
         n8 = (N + 2047) // 2048
-        if B * n8 * (n8 + 1) // 2 >= (4 if pipelined else 8) * cus:
+        # (pipelined, 16 operators per launch = 576 tiles on 192-224 units: 108.8 -> 107.6 ms per call)
+        if B * n8 * (n8 + 1) // 2 >= (2 if pipelined else 8) * cus:
             o |= K1S_WIDE8
     return o
 

@@ -378,7 +378,9 @@ class _Group:
         self.info.zero_()
         self.cond.zero_()
         self.orth.zero_()
-        self.best_slot, self.best_evals = -1, None
+        # (the best iterate so far stays: it passed the guard when it was recorded, and its block lives in the X buffer
+        #  the void step did not write — a roll-back on the last allowed iteration still returns it, like the reference
+        #  returns its best iterate with a ConvergenceWarning, symeig.py:196-200)
         self.reorthonormalise(k_good)
 
     def reorthonormalise(self, k):
@@ -738,6 +740,13 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         wide_symm = whole.kind == "dense" and whole.symm and dtype == torch.float32 and \
             K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and N >= K.SYMM_WIDE_MIN_N and N % 64 == 0
         reserve_cus = 32 if wide_symm else 64
+        # resident K1s launches of the two groups on two streams (below): the panel stream gains more from 32 further
+        # units than the chain loses (configs[1]: 211.4 ms per call with 64 left to the chain, 209.9 with 48, 206.7 with
+        # 32, 211.6 with 16 — profiles/r05_k1s_pipeline_ab.jsonl)
+        if can_two and K.K1S_OPTS is None and whole.kind == "dense" and whole.symm and whole.symm_narrow and p <= 6:
+            total_cus = torch.cuda.get_device_properties(device).multi_processor_count
+            if K.k1s_auto_opts(B // ngrp, N, dtype, max(1, total_cus - 32), pipelined=True) & K.K1S_PERSIST:
+                reserve_cus = 32
     if two:
         try:
             grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
@@ -930,7 +939,6 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
             for g in range(G):
                 with torch.cuda.stream(streams[g]):
                     groups[g].rollback(k_good, 2 + len(redo) - 1)
-            best_resid = float("inf")
             history.append(max_resid)
             if verbose:
                 print("Iter %3d (guess size: %d): guard %.2e: back to %d vectors" % (it + 1, k_rr, guard, k_good))
