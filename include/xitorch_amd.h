@@ -79,11 +79,18 @@ int xk_dense_mm_f32(const float* A, const float* X, float* Y, float* ws, long ws
 long xk_dense_symm_workspace_elems(int B, int N, int P, int elem_size);
 /* Results are run-to-run bit-identical: the four waves of a workgroup add into the LDS row accumulator in a fixed
  * order (phase rotation with barriers), partial slots are folded in a fixed order.
- * opts (measurements; 0 = the shipped behaviour; results do not depend on it): bit 0 plain instead of non-temporal
- * stores of the row / column partials, bit 1 plain instead of non-temporal loads in the fold, bits 8..15 column slabs
- * per workgroup run (0 = 1; row partials per row tile = ceil(slabs / run), at most 64); bit 2: 512-row tiles (fp64),
- * bit 3: 1024-row tiles — without either the library picks 512 rows for fp64 launches of fewer than 2200 workgroups
- * (<= 16 operators of order 16384: +1 %). */
+ * opts (results never depend on the launch shape chosen through it, only — for bits 5, 8..15 and 2/3 — on the fixed
+ * summation order of the partial slots): bit 0 plain instead of non-temporal stores of the row / column partials, bit 1
+ * plain instead of non-temporal loads in the fold, bits 8..15 column slabs per workgroup run (0 = 1; row partials per row
+ * tile = ceil(slabs / run), at most 64); bit 2: 512-row tiles (fp64), bit 3: 1024-row tiles — without either the library
+ * picks 512 rows for fp64 launches of fewer than 2200 workgroups (<= 16 operators of order 16384: +1 %);
+ * bit 4 (round 5): RESIDENT launch — bits 16..27 workgroups (0 = two per compute unit of the device) take the runs from a
+ * queue (the last 64 bytes of `ws`, reset by the call in stream order) until it is empty: bit-identical to the
+ * one-workgroup-per-run launch; a second resident launch on another stream moves into the slots this one's tail frees
+ * (the eigensolver's two batch groups: 217.6 -> 211.9 ms per BASELINE configs[1] call);
+ * bit 5 (round 5, fp64 only): 8-wave workgroups on 2048 x 2048 tiles, one workgroup per compute unit (with bit 4: half
+ * the bits-16..27 count) — half the partial-sum bytes; worth it from ~8 tiles per compute unit alone on the device, ~2
+ * inside the pipeline (-> 206.7 ms).  The Python host picks bits 4 / 5 per launch (xitorch_amd.kernels.k1s_auto_opts). */
 int xk_dense_symm_f64(const double* A, const double* X, double* Y, double* ws, long ws_elems, int B,
                       int N, int P, long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream);
 int xk_dense_symm_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N,
@@ -111,7 +118,9 @@ int xk_dense_symm_fold_f32(float* Y, const float* ws, long ws_elems, int B, int 
  * eigensolver's two-group pipeline), `ws` untouched in between.  opts: 0 = one wave per tile (above); 1 = the
  * workgroup-cooperative form (three waves per SIMD, four 128-column strips per workgroup sharing their row sums
  * through LDS; + 2 = raised wave priority around its MFMA block; 3 is what the Python host passes: 3.58 ms against 3.97 ms
- * for 8 x 32768^2, profiles/r04_k1sw_forms.jsonl).  _tiles and _fold of one product take the same opts. */
+ * for 8 x 32768^2, profiles/r04_k1sw_forms.jsonl); + 4 (round 5, with 1): resident launch — bits 16..27 workgroups (0 =
+ * three per compute unit) take the super-tiles from a queue in the last 64 bytes of `ws` (reset by the call), bit-identical
+ * to opts 1 / 3.  _tiles and _fold of one product take the same opts. */
 long xk_dense_symm_wide_workspace_elems(int B, int N);
 int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
                            long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream);

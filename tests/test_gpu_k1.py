@@ -544,3 +544,23 @@ def test_dense_symm_wide_mfma_vs_oracle(dev, B, N, P, form, monkeypatch):
     op.apply_on(Xp, out2, side)
     torch.cuda.synchronize()
     assert torch.equal(out2[:, :, :N], Y)
+
+
+@pytest.mark.parametrize("B,N,P", [(2, 2048, 16), (1, 4096, 9), (3, 1088, 12)])
+def test_dense_symm_wide_resident_launch_is_bit_identical(dev, B, N, P, monkeypatch):
+    """(r05) the resident form of the cooperative K1sw launch (opts bit 2: workgroups take the super-tiles from a queue,
+    three per compute unit) gives the bits of the one-workgroup-per-super-tile launch, repeatedly (the queue word is
+    reset by every launch)."""
+    g = torch.Generator().manual_seed(13 * N + P)
+    R = torch.randn(B, N, N, dtype=torch.float32, generator=g)
+    A = (R + R.transpose(-2, -1)).to(dev)
+    X = torch.randn(B, P, N, dtype=torch.float32, generator=g).to(dev)
+    monkeypatch.setattr(K, "K1SW_OPTS", 3)
+    monkeypatch.setattr(K, "K1SW_RESIDENT", False)
+    Y0 = K.dense_symm_wide(A, X).clone()
+    ref = torch.matmul(X.double().cpu(), A.double().cpu())
+    assert (Y0.cpu().double() - ref).abs().max().item() <= 3e-6 * N ** 0.5 * ref.abs().max().item()
+    monkeypatch.setattr(K, "K1SW_RESIDENT", True)
+    for rep in range(3):
+        assert torch.equal(K.dense_symm_wide(A, X), Y0), "resident K1sw launch differs (repetition %d)" % rep
+    torch.cuda.synchronize()

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
   constexpr int SEG = 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_next[2];
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int item = blockIdx.x, par = 0;
   if (PERSIST) {
@@ -295,6 +295,10 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
     if (item >= nitems) break;
     if (threadIdx.x == 0) s_next[par] = (int)atomicAdd(queue, 1u);     // the super-tile after this one
   }
+  // (the kernel has 168 registers for three waves per SIMD: everything derived from the lane index is rebuilt per
+  //  super-tile instead of living across the queue loop — hoisted, it spilled 9 registers)
+  int lane = lane0;
+  if (PERSIST) asm volatile("" : "+v"(lane));
   const int b = __builtin_amdgcn_readfirstlane((int)((unsigned)item / (unsigned)tiles_per_op));
   int ti = __builtin_amdgcn_readfirstlane((int)((unsigned)item - (unsigned)b * tiles_per_op));
   // strip-major: consecutive workgroups walk down one 512-column super-strip (row-tile-major order — the workgroups in

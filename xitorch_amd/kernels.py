@@ -691,6 +691,24 @@ def dense_symm(A, X, out=None, opts=None):
 SYMM_WIDE_MIN_P, SYMM_WIDE_MAX_P = 9, 16
 SYMM_WIDE_MIN_N = 1024        # below this the tiles are too few to fill the chip: K1w / K1s serve
 K1SW_OPTS = 3                 # bit 0: workgroup-cooperative form (3 waves per SIMD), bit 1: s_setprio around its MFMA block; 0: one wave per tile (include/xitorch_amd.h)
+K1SW_PERSIST = 4              # bit 2 (with bit 0): resident workgroups taking super-tiles from a queue, three per compute unit
+K1SW_RESIDENT = "auto"        # "auto": resident launches inside the eigensolver's two-group pipeline when the launch has
+                              # >= 4 rounds of workgroups; True / False force it (measurements)
+
+
+def _k1sw_opts(stream, B, N, pipelined=False):
+    o = int(K1SW_OPTS)
+    if not (o & 1):
+        return o
+    cus = stream_cus(stream)
+    tr = 1024 if N >= 8192 else (512 if N >= 2048 else 256)
+    tiles = B * (N // 512 + 1) * (N // 512 + 2) // 2 * 512 // tr
+    want = K1SW_RESIDENT
+    if want == "auto":
+        want = pipelined and tiles >= 4 * 3 * cus
+    if want:
+        o |= K1SW_PERSIST | (min(0xfff, 3 * cus) << 16)
+    return o
 
 
 def symm_wide_ok(A, X):
@@ -729,7 +747,7 @@ def dense_symm_wide(A, X, out=None):
     B, P, N, lda, sA, ldx, sX, ldy, sY, nws = _symm_wide_args(A, X, out)
     ws = _workspace(nws, X.dtype, X.device)
     rc = fn("xk_dense_symm_wide_f32")(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, ldy, sY,
-                                      K1SW_OPTS, stream_ptr())
+                                      _k1sw_opts(torch.cuda.current_stream(), B, N), stream_ptr())
     check(rc, "xk_dense_symm_wide")
     return out
 
@@ -745,19 +763,20 @@ def dense_symm_wide_split(A, X, out, tiles_stream, timed=False):
     ready, done = sync_events(cur)
     ready.record(cur)
     e0 = e1 = None
+    wopts = _k1sw_opts(tiles_stream, B, N, pipelined=True)
     with torch.cuda.stream(tiles_stream):
         tiles_stream.wait_event(ready)
         if timed:
             e0, e1 = timing_event_pair()
             e0.record(tiles_stream)
-        rc = fn("xk_dense_symm_wide_tiles_f32")(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, K1SW_OPTS,
+        rc = fn("xk_dense_symm_wide_tiles_f32")(ptr(A), ptr(X), ptr(ws), nws, B, N, P, lda, sA, ldx, sX, wopts,
                                                 stream_ptr())
         check(rc, "xk_dense_symm_wide_tiles")
         if timed:
             e1.record(tiles_stream)
         done.record(tiles_stream)
     cur.wait_event(done)
-    rc = fn("xk_dense_symm_wide_fold_f32")(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, K1SW_OPTS, stream_ptr())
+    rc = fn("xk_dense_symm_wide_fold_f32")(ptr(out), ptr(ws), nws, B, N, P, ldy, sY, wopts, stream_ptr())
     check(rc, "xk_dense_symm_wide_fold")
     return e0, e1
 

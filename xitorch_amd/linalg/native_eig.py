@@ -765,6 +765,11 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
                     and whole.symm_narrow and p <= 6
             else:
                 split_k1 = bool(k1_streams_opt)
+            if k1_streams_opt == "auto" and not split_k1 and whole.kind == "dense" and whole.symm and \
+                    dtype == torch.float32 and K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and \
+                    N >= K.SYMM_WIDE_MIN_N and N % 64 == 0:
+                # K1sw (fp32, 9 .. 16 columns): the same, when its launches are resident (kernels._k1sw_opts)
+                split_k1 = bool(K._k1sw_opts(k1_stream, B // ngrp, N, pipelined=True) & K.K1SW_PERSIST)
             if split_k1:
                 k1_streams = [K.masked_stream(device, reserve_cus, slot=64 + g) for g in range(ngrp)]
         except NativeLibraryError as err:            # no CU-mask support: same kernels, one group, one stream
