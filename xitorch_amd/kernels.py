@@ -692,8 +692,11 @@ SYMM_WIDE_MIN_P, SYMM_WIDE_MAX_P = 9, 16
 SYMM_WIDE_MIN_N = 1024        # below this the tiles are too few to fill the chip: K1w / K1s serve
 K1SW_OPTS = 3                 # bit 0: workgroup-cooperative form (3 waves per SIMD), bit 1: s_setprio around its MFMA block; 0: one wave per tile (include/xitorch_amd.h)
 K1SW_PERSIST = 4              # bit 2 (with bit 0): resident workgroups taking super-tiles from a queue, three per compute unit
-K1SW_RESIDENT = "auto"        # "auto": resident launches inside the eigensolver's two-group pipeline when the launch has
-                              # >= 4 rounds of workgroups; True / False force it (measurements)
+K1SW_RESIDENT = False         # False (shipped): one workgroup per super-tile.  True / "auto" (inside the two-group pipeline, from
+                              # 4 rounds of workgroups): resident launches + one panel stream per group — measured on the
+                              # configs[4] shard (profiles/r05_k1sw_pipeline_ab.jsonl): the resident kernel is 3.7 % slower
+                              # per launch (4.32 vs 4.17 ms on one stream: issue-bound, 672 workgroups starting in lock step),
+                              # two streams win that back (4.20) and the call stays 106.6 -> 109.6 ms: not shipped
 
 
 def _k1sw_opts(stream, B, N, pipelined=False):
