@@ -1,6 +1,6 @@
 """K1s inside the eigensolver's two-group pipeline, A/B in ONE process on ONE resident operator batch (r05).
    python scripts/k1s_pipeline_ab.py [--batch 64] [--n 16384] [--steps 4] [--reps 2] name=opts:streams[:reserve] ...
-`opts` = low 16 bits of the K1s `opts` argument (include/xitorch_amd.h; 16 = resident launch, + run << 8), `streams` =
+name=opts:streams[:reserve[:early:kswitch]] — `opts` = low 16 bits of the K1s `opts` argument (include/xitorch_amd.h; 16 = resident launch, + run << 8), `streams` =
 1 (both groups' panel products on one CU-masked stream) or 2 (one stream each), `reserve` = compute units left to the
 other group's chain (default: the solver's auto).  Repetitions of all variants are interleaved; one JSON line per
 variant: median ms per symeig call, completion periods of the panel launches (bench.py's definition), eigenvalue error.
@@ -40,7 +40,8 @@ def parse(spec):
     f = rest.split(":")
     return {"name": name, "opts": None if f[0] == "auto" else int(f[0]),
             "streams": ("auto" if f[1] == "auto" else int(f[1])) if len(f) > 1 else 1,
-            "reserve": int(f[2]) if len(f) > 2 else "auto"}
+            "reserve": int(f[2]) if len(f) > 2 else "auto",
+            "early": (int(f[3]), int(f[4])) if len(f) > 4 else None}     # (reserved CUs, basis width) of the early phase
 
 
 variants = [parse(v) for v in args.variants]
@@ -52,7 +53,7 @@ def call(v, events):
     tr = {"k1_events": events}
     with torch.no_grad():
         ev, _ = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, v_init="randn", rng_device="device",
-                       max_niter=200, reserve_cus=v["reserve"],
+                       max_niter=200, reserve_cus=v["reserve"], reserve_early=v["early"],
                        k1_streams=("auto" if v["streams"] == "auto" else v["streams"] == 2), trace=tr)
     return ev, tr
 
@@ -84,7 +85,7 @@ for v in variants:
     per = r["periods"]
     avg = sum(per) / len(per)
     print(json.dumps({"variant": v["name"], "opts": v["opts"], "k1_streams": v["streams"], "reserve_cus": v["reserve"],
-                      "batch": B, "N": N, "ms_per_call_median": round(ms, 2), "ms_per_call_all": [round(t, 2) for t in r["ms"]],
+                      "reserve_early": v["early"], "batch": B, "N": N, "ms_per_call_median": round(ms, 2), "ms_per_call_all": [round(t, 2) for t in r["ms"]],
                       "k1_launches": len(per), "k1_period_avg_ms": round(avg * 1e3, 4),
                       "k1_period_p10_p50_p90_ms": [round(bench._pct(per, q) * 1e3, 3) for q in (0.1, 0.5, 0.9)],
                       "k1_own_interval_avg_ms": round(sum(r["raw"]) / len(r["raw"]) * 1e3, 4),

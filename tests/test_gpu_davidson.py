@@ -617,6 +617,37 @@ def test_unrestarted_run_beyond_128_vectors_stays_native(dev, monkeypatch):
     assert (mat @ X - X * ev.unsqueeze(-2)).abs().max().item() <= 1e-7
 
 
+def test_unrestarted_run_to_900_vectors_makes_no_library_eigh_call(dev, monkeypatch):
+    """(r05) The reference's basis is unbounded until k == N (symeig.py:174,202).  An un-restarted run that
+    is stopped by max_niter at a basis of 900+ vectors (fp64: beyond the 768 of r04's native range) makes no
+    torch.linalg.eigh call, and its best iterate is a valid Ritz block: eigenvalues above the exact ones (Cauchy
+    interlacing), decreasing residual."""
+    from xitorch_amd import synthetic
+    import warnings
+    B, N, p = 2, 4096, 6
+    mat = synthetic.dense_symmetric(B, N, "S3", dtype=torch.float64, device=dev)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    calls = []
+    real_eigh = torch.linalg.eigh
+    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (calls.append(1), real_eigh(*a, **k))[1])
+    tr = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, X = davidson(A, p, "lowest", min_eps=1e-12, max_niter=152, trace=tr)
+    monkeypatch.undo()
+    assert tr["basis_size"] >= 900, tr["basis_size"]
+    assert not calls and tr["k3_fallbacks"] == 0, (len(calls), tr["k3_fallbacks"])
+    exact = synthetic.spectrum("S3", N, device=dev)[:p]
+    # (a 912-dimensional block Krylov space of a spectrum of width 4096 with unit gaps: far from converged, by design)
+    assert (ev - exact).min().item() >= -1e-9 and (ev - exact).abs().max().item() <= 0.5
+    G = X.transpose(-2, -1) @ X
+    assert (G - torch.eye(p, dtype=torch.float64, device=dev)).abs().max().item() <= 1e-9
+    hist = tr["resid_history"]
+    assert hist[-1] < hist[5]
+    R = mat @ X - X * ev.unsqueeze(-2)
+    assert abs(R.abs().max().item() - tr["best_resid"]) <= 1e-6 * max(1.0, tr["best_resid"])
+
+
 @pytest.mark.parametrize("N,p", [(900, 8), (900, 10), (2048, 12)])
 def test_default_orthonormalisation_survives_mixed_convergence(dev, N, p):
     """Regression (round 3): with some wanted pairs long converged and others (inside the dense part of the S1

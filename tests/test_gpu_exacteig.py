@@ -59,13 +59,25 @@ def test_native_partial_eigh_sizes_and_dtypes(dev, dtype, n, p, mode):
     assert R.abs().max().item() <= tol * 10
 
 
-def test_native_exacteig_falls_back_where_it_must(dev):
-    # orders beyond 768, complex Hermitian and CPU tensors take torch.linalg.eigh like the reference
+def test_native_exacteig_falls_back_where_it_must(dev, monkeypatch):
+    # orders beyond 1024, complex Hermitian and CPU tensors take torch.linalg.eigh like the reference; fp64 orders
+    # 769 .. 1024 are native since r05 (no library call in the forward pass)
     g = torch.Generator().manual_seed(1)
-    A = torch.randn(800, 800, dtype=torch.float64, generator=g)
+    A = torch.randn(1100, 1100, dtype=torch.float64, generator=g)
     A = (A + A.T) * 0.5
     ev, _ = symeig(xa.LinearOperator.m(A.to(dev), is_hermitian=True), neig=3)
     assert (ev.cpu() - torch.linalg.eigvalsh(A)[:3]).abs().max().item() <= 1e-10
+    for n in (800, 1000):
+        calls = []
+        real_eigh = torch.linalg.eigh
+        monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (calls.append(1), real_eigh(*a, **k))[1])
+        with torch.no_grad():
+            ev, X = symeig(xa.LinearOperator.m(A[:n, :n].contiguous().to(dev), is_hermitian=True), neig=3)
+        monkeypatch.undo()
+        assert not calls, "torch.linalg.eigh called at order %d" % n
+        assert (ev.cpu() - torch.linalg.eigvalsh(A[:n, :n])[:3]).abs().max().item() <= 1e-10
+        R = A[:n, :n].to(dev) @ X - X * ev.unsqueeze(-2)
+        assert R.abs().max().item() <= 1e-9
     C = torch.randn(40, 40, dtype=torch.complex128, generator=g)
     C = (C + C.conj().T) * 0.5
     ev, _ = symeig(xa.LinearOperator.m(C.to(dev), is_hermitian=True), neig=3)

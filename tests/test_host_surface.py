@@ -505,14 +505,15 @@ def test_davidson_orthonormalisation_pass_policy():
 
 def test_rayleigh_ritz_solver_limits_by_order_and_precision():
     """Host-side queries of K3g (no device needed): which orders the one-launch-per-step form and the two-stage form of
-    r04 serve — fp64 to 768 (the two-stage form inside it to 614: its band + bulges must fit 160 KB of LDS), fp32 to
-    1024 through the two-stage form — and that the workspace query covers the two-stage blocks
+    r04 serve — both precisions to 1024 (r05: fp64 beyond 768 on the one-launch-per-step form with 16 column slots; the
+    two-stage form to 614 in fp64, to 1024 in fp32: its band + bulges must fit 160 KB of LDS) — and that the workspace
+    query covers the two-stage blocks
     (torch.linalg.eigh of the whole T in the reference: xitorch/_impls/linalg/symeig.py:174-175)."""
     batch = _capi.fn("xk_small_eigh_big_batch")
     ws = _capi.fn("xk_small_eigh_big_workspace_elems")
-    for k in (8, 129, 614, 615, 768):
+    for k in (8, 129, 614, 615, 768, 769, 1024):
         assert batch(k, 6, 8) > 0, k
-    assert batch(769, 6, 8) == 0 and batch(1024, 6, 8) == 0          # fp64: the band of order > 614 does not fit the LDS
+    assert batch(1025, 6, 8) == 0
     for k in (8, 600, 768, 769, 1024):
         assert batch(k, 6, 4) > 0, k
     assert batch(1025, 6, 4) == 0 and batch(7, 6, 4) == 0

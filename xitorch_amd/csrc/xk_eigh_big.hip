@@ -430,8 +430,10 @@ __device__ __forceinline__ void step_load_rows(T (&sr)[RPT][NT], const T* __rest
   }
 }
 
-template <typename T, int NT, bool FIRST>
-__global__ __launch_bounds__(512) void tridiag_step_kernel(
+// LB: threads per workgroup the instantiation is built for.  16 column slots (orders 769 .. 1024, r05) keep 16 values per
+// lane in nine arrays (~330 registers in fp64): built for 256 threads = one wave per SIMD, which may use up to 512.
+template <typename T, int NT, bool FIRST, int LB = 512>
+__global__ __launch_bounds__(LB) void tridiag_step_kernel(
     const T* __restrict__ Tin, T* __restrict__ Sws, T* __restrict__ aux, long aux_stride, int n, int j, int W,
     long ldt, long sT, int skip) {
   constexpr int RPT = 2;
@@ -687,12 +689,14 @@ static int big_pick_w(int B, int k, int wg) {
 template <typename T, int NT>
 static void big_launch_step(const T* Tin, T* S, T* aux, long aux_stride, int B, int k, int j, int W, long ldt, long sT,
                             int nt, hipStream_t st) {
+  constexpr int LB = NT > 12 ? 256 : 512;
+  if (nt > LB) nt = LB;
   const size_t lds = (size_t)step_lds_elems(k, nt / 64) * sizeof(T);
   if (j < 0)
-    hipLaunchKernelGGL((tridiag_step_kernel<T, NT, true>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k, j,
-                       W, ldt, sT, XK_BIG_SKIP);
+    hipLaunchKernelGGL((tridiag_step_kernel<T, NT, true, LB>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k,
+                       j, W, ldt, sT, XK_BIG_SKIP);
   else
-    hipLaunchKernelGGL((tridiag_step_kernel<T, NT, false>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k,
+    hipLaunchKernelGGL((tridiag_step_kernel<T, NT, false, LB>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k,
                        j, W, ldt, sT, XK_BIG_SKIP);
 }
 
@@ -733,10 +737,12 @@ static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, 
     if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
     else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
     else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
-    else big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    else if (m2 <= 768) big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    else big_launch_step<T, 16>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
   }
   const int rc = k <= 512 ? big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st)
-                          : big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st);
+                 : k <= 768 ? big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st)
+                            : big_launch_final<T, 16>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st);
   if (rc != XK_OK) return rc;
   XK_LAUNCH_CHECK();
   return XK_OK;
@@ -748,9 +754,9 @@ extern "C" {
 /* the LU batch size (shifts factorised at a time) the kernel would use for order k, p pairs, or 0 when it does not
  * fit the 160 KiB of LDS at all (elem_size 8 / 4) */
 int xk_small_eigh_big_batch(int k, int p, int elem_size) {
-  // orders 769 .. 1024: only where the two-stage form serves (its band must fit the LDS: fp32)
-  if (k < 8 || p < 1 || p > xk::BIG_MAXP || p > k) return 0;
-  if (k > 768 && !(k <= 1024 && xk::band_supported(k, elem_size))) return 0;
+  // orders 769 .. 1024 (r05): the two-stage form where its band fits the LDS (fp32), else one launch per Householder step
+  // with 16 column slots
+  if (k < 8 || p < 1 || p > xk::BIG_MAXP || p > k || k > 1024) return 0;
   for (int pb = p; pb >= 1; --pb)
     if (xk::big_lds_elems(k, p, pb) * elem_size + 64 <= 160 * 1024) return pb;
   return 0;
@@ -770,7 +776,6 @@ long xk_small_eigh_big_workspace_elems(int B, int k, int wg) {
     if (B < 0 || k < 8 || k > 1024 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                  \
     if (wg < 0 || wg > 32 || (threads != 0 && threads != 256 && threads != 512)) return XK_ERR_ARG;           \
     if (algo < 0 || algo > 2) return XK_ERR_ARG;                                                              \
-    if (k > 768 && (algo == 1 || !xk::band_supported(k, (int)sizeof(T)))) return XK_ERR_UNSUPPORTED;          \
     if (B == 0) return XK_OK;                                                                                 \
     return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, wg,                      \
                           threads ? threads : 512, algo, (hipStream_t)stream);                                \

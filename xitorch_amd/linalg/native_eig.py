@@ -37,8 +37,8 @@ __all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend", "native_par
 
 _PRELAUNCH = True          # enqueue the next group's chain early (module attribute: measurement scripts flip it for A/B)
 # largest basis the global-memory Rayleigh-Ritz solver (K3g, tridiagonalisation spread over several workgroups per
-# matrix: xk_eigh_big.hip) serves before the library takes over (>= 16 matrices per group, fewer): its limit of 768
-K3G_MAX_K = [1024, 1024]      # (the library decides per dtype: 768 in fp64, 1024 in fp32 — small_eigh_big_ok)
+# matrix: xk_eigh_big.hip) serves before the library takes over (>= 16 matrices per group, fewer)
+K3G_MAX_K = [1024, 1024]      # (the library decides: small_eigh_big_ok)
 
 
 def take_eigpairs(evals, evecs, neig, mode):
@@ -105,6 +105,7 @@ class _Group:
         self._compress = None                     # (Yt (B, pk, k), lam_all (B, pk)) of a pending restart
         self.nrestart = 0
         self.k1_stream = None                     # two-group pipeline: the (CU-masked) stream of the panel products
+        self.k1_stream_early, self.k1_switch = None, 0   # (optional) a wider-masked stream while the basis is small
         self.pg = None                            # sharded runs: the process group whose ranks decide together
         self.timeline, self.tag = None, 0         # debugging: (tag, label, start event, end event) per phase
         self.B, self.N, self.Npad, self.p = B, N, Npad, p
@@ -230,7 +231,10 @@ class _Group:
             self.opA.apply(X, out)
             return
         n0 = len(self.opA.events) if (self.timeline is not None and self.opA.events is not None) else None
-        self.opA.apply_on(X, out, self.k1_stream)
+        k1s = self.k1_stream
+        if self.k1_stream_early is not None and self.k < self.k1_switch:
+            k1s = self.k1_stream_early          # small basis = light chain: the panel stream may take more of the chip
+        self.opA.apply_on(X, out, k1s)
         if n0 is not None and len(self.opA.events) > n0:            # timeline: the launch's own events
             e0, e1 = self.opA.events[-1][:2]
             self.timeline.append((self.tag, "k1", e0, e1))
@@ -277,7 +281,7 @@ class _Group:
         elif self.small_eigh in ("native", "tri") and not force_jacobi and \
                 (k > K.SMALL_EIGH_MAX_K or pk > K.SMALL_EIGH_MAX_P) and \
                 k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
-            # K3g: bases of 129 .. 768 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
+            # K3g: bases of 129 .. 1024 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
             # wanted pairs at any order (wide eigen-blocks, thick restarts that keep 2 neig > 16 vectors): the same
             # tridiagonalisation route with the matrix in global memory: from order 192 on (fp64 to 614) the two-stage
             # form (band by block reflectors, bulge chasing in LDS: xk_eigh_band.hip), else one launch per Householder
@@ -292,7 +296,7 @@ class _Group:
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)
         else:
-            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 64 pairs, > 768 (fp32: > 1024)
+            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 64 pairs, > 1024 vectors
             if due:
                 lk, Yk = take_eigpairs(lam_all, Y_all, pk, self.mode)
                 self._compress = (Yk.transpose(1, 2).contiguous(), lk.contiguous())
@@ -588,10 +592,144 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         return res
 
 
+class _Plan:
+    """What `_plan_groups` decides for one davidson call: how many batch groups, which streams."""
+    __slots__ = ("two", "ngrp", "reserve_cus", "spans", "ops", "streams", "k1_streams", "k1_early", "distributed")
+
+
+def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, reserve_cus, k1_streams_opt,
+                 reserve_early, process_group):
+    """The pipeline policy of one davidson call (no kernel is launched here): one batch group on the caller's stream,
+    or `ngrp` groups whose small-kernel chains run on their own hardware queues while their operator-panel products
+    go to CU-masked streams (see `_davidson`'s `overlap` / `groups` / `reserve_cus` / `k1_streams` options)."""
+    plan = _Plan()
+    nA = 1
+    for d in A.shape[:-2]:
+        nA *= d
+    # Two groups pay off when a half-batch panel product is long enough (>= ~1 ms) to hide the other half's
+    # small-kernel chain: "auto" switches them on from 8 GiB of operator storage (config 2: 137 GB).
+    can_two = M is None and whole.kind == "dense" and not whole.flip and nA == B and B >= 2 \
+        and not (precond is not None and not isinstance(precond, (str, torch.Tensor)))
+    big = B * N * N * (8 if dtype == torch.float64 else 4) >= 2 ** 33
+    two = can_two and (overlap is True or (overlap == "auto" and big))
+    ngrp = 2
+    if two:
+        if groups == "auto":
+            ngrp = 2
+        else:
+            ngrp = max(2, min(int(groups), B))
+    if reserve_cus == "auto":
+        wide_symm = whole.kind == "dense" and whole.symm and dtype == torch.float32 and \
+            K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and N >= K.SYMM_WIDE_MIN_N and N % 64 == 0
+        reserve_cus = 32 if wide_symm else 64
+        # resident K1s launches of the two groups on two streams (below): the panel stream gains more from 32 further
+        # units than the chain loses (configs[1]: 211.4 ms per call with 64 left to the chain, 209.9 with 48, 206.7 with
+        # 32, 211.6 with 16 — profiles/r05_k1s_pipeline_ab.jsonl)
+        if can_two and K.K1S_OPTS is None and whole.kind == "dense" and whole.symm and whole.symm_narrow and p <= 6:
+            total_cus = torch.cuda.get_device_properties(device).multi_processor_count
+            if K.k1s_auto_opts(B // ngrp, N, dtype, max(1, total_cus - 32), pipelined=True) & K.K1S_PERSIST:
+                reserve_cus = 32
+    grp_streams, k1_streams, k1_early = None, [None], None
+    if two:
+        try:
+            grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
+            k1_stream = K.masked_stream(device, reserve_cus)
+            # Resident K1s launches (kernels.K1S_PERSIST): every group's panel product gets its own CU-masked stream.
+            # A resident launch holds every workgroup slot of the masked units until its run queue is empty, so the
+            # next group's launch — already enqueued on its stream — moves into the slots the tail frees instead of
+            # waiting for the last workgroup (one stream: a kernel boundary per launch, the tail of a launch of 8.5
+            # workgroup rounds leaves slots idle).  One-workgroup-per-run launches on two streams would share the slots
+            # evenly and finish together: they stay on one stream.
+            k1_streams = [k1_stream] * ngrp
+            if k1_streams_opt == "auto":
+                k1o = K.K1S_OPTS if K.K1S_OPTS is not None else \
+                    K.k1s_auto_opts(B // ngrp, N, dtype, K.stream_cus(k1_stream), pipelined=True)
+                split_k1 = bool(k1o & K.K1S_PERSIST) and whole.kind == "dense" and whole.symm \
+                    and whole.symm_narrow and p <= 6
+            else:
+                split_k1 = bool(k1_streams_opt)
+            if k1_streams_opt == "auto" and not split_k1 and whole.kind == "dense" and whole.symm and \
+                    dtype == torch.float32 and K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and \
+                    N >= K.SYMM_WIDE_MIN_N and N % 64 == 0:
+                # K1sw (fp32, 9 .. 16 columns): the same, when its launches are resident (kernels._k1sw_opts)
+                split_k1 = bool(K._k1sw_opts(k1_stream, B // ngrp, N, pipelined=True) & K.K1SW_PERSIST)
+            if split_k1:
+                k1_streams = [K.masked_stream(device, reserve_cus, slot=64 + g) for g in range(ngrp)]
+                if reserve_early is not None and int(reserve_early[0]) != int(reserve_cus):
+                    k1_early = [K.masked_stream(device, int(reserve_early[0]), slot=64 + g) for g in range(ngrp)]
+        except NativeLibraryError as err:            # no CU-mask support: same kernels, one group, one stream
+            import warnings
+            warnings.warn("xitorch_amd davidson: CU-masked streams unavailable (%s); running one batch group" % err)
+            two = False
+    distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
+    if distributed:
+        # Sharded run: every batch group issues one status all-reduce per iteration (`_Group.small`), so the ranks must
+        # run the SAME number of groups.  What a rank would pick depends on its local shard (B >= 2, the 8 GiB
+        # threshold, whether CU-masked streams came up): the ranks agree on the minimum before any group exists.
+        g_local = ngrp if two else 1
+        g_all = torch.tensor([-float(g_local)], dtype=torch.float64, device=device)
+        # (through c10d: a one-off on the caller's stream is not worth a communicator of its own)
+        torch.distributed.all_reduce(g_all, op=torch.distributed.ReduceOp.MAX, group=process_group)
+        g_common = int(round(-g_all.item()))
+        if g_common < g_local:
+            if g_common <= 1:
+                two = False
+            else:
+                ngrp = g_common
+                grp_streams, k1_streams = grp_streams[:ngrp], k1_streams[:ngrp]
+                k1_early = k1_early[:ngrp] if k1_early is not None else None
+    if two:
+        cuts = [(B * g) // ngrp for g in range(ngrp + 1)]
+        spans = [(cuts[g], cuts[g + 1]) for g in range(ngrp)]
+        ops = [_PanelOperator(_sub_operator(A, B, N, b0, b1), [b1 - b0], b1 - b0, N) for (b0, b1) in spans]
+        cur = torch.cuda.current_stream()
+        # each group gets a stream with its own hardware queue (see kernels.masked_stream).  The caller's
+        # stream is not used for a group: it usually is the legacy null stream, which synchronises implicitly
+        # with every blocking stream and serialises the pipeline (measured: 280 instead of 224 ms)
+        streams = grp_streams
+        for st in streams + list(set(k1_streams)) + list(k1_early or []):
+            st.wait_stream(cur)
+    else:
+        spans, ops, streams, k1_streams, k1_early = [(0, B)], [whole], [torch.cuda.current_stream()], [None], None
+    plan.two, plan.ngrp, plan.reserve_cus, plan.spans, plan.ops, plan.streams = two, ngrp, reserve_cus, spans, ops, streams
+    plan.k1_streams, plan.k1_early, plan.distributed = k1_streams, k1_early, distributed
+    return plan
+
+
+def _preconditioner(precond, whole, M, bdims, B, N, dtype, device):
+    """(extension; the reference has none, symeig.py:206-207) the preconditioner of the new directions in the form the
+    groups take it: None, ("diag", diag A, diag M or None) or ("op", panel operator)."""
+    if precond is None:
+        return None
+    from xitorch_amd.linop import LinearOperator as _LinOp
+    if isinstance(precond, str):
+        if precond.lower() not in ("diag", "jacobi", "davidson"):
+            raise RuntimeError("Unknown davidson preconditioner: %s" % precond)
+        dA = whole.diagonal()
+        dM = _PanelOperator(M, bdims, B, N).diagonal() if M is not None else None
+        return ("diag", dA, dM)
+    if isinstance(precond, torch.Tensor):
+        if precond.shape[-1] != N:
+            raise RuntimeError("precond diagonal must have shape (*batch, %d), got %s" % (N, tuple(precond.shape)))
+        dA = precond.to(device=device, dtype=dtype).expand(*bdims, N).reshape(B, N).contiguous()
+        dM = _PanelOperator(M, bdims, B, N).diagonal() if M is not None else None
+        return ("diag", dA, dM)
+    if isinstance(precond, _LinOp):
+        return ("op", _PanelOperator(precond, bdims, B, N))
+    raise TypeError("precond must be None, 'diag', a tensor or a LinearOperator, got %s" % type(precond))
+
+
+def _pc_slice(pc_full, b0, b1):
+    if pc_full is None or pc_full[0] == "op":
+        return pc_full
+    cut = lambda t: None if t is None else (t if t.shape[0] == 1 else t[b0:b1])
+    return ("diag", cut(pc_full[1]), cut(pc_full[2]))
+
+
 def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
               min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
               rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus="auto", restart=None,
-              groups="auto", chain="calls", basis_capacity=None, k1_streams="auto", **unused):
+              groups="auto", chain="calls", basis_capacity=None, k1_streams="auto", reserve_early=None, **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -620,11 +758,11 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         (extension) ``"native"`` (default): the wanted eigenpairs of the Rayleigh–Ritz matrix come from native
         kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
         iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
-        flags a result; from 129 to 768 vectors (fp32: 1024), or 17 to 64 wanted / kept pairs at any order, the same
+        flags a result; from 129 to 1024 vectors, or 17 to 64 wanted / kept pairs at any order, the same
         route with the matrix in global memory (K3g: from order 192 on — fp64 to 614 — a two-stage reduction, band by
         block reflectors then bulge chasing in LDS; else one launch per Householder step over several workgroups per
         matrix; 3.5x / 2.4x the library at order 582, measured; fallback: the library);
-        ``torch.linalg.eigh`` beyond 768 (fp32: 1024) vectors or 64 pairs; ``"jacobi"`` / ``"tri"`` force one of
+        ``torch.linalg.eigh`` beyond 1024 vectors or 64 pairs; ``"jacobi"`` / ``"tri"`` force one of
         the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
@@ -690,7 +828,6 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         uses the all-reduced (MAX) residual, so all ranks iterate in lock step (RCCL over xGMI)
     """
     na = A.shape[-1]
-    k1_streams_opt = k1_streams
     if nguess is None:
         nguess = neig
     bdims = list(A.shape[:-2]) if M is None else bcast_shape(A.shape[:-2], M.shape[:-2])
@@ -719,122 +856,16 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         orth_passes = 2
     events = trace.get("k1_events") if trace is not None else None
 
-    # ---- batch groups: one, or two pipelined on two streams ---------------------------------
+    # ---- batch groups: one, or two pipelined on their own streams (policy: `_plan_groups`) --------------------------
     whole = _PanelOperator(A, bdims, B, N)
-    nA = 1
-    for d in A.shape[:-2]:
-        nA *= d
-    # Two groups pay off when a half-batch panel product is long enough (>= ~1 ms) to hide the other half's
-    # small-kernel chain: "auto" switches them on from 8 GiB of operator storage (config 2: 137 GB).
-    can_two = M is None and whole.kind == "dense" and not whole.flip and nA == B and B >= 2 \
-        and not (precond is not None and not isinstance(precond, (str, torch.Tensor)))
-    big = B * N * N * (8 if dtype == torch.float64 else 4) >= 2 ** 33
-    two = can_two and (overlap is True or (overlap == "auto" and big))
-    ngrp = 2
-    if two:
-        if groups == "auto":
-            ngrp = 2
-        else:
-            ngrp = max(2, min(int(groups), B))
-    if reserve_cus == "auto":
-        wide_symm = whole.kind == "dense" and whole.symm and dtype == torch.float32 and \
-            K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and N >= K.SYMM_WIDE_MIN_N and N % 64 == 0
-        reserve_cus = 32 if wide_symm else 64
-        # resident K1s launches of the two groups on two streams (below): the panel stream gains more from 32 further
-        # units than the chain loses (configs[1]: 211.4 ms per call with 64 left to the chain, 209.9 with 48, 206.7 with
-        # 32, 211.6 with 16 — profiles/r05_k1s_pipeline_ab.jsonl)
-        if can_two and K.K1S_OPTS is None and whole.kind == "dense" and whole.symm and whole.symm_narrow and p <= 6:
-            total_cus = torch.cuda.get_device_properties(device).multi_processor_count
-            if K.k1s_auto_opts(B // ngrp, N, dtype, max(1, total_cus - 32), pipelined=True) & K.K1S_PERSIST:
-                reserve_cus = 32
-    if two:
-        try:
-            grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
-            k1_stream = K.masked_stream(device, reserve_cus)
-            # Resident K1s launches (kernels.K1S_PERSIST): every group's panel product gets its own CU-masked stream.
-            # A resident launch holds every workgroup slot of the masked units until its run queue is empty, so the
-            # next group's launch — already enqueued on its stream — moves into the slots the tail frees instead of
-            # waiting for the last workgroup (one stream: a kernel boundary per launch, the tail of a launch of 8.5
-            # workgroup rounds leaves slots idle).  One-workgroup-per-run launches on two streams would share the slots
-            # evenly and finish together: they stay on one stream.
-            k1_streams = [k1_stream] * ngrp
-            if k1_streams_opt == "auto":
-                k1o = K.K1S_OPTS if K.K1S_OPTS is not None else \
-                    K.k1s_auto_opts(B // ngrp, N, dtype, K.stream_cus(k1_stream), pipelined=True)
-                split_k1 = bool(k1o & K.K1S_PERSIST) and whole.kind == "dense" and whole.symm \
-                    and whole.symm_narrow and p <= 6
-            else:
-                split_k1 = bool(k1_streams_opt)
-            if k1_streams_opt == "auto" and not split_k1 and whole.kind == "dense" and whole.symm and \
-                    dtype == torch.float32 and K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and \
-                    N >= K.SYMM_WIDE_MIN_N and N % 64 == 0:
-                # K1sw (fp32, 9 .. 16 columns): the same, when its launches are resident (kernels._k1sw_opts)
-                split_k1 = bool(K._k1sw_opts(k1_stream, B // ngrp, N, pipelined=True) & K.K1SW_PERSIST)
-            if split_k1:
-                k1_streams = [K.masked_stream(device, reserve_cus, slot=64 + g) for g in range(ngrp)]
-        except NativeLibraryError as err:            # no CU-mask support: same kernels, one group, one stream
-            import warnings
-            warnings.warn("xitorch_amd davidson: CU-masked streams unavailable (%s); running one batch group" % err)
-            two = False
-    distributed = process_group is not None and torch.distributed.get_world_size(process_group) > 1
-    if distributed:
-        # Sharded run: every batch group issues one status all-reduce per iteration (`_Group.small`), so the ranks must
-        # run the SAME number of groups.  What a rank would pick depends on its local shard (B >= 2, the 8 GiB
-        # threshold, whether CU-masked streams came up): the ranks agree on the minimum before any group exists.
-        g_local = ngrp if two else 1
-        g_all = torch.tensor([-float(g_local)], dtype=torch.float64, device=device)
-        # (through c10d: a one-off on the caller's stream is not worth a communicator of its own)
-        torch.distributed.all_reduce(g_all, op=torch.distributed.ReduceOp.MAX, group=process_group)
-        g_common = int(round(-g_all.item()))
-        if g_common < g_local:
-            if g_common <= 1:
-                two = False
-            else:
-                ngrp = g_common
-                grp_streams, k1_streams = grp_streams[:ngrp], k1_streams[:ngrp]
-    if two:
-        cuts = [(B * g) // ngrp for g in range(ngrp + 1)]
-        spans = [(cuts[g], cuts[g + 1]) for g in range(ngrp)]
-        ops = [_PanelOperator(_sub_operator(A, B, N, b0, b1), [b1 - b0], b1 - b0, N) for (b0, b1) in spans]
-        cur = torch.cuda.current_stream()
-        # each group gets a stream with its own hardware queue (see kernels.masked_stream).  The caller's
-        # stream is not used for a group: it usually is the legacy null stream, which synchronises implicitly
-        # with every blocking stream and serialises the pipeline (measured: 280 instead of 224 ms)
-        streams = grp_streams
-        for st in streams + list(set(k1_streams)):
-            st.wait_stream(cur)
-    else:
-        spans, ops, streams, k1_stream, k1_streams = [(0, B)], [whole], [torch.cuda.current_stream()], None, [None]
+    plan = _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, reserve_cus, k1_streams,
+                        reserve_early, process_group)
+    two, spans, ops, streams = plan.two, plan.spans, plan.ops, plan.streams
+    k1_streams, k1_early, distributed = plan.k1_streams, plan.k1_early, plan.distributed
     for op in ops:
         op.events = events                       # bench.py: per-launch HIP events of the panel product
     G = len(spans)
-
-    # ---- optional preconditioner of the new directions -----------------------------------------
-    pc_full = None
-    if precond is not None:
-        from xitorch_amd.linop import LinearOperator as _LinOp
-        if isinstance(precond, str):
-            if precond.lower() not in ("diag", "jacobi", "davidson"):
-                raise RuntimeError("Unknown davidson preconditioner: %s" % precond)
-            dA = whole.diagonal()
-            dM = _PanelOperator(M, bdims, B, N).diagonal() if M is not None else None
-            pc_full = ("diag", dA, dM)
-        elif isinstance(precond, torch.Tensor):
-            if precond.shape[-1] != N:
-                raise RuntimeError("precond diagonal must have shape (*batch, %d), got %s" % (N, tuple(precond.shape)))
-            dA = precond.to(device=device, dtype=dtype).expand(*bdims, N).reshape(B, N).contiguous()
-            dM = _PanelOperator(M, bdims, B, N).diagonal() if M is not None else None
-            pc_full = ("diag", dA, dM)
-        elif isinstance(precond, _LinOp):
-            pc_full = ("op", _PanelOperator(precond, bdims, B, N))
-        else:
-            raise TypeError("precond must be None, 'diag', a tensor or a LinearOperator, got %s" % type(precond))
-
-    def _pc_slice(b0, b1):
-        if pc_full is None or pc_full[0] == "op":
-            return pc_full
-        cut = lambda t: None if t is None else (t if t.shape[0] == 1 else t[b0:b1])
-        return ("diag", cut(pc_full[1]), cut(pc_full[2]))
+    pc_full = _preconditioner(precond, whole, M, bdims, B, N, dtype, device)
 
     V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device)       # (B, nguess, N)
     if two:
@@ -845,8 +876,10 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         with torch.cuda.stream(streams[g]):
             opM = _PanelOperator(M, bdims, B, N) if M is not None else None
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
-                         precond=_pc_slice(b0, b1), restart=restart, capacity=basis_capacity)
+                         precond=_pc_slice(pc_full, b0, b1), restart=restart, capacity=basis_capacity)
             grp.k1_stream = k1_streams[g]
+            if two and k1_early is not None:
+                grp.k1_stream_early, grp.k1_switch = k1_early[g], int(reserve_early[1])
             grp.adaptive = adaptive
             # (panels wider than 32 need the chunked orthonormalisation of xk_davidson_orth)
             grp.fast = (chain != "kernels") or p > 32 or nguess > 32
@@ -974,7 +1007,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         raise RuntimeError("xitorch_amd davidson: no finite residual was produced")
     if two:
         cur = torch.cuda.current_stream()
-        for st in streams + list(set(k1_streams)):
+        for st in streams + list(set(k1_streams)) + list(k1_early or []):
             cur.wait_stream(st)
         evals = torch.cat([grp.best_evals for grp in groups], dim=0)
         Xall = torch.cat([grp.Xbuf[grp.best_slot] for grp in groups], dim=0)
@@ -1012,7 +1045,7 @@ def _native_dense_ok(mat, neig):
 def native_partial_eigh(mat, neig, mode):
     """Lowest / uppermost ``neig`` eigenpairs of the dense symmetric matrices ``mat (*B, n, n)`` on the native HIP
     eigensolvers — Householder tridiagonalisation, bisection, inverse iteration, back-transformation: K3t (LDS-resident,
-    n <= 128, neig <= 16) or K3g (global-memory work matrix, n <= 768, neig <= 64).  Only the wanted pairs are computed
+    n <= 128, neig <= 16) or K3g (global-memory work matrix, n <= 1024, neig <= 64).  Only the wanted pairs are computed
     (the reference's exacteig computes all n and slices, symeig.py:22-24,255-264).  Returns ``evals (*B, neig)``
     ascending and ``evecs (*B, n, neig)``; members whose self-check flags the result are redone on
     ``torch.linalg.eigh``."""
@@ -1068,7 +1101,7 @@ class _NativeEigh(torch.autograd.Function):
 
 def exacteig(A, neig, mode, M=None):
     """Eigendecomposition by building the full matrix (reference: exacteig, symeig.py:11-44).  On a HIP device, for real
-    matrices of order 8 .. 768 and up to 64 wanted pairs — the reference's own benchmark shapes, n in {100, 350, 700} with
+    matrices of order 8 .. 1024 and up to 64 wanted pairs — the reference's own benchmark shapes, n in {100, 350, 700} with
     neig = 10 (benchmarks/benchmarks_solve.py:37-59) — the eigenpairs come from the native dense eigensolver
     (`native_partial_eigh`: only the wanted pairs are computed); everything else (CPU tensors, complex Hermitian, larger
     orders) is `torch.linalg.eigh` like the reference.  Both carry the degeneracy-aware backward of degen_symeig."""
