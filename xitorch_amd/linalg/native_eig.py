@@ -592,6 +592,48 @@ def davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn",
         return res
 
 
+class _GuardPolicy:
+    """What the driver does with the a-posteriori check of every Rayleigh-Ritz block (`xk_ritz_guard`: max|X^T M X - I|,
+    read with the iteration's status): which steps are void, where a void step returns to, when the run gives up.
+    The same decisions on every group and rank (the values it sees are the folded / all-reduced ones)."""
+
+    def __init__(self, dtype, k_start):
+        self.good, self.bad = GUARD_GOOD[dtype], GUARD_BAD[dtype]
+        self.k_good = k_start                     # widest basis whose Ritz block passed `good` (None: none left)
+        self.history, self.redo = [], []
+        self._restarts = 0
+
+    def seen(self, guard, nrestart):
+        self.history.append(guard)
+        if nrestart != self._restarts:            # a thick restart rewrote the basis since the last step
+            self._restarts, self.k_good = nrestart, None
+
+    def void(self, chol_flag, guard):
+        return chol_flag != 0 or guard > self.bad
+
+    def roll_back(self, chol_flag, guard, k_rr, niter, trace):
+        """-> (basis width to return to, projection passes from now on); raises when nothing is left to return to"""
+        if self.k_good is None or self.k_good >= k_rr or len(self.redo) >= GUARD_MAX_REDO:
+            if chol_flag != 0 and not self.redo:
+                raise RuntimeError("xitorch_amd davidson: the panel Gram matrix is not positive definite "
+                                   "(linearly dependent guess/residual vectors)")
+            if trace is not None:
+                trace.update(niter=niter, orth_redo=self.redo, orth_guard_history=self.history)
+            raise _GuardFailure("the Ritz block lost its orthonormality (max|X^T M X - I| = %.2e at iteration %d, "
+                                "basis of %d vectors) and no earlier basis is left to return to" % (guard, niter, k_rr))
+        self.redo.append({"iter": niter, "guard": guard, "chol_flag": chol_flag, "k_from": k_rr, "k_to": self.k_good,
+                          "passes": 2 + len(self.redo)})
+        return self.k_good, 2 + len(self.redo) - 1
+
+    def passed(self, guard, k_rr):
+        """a block at or below `good` makes this basis width the new roll-back point; between `good` and `bad` the step
+        counts but the groups stop trusting one projection pass"""
+        if guard <= self.good:
+            self.k_good = k_rr
+            return True
+        return False
+
+
 class _Plan:
     """What `_plan_groups` decides for one davidson call: how many batch groups, which streams."""
     __slots__ = ("two", "ngrp", "reserve_cus", "spans", "ops", "streams", "k1_streams", "k1_early", "distributed")
@@ -766,9 +808,9 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
-        products of both groups run back to back on one stream whose CU mask leaves ``reserve_cus`` compute
-        units free, and the small Rayleigh–Ritz / orthogonalisation kernels of one group run on those CUs (own
-        hardware queue) underneath the panel product of the other.  Iteration counts and the stopping rule are
+        products of both groups run on streams whose CU mask leaves ``reserve_cus`` compute units free (one stream for
+        both, or one each: ``k1_streams``), and the small Rayleigh–Ritz / orthogonalisation kernels of one group run
+        on those CUs (own hardware queue) underneath the panel product of the other.  Iteration counts and the stopping rule are
         unchanged.  ``"auto"`` (default): on from 8 GiB of operator storage; ``True`` / ``False`` force it
     groups: str or int
         (extension) number of batch groups of the overlapped form.  ``"auto"`` (default): two.  More groups
@@ -777,11 +819,20 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         exposed the host is the limit: 8 operators of order 16384: 32.7 ms with 2 groups, 40.1 with 3, 52 with 4;
         16 operators: 56.6 vs 69.8 ms with 4 (r02).  An integer forces it (clamped to the batch size)
     reserve_cus: int or str
-        (extension) compute units the panel-product stream leaves to the small kernels.  ``"auto"`` (default): 64 of 256
-        for the HBM-bound panel kernels (as fast on 192 CUs as on all of them; whole 32-CU mask words measured best:
+        (extension) compute units the panel-product stream leaves to the small kernels.  ``"auto"`` (default): 32 with
+        resident K1s launches on per-group streams (r05: 211.4 ms per configs[1] call with 64, 209.9 with 48, 206.7 with
+        32, 211.6 with 16), else 64 of 256 for the HBM-bound panel kernels (as fast on 192 CUs as on all of them; whole 32-CU mask words measured best:
         224.2 ms per config-2 call with 64, 227.5 with 32, 233 with 48 or 8, 241 with 96), 32 when the panel product is
         K1sw (fp32, 9 .. 16 columns, symmetric storage: issue-bound on the matrix cores, it scales with the CUs it gets —
         configs[4] shard: 120.6 ms per call with 64, 109.5 with 32, 109.8 with 16 or 8)
+    k1_streams: str or bool
+        (extension, r05) ``"auto"`` (default): each batch group's operator-panel product runs on its OWN CU-masked stream
+        when its launches are resident (``kernels.k1s_auto_opts``: workgroups that take tile runs from a queue hold the
+        machine until the queue is empty, so the other group's launch fills the slots the tail frees: 217.6 -> 211.9 ms
+        per BASELINE configs[1] call); otherwise both groups share one masked stream.  ``True`` / ``False`` force it
+    reserve_early: tuple or None
+        (extension, measurement) ``(cus, k)``: while the basis holds fewer than ``k`` vectors the panel products run on
+        streams that leave only ``cus`` compute units to the other group's (then still light) chain
     chain: str
         (extension) ``"calls"`` (default): every stage between two operator-panel products (rotation + residual +
         status, orthonormalisation of the new block, extension of T) is enqueued by one C call
@@ -896,10 +947,8 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         grp.pg = process_group if distributed else None
     n_fallback = [0]
     cond_hist = [[] for _ in range(G)]            # squared pivot ratio of each group's panels (status[3]), as read
-    guard_good, guard_bad = GUARD_GOOD[dtype], GUARD_BAD[dtype]
-    guard_hist, redo = [], []
-    k_good = groups[0].k                          # roll-back point: the start block (CholeskyQR2)
-    n_restart_seen = 0
+    policy = _GuardPolicy(dtype, groups[0].k)     # roll-back point at the start: the start block (CholeskyQR2)
+    guard_hist, redo = policy.history, policy.redo
     for it in range(max_niter):
         niter = it + 1
         local_max, bad, guard = 0.0, 0.0, 0.0
@@ -956,34 +1005,21 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         # (sharded runs: every group's status was all-reduced on the device before the host read it — `_Group.small` —
         #  so the values folded above already are the global ones: no further exchange, no further host read)
         max_resid = local_max
-        guard_hist.append(guard)
-        if groups[0].nrestart != n_restart_seen:        # a thick restart rewrote the basis since the last step
-            n_restart_seen, k_good = groups[0].nrestart, None
-        if bad != 0 or guard > guard_bad:
+        policy.seen(guard, groups[0].nrestart)
+        if policy.void(bad, guard):
             # The basis lost its orthogonality (or a panel its rank).  The reference cannot get here: it
             # re-orthonormalises the whole basis every iteration (tallqr of [V, t], _utils/tensor.py:8-19,
             # symeig.py:207-223).  This step is void; every rank / group takes the same decision (the values are the
             # all-reduced ones), so the groups stay in lock step.
-            if k_good is None or k_good >= k_rr or len(redo) >= GUARD_MAX_REDO:
-                if bad != 0 and not redo:
-                    raise RuntimeError("xitorch_amd davidson: the panel Gram matrix is not positive definite "
-                                       "(linearly dependent guess/residual vectors)")
-                if trace is not None:
-                    trace.update(niter=niter, orth_redo=redo, orth_guard_history=guard_hist)
-                raise _GuardFailure("the Ritz block lost its orthonormality (max|X^T M X - I| = %.2e at iteration %d, "
-                                    "basis of %d vectors) and no earlier basis is left to return to" % (guard, niter, k_rr))
-            redo.append({"iter": niter, "guard": guard, "chol_flag": bad, "k_from": k_rr, "k_to": k_good,
-                         "passes": 2 + len(redo)})
+            k_to, passes = policy.roll_back(bad, guard, k_rr, niter, trace)
             for g in range(G):
                 with torch.cuda.stream(streams[g]):
-                    groups[g].rollback(k_good, 2 + len(redo) - 1)
+                    groups[g].rollback(k_to, passes)
             history.append(max_resid)
             if verbose:
-                print("Iter %3d (guess size: %d): guard %.2e: back to %d vectors" % (it + 1, k_rr, guard, k_good))
+                print("Iter %3d (guess size: %d): guard %.2e: back to %d vectors" % (it + 1, k_rr, guard, k_to))
             continue
-        if guard <= guard_good:
-            k_good = k_rr
-        else:
+        if not policy.passed(guard, k_rr):
             for grp in groups:
                 grp.distrust(it)
         history.append(max_resid)
