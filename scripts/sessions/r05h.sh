@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05h: L2 touch-ahead of the K1s ring (opts bit 6): bit identity, alone and inside the pipeline
+# r05h: TRIAL BUILD (kernel change not in the tree: git history of this session) — L2 touch-ahead of the K1s ring (opts bit 6): bit identity, alone and inside the pipeline
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r05h; mkdir -p $O
 python - <<'PY' 2>&1 | tail -3 | tee $O/identity.txt
