@@ -49,6 +49,12 @@ int xk_abi_version(void);
  * (bench.py: the practical streaming ceiling of the operator batch) */
 int xk_stream_read(const void* src, long bytes, long pitch_bytes, void* scratch, void* stream);
 int xk_stream_create_cu_masked(int device, int reserve_cus, void** stream_out);
+/* the same with the bits to clear chosen by `pattern`: 0 = the last reserve_cus bits of the linear mask (what
+ * xk_stream_create_cu_masked does), 1 = every (units / reserve_cus)-th bit */
+int xk_stream_create_cu_masked_pattern(int device, int reserve_cus, int pattern, void** stream_out);
+/* measurement utility: `workgroups` one-wave workgroups on `stream`, each spinning `spin_cycles`; hist16[x] = workgroups
+ * that ran on XCD x, units128[8 x + w] = bit set of the (SE, SH, CU) ids seen there (device memory, zeroed by the call) */
+int xk_probe_xcc(unsigned* hist16, unsigned* units128, int workgroups, int spin_cycles, void* stream);
 int xk_stream_destroy(void* stream);
 
 /* ---- K1: batched dense operator-panel product --------------------------------

@@ -41,7 +41,8 @@ def parse(spec):
     return {"name": name, "opts": None if f[0] == "auto" else int(f[0]),
             "streams": ("auto" if f[1] == "auto" else int(f[1])) if len(f) > 1 else 1,
             "reserve": int(f[2]) if len(f) > 2 else "auto",
-            "early": (int(f[3]), int(f[4])) if len(f) > 4 else None}     # (reserved CUs, basis width) of the early phase
+            "early": (int(f[3]), int(f[4])) if len(f) > 4 and int(f[4]) > 0 else None,   # (reserved CUs, basis width) of the early phase
+            "pat": int(f[5]) if len(f) > 5 else 0}                       # which mask bits the panel streams give up (kernels.CU_MASK_PATTERN)
 
 
 variants = [parse(v) for v in args.variants]
@@ -50,6 +51,7 @@ K.prefill_timing_events(2 * 48 * (args.steps + 1) * args.reps * max(1, len(varia
 
 def call(v, events):
     K.K1S_OPTS = v["opts"]
+    K.CU_MASK_PATTERN = v["pat"]
     tr = {"k1_events": events}
     with torch.no_grad():
         ev, _ = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, v_init="randn", rng_device="device",
@@ -85,7 +87,7 @@ for v in variants:
     per = r["periods"]
     avg = sum(per) / len(per)
     print(json.dumps({"variant": v["name"], "opts": v["opts"], "k1_streams": v["streams"], "reserve_cus": v["reserve"],
-                      "reserve_early": v["early"], "batch": B, "N": N, "ms_per_call_median": round(ms, 2), "ms_per_call_all": [round(t, 2) for t in r["ms"]],
+                      "reserve_early": v["early"], "cu_mask_pattern": v["pat"], "batch": B, "N": N, "ms_per_call_median": round(ms, 2), "ms_per_call_all": [round(t, 2) for t in r["ms"]],
                       "k1_launches": len(per), "k1_period_avg_ms": round(avg * 1e3, 4),
                       "k1_period_p10_p50_p90_ms": [round(bench._pct(per, q) * 1e3, 3) for q in (0.1, 0.5, 0.9)],
                       "k1_own_interval_avg_ms": round(sum(r["raw"]) / len(r["raw"]) * 1e3, 4),

@@ -50,6 +50,8 @@ def _declare(L):
     sigs = {
         "xk_abi_version": (I, []),
         "xk_stream_create_cu_masked": (I, [I, I, P]),
+        "xk_stream_create_cu_masked_pattern": (I, [I, I, I, P]),
+        "xk_probe_xcc": (I, [P, P, I, I, P]),
         "xk_stream_destroy": (I, [P]),
         "xk_stream_read": (I, [P, Lg, Lg, P, P]),
         "xk_dense_mm_workspace_elems": (Lg, [I, I, I, I, I]),

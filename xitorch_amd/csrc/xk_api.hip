@@ -12,8 +12,12 @@ extern "C" int xk_abi_version(void) { return 1; }
 // workgroup with ~100 KB of LDS per matrix, which cannot start on a CU already holding two panel-product
 // blocks), so the two really overlap.  The stream lives until xk_stream_destroy / process exit.
 // ---------------------------------------------------------------------------------------------
-extern "C" int xk_stream_create_cu_masked(int device, int reserve_cus, void** stream_out) {
-  if (!stream_out || reserve_cus < 0) return XK_ERR_ARG;
+// pattern 0: the LAST `reserve_cus` bits of the linear CU mask are cleared (what every round shipped); pattern 1: every
+// (ncu / reserve_cus)-th bit is cleared instead — on a multi-XCD device the driver deals the linear mask out over the
+// XCDs, so the two patterns differ in WHICH units a stream gives up (the tail of every XCD against whole XCDs, or the
+// other way round): measured, profiles/r05_cu_mask_pattern.jsonl.
+extern "C" int xk_stream_create_cu_masked_pattern(int device, int reserve_cus, int pattern, void** stream_out) {
+  if (!stream_out || reserve_cus < 0 || pattern < 0 || pattern > 1) return XK_ERR_ARG;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) return (int)e;
@@ -23,7 +27,17 @@ extern "C" int xk_stream_create_cu_masked(int device, int reserve_cus, void** st
   uint32_t mask[64];
   if (nwords > 64) return XK_ERR_UNSUPPORTED;
   for (int w = 0; w < nwords; ++w) mask[w] = 0;
-  for (int cu = 0; cu < ncu - reserve_cus; ++cu) mask[cu >> 5] |= (1u << (cu & 31));
+  if (pattern == 0 || reserve_cus == 0) {
+    for (int cu = 0; cu < ncu - reserve_cus; ++cu) mask[cu >> 5] |= (1u << (cu & 31));
+  } else {
+    const int step = ncu / reserve_cus;                       // clear bit step-1, 2*step-1, ... (reserve_cus of them)
+    int cleared = 0;
+    for (int cu = 0; cu < ncu; ++cu) {
+      const bool clear = step > 0 && (cu % step) == step - 1 && cleared < reserve_cus;
+      if (clear) ++cleared;
+      else mask[cu >> 5] |= (1u << (cu & 31));
+    }
+  }
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess) prev = device;
   if (prev != device && hipSetDevice(device) != hipSuccess) return XK_ERR_ARG;
@@ -32,6 +46,40 @@ extern "C" int xk_stream_create_cu_masked(int device, int reserve_cus, void** st
   if (prev != device) (void)hipSetDevice(prev);
   if (e != hipSuccess) return (int)e;
   *stream_out = (void*)st;
+  return XK_OK;
+}
+
+extern "C" int xk_stream_create_cu_masked(int device, int reserve_cus, void** stream_out) {
+  return xk_stream_create_cu_masked_pattern(device, reserve_cus, 0, stream_out);
+}
+
+// Measurement utility: which XCDs (accelerator complex dies) the workgroups of a launch on `stream` land on.  Every
+// workgroup reads its XCC id (HW_REG_XCC_ID, bits 3..0) and the id of its compute unit inside the XCD (HW_REG_HW_ID:
+// CU_ID bits 11..8, SH bit 12, SE bits 15..13), marks the unit in a per-XCD bit set and counts itself:
+// hist[xcc] = workgroups, units[xcc * 4 + w] = bit set of (se, sh, cu) seen.  Used to see what a CU mask leaves.
+namespace xk {
+__global__ __launch_bounds__(64) void xcc_probe_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ units, int spin) {
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;          // HW_REG_XCC_ID[3:0]
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));                   // HW_REG_HW_ID[15:8]
+  if (threadIdx.x == 0) {
+    atomicAdd(&hist[xcc], 1u);
+    atomicOr(&units[xcc * 8 + (hw >> 5)], 1u << (hw & 31));
+  }
+  // stay resident long enough for the dispatcher to use every unit the mask allows
+  unsigned long long t0 = __builtin_readcyclecounter();
+  while ((long long)(__builtin_readcyclecounter() - t0) < (long long)spin) {}
+}
+}  // namespace xk
+
+extern "C" int xk_probe_xcc(unsigned* hist16, unsigned* units128, int workgroups, int spin_cycles, void* stream) {
+  if (!hist16 || !units128 || workgroups < 1 || spin_cycles < 0) return XK_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(hist16, 0, 16 * sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(units128, 0, 128 * sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(xk::xcc_probe_kernel, dim3((unsigned)workgroups), dim3(64), 0, st, hist16, units128, spin_cycles);
+  XK_LAUNCH_CHECK();
   return XK_OK;
 }
 

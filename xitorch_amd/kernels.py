@@ -4,6 +4,7 @@ All tensors are device tensors; "panel" arguments are PANEL-MAJOR: shape
 (B, P, N) with unit stride along N (the reference's Fortran-order (B, N, P)
 view, xitorch/_utils/tensor.py:21-32, seen as its transpose).
 """
+import os
 import torch
 from xitorch_amd import _capi
 from xitorch_amd._capi import ptr, stream_ptr, check, suffix, fn, require_device
@@ -567,6 +568,10 @@ def stream_read(t):
 
 # --------------------------------------------------------------------------- CU-masked stream
 _MASKED_STREAMS = {}
+# which bits of the linear CU mask a masked stream gives up (include/xitorch_amd.h): 1 = every (units / reserve)-th bit,
+# 0 = the last `reserve` bits (rounds 1-4).  r05i, one process, configs[1] with the resident 8-wave panel launches: 32
+# units reserved 209.7 (tail) -> 208.0 ms per call (strided), 64 reserved 214.0 -> 208.5 (profiles/r05_cu_mask_pattern.jsonl)
+CU_MASK_PATTERN = int(os.environ.get("XITORCH_AMD_CU_MASK_PATTERN", "1"))
 
 
 def masked_stream(device, reserve_cus=64, slot=0):
@@ -579,10 +584,11 @@ def masked_stream(device, reserve_cus=64, slot=0):
     product" barrier is serialised with it."""
     import ctypes
     device = torch.device(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(reserve_cus), int(slot))
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(reserve_cus), int(slot),
+           int(CU_MASK_PATTERN))
     if key not in _MASKED_STREAMS:
         out = ctypes.c_void_p()
-        rc = fn("xk_stream_create_cu_masked")(key[0], key[1], ctypes.byref(out))
+        rc = fn("xk_stream_create_cu_masked_pattern")(key[0], key[1], key[3], ctypes.byref(out))
         check(rc, "xk_stream_create_cu_masked")
         if not _MASKED_STREAMS:
             import atexit
