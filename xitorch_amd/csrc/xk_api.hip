@@ -12,10 +12,10 @@ extern "C" int xk_abi_version(void) { return 1; }
 // workgroup with ~100 KB of LDS per matrix, which cannot start on a CU already holding two panel-product
 // blocks), so the two really overlap.  The stream lives until xk_stream_destroy / process exit.
 // ---------------------------------------------------------------------------------------------
-// pattern 0: the LAST `reserve_cus` bits of the linear CU mask are cleared (what every round shipped); pattern 1: every
-// (ncu / reserve_cus)-th bit is cleared instead — on a multi-XCD device the driver deals the linear mask out over the
-// XCDs, so the two patterns differ in WHICH units a stream gives up (the tail of every XCD against whole XCDs, or the
-// other way round): measured, profiles/r05_cu_mask_pattern.jsonl.
+// pattern 0: the LAST `reserve_cus` bits of the linear CU mask are cleared (what ships); pattern 1: every
+// (ncu / reserve_cus)-th bit is cleared instead.  Measured with xk_probe_xcc below (profiles/r05_cu_mask_probe.jsonl): the
+// driver deals the linear mask out over the XCDs bit by bit, so pattern 0 takes reserve / 8 units from every XCD, pattern 1
+// all of them from one XCD — and a mask that leaves an XCD without any unit is not honoured (all units stay usable).
 extern "C" int xk_stream_create_cu_masked_pattern(int device, int reserve_cus, int pattern, void** stream_out) {
   if (!stream_out || reserve_cus < 0 || pattern < 0 || pattern > 1) return XK_ERR_ARG;
   hipDeviceProp_t prop;

@@ -568,10 +568,14 @@ def stream_read(t):
 
 # --------------------------------------------------------------------------- CU-masked stream
 _MASKED_STREAMS = {}
-# which bits of the linear CU mask a masked stream gives up (include/xitorch_amd.h): 1 = every (units / reserve)-th bit,
-# 0 = the last `reserve` bits (rounds 1-4).  r05i, one process, configs[1] with the resident 8-wave panel launches: 32
-# units reserved 209.7 (tail) -> 208.0 ms per call (strided), 64 reserved 214.0 -> 208.5 (profiles/r05_cu_mask_pattern.jsonl)
-CU_MASK_PATTERN = int(os.environ.get("XITORCH_AMD_CU_MASK_PATTERN", "1"))
+# which bits of the linear CU mask a masked stream gives up (include/xitorch_amd.h): 0 (shipped) = the last `reserve` bits,
+# 1 = every (units / reserve)-th bit.  The driver deals the linear mask out over the 8 XCDs bit by bit (measured with
+# xk_probe_xcc, profiles/r05_cu_mask_probe.jsonl): the tail pattern takes reserve / 8 units from EVERY XCD (32 reserved: 28
+# of 32 left on each); the strided pattern would take them all from one XCD — and a mask that empties an XCD is not
+# honoured at all (every unit stays usable: "strided 32 / 64" in profiles/r05_cu_mask_pattern.jsonl are runs WITHOUT a
+# reservation: 208.0 ms per configs[1] call against 209.7 with the tail pattern, but 33.8 vs 30.8 ms at 8 operators,
+# 59.4 vs 55.9 at 16, and 109.4 vs 105.6 for the configs[4] shard)
+CU_MASK_PATTERN = int(os.environ.get("XITORCH_AMD_CU_MASK_PATTERN", "0"))
 
 
 def masked_stream(device, reserve_cus=64, slot=0):
