@@ -10,7 +10,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libxitorch_amd.so")
+# (XITORCH_AMD_LIB: a measurement build of the same ABI — trial kernels are compared against the shipped library this way)
+LIB_PATH = os.environ.get("XITORCH_AMD_LIB") or os.path.join(_HERE, "csrc", "libxitorch_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "xitorch_amd.h")
 
 _lib = None

@@ -67,9 +67,14 @@ typedef __amdgpu_buffer_rsrc_t TileRsrc;
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 constexpr unsigned SYMM_OOR = 0x7ffffff0u;     // beyond any descriptor range: returns zeros, moves no data
 
+// cache-policy bits of the operator loads (gfx942+: bit 0 sc0, bit 1 nt, bit 4 sc1).  2 = non-temporal, device-default scope:
+// what ships; the other combinations were measured as trial builds (-DXK_SYMM_AUX=n, profiles/r05_k1s_cache_policy.jsonl)
+#ifndef XK_SYMM_AUX
+#define XK_SYMM_AUX 2
+#endif
 template <typename VT>
 __device__ __forceinline__ VT ld_tile(const TileRsrc rsrc, unsigned lane_off, unsigned s_off) {
-  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)s_off, 2);
+  const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)s_off, XK_SYMM_AUX);
   return __builtin_bit_cast(VT, raw);
 }
 
