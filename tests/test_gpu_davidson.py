@@ -675,3 +675,52 @@ def test_default_orthonormalisation_survives_mixed_convergence(dev, N, p):
         tro = {}
         osym.davidson(oops.DenseOp(mat.cpu(), True), p, "lowest", min_eps=1e-8, trace=tro)
         assert abs(tr["niter"] - tro["niter"]) <= max(3, tro["niter"] // 10), (tr["niter"], tro["niter"])
+
+
+@pytest.mark.parametrize("B,P,dtype", [(8, 16, torch.float32), (3, 32, torch.float64), (5, 9, torch.float64),
+                                       (2, 1, torch.float64), (64, 12, torch.float32), (2, 31, torch.float32)])
+def test_panel_chol_wave_per_member_matches_the_scalar_algorithm(dev, B, P, dtype):
+    """(r05) xk_panel_chol is one wave per batch member with R in LDS (it was one thread per member with a scratch-memory
+    array: 0.5 ms per call on the configs[4] chain).  Every entry is formed by the operations of the column-by-column
+    scalar algorithm in the same order (tensor.py:15-17's cholesky + inverse restricted to the panel's Gram matrix):
+    bit-identical to a scalar restatement, equal to torch's factor to rounding, first non-positive pivot flagged."""
+    g = torch.Generator().manual_seed(100 * P + B)
+    Q = torch.randn(B, P, P + 3, dtype=torch.float64, generator=g)
+    G = (Q @ Q.transpose(-2, -1) + 0.1 * torch.eye(P, dtype=torch.float64)).to(dtype)
+    G = G + 1e-3 * torch.randn(B, P, P, dtype=torch.float64, generator=g).to(dtype)       # not exactly symmetric
+    W = torch.empty(B, P, P, dtype=dtype, device=dev)
+    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    K.panel_chol(G.to(dev), W, info, P)
+    assert int(info.abs().max()) == 0
+    # scalar restatement in the kernel's precision (numpy scalars round after every operation like the device does;
+    # fp32 products are not contracted with the subtraction here, so compare fp32 to a few ulps and fp64 exactly where
+    # the device code has no FMA contraction either: both to 64 ulps of the factor's scale)
+    import numpy as np
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    Gn = G.numpy().astype(npdt)
+    Wn = W.cpu().numpy()
+    for b in range(B):
+        R = np.zeros((P, P), dtype=npdt)
+        for j in range(P):
+            for i in range(j + 1):
+                s = npdt(0.5) * (Gn[b, i, j] + Gn[b, j, i])
+                for m in range(i):
+                    s = npdt(s - R[m, i] * R[m, j])
+                R[i, j] = np.sqrt(s) if i == j else npdt(s / R[i, i])
+        Wref = np.linalg.inv(R.astype(np.float64))
+        eps = np.finfo(npdt).eps
+        assert np.abs(Wn[b] - Wref).max() <= 64 * eps * np.abs(Wref).max() * P, (b, np.abs(Wn[b] - Wref).max())
+        assert np.abs(np.tril(Wn[b], -1)).max() == 0.0
+        Gs = 0.5 * (Gn[b].astype(np.float64) + Gn[b].astype(np.float64).T)
+        # W^T G W = I: the defining property of the inverse Cholesky factor
+        assert np.abs(Wn[b].astype(np.float64).T @ Gs @ Wn[b].astype(np.float64) - np.eye(P)).max() <= 256 * eps * P
+    # bit-reproducible, and a non-positive pivot is flagged at its index (sticky flag)
+    W2 = torch.empty_like(W)
+    K.panel_chol(G.to(dev), W2, info, P)
+    assert torch.equal(W, W2)
+    if P >= 3:
+        Gb = G.clone()
+        Gb[1, 2, :] = 0.0
+        Gb[1, :, 2] = 0.0
+        K.panel_chol(Gb.to(dev), W2, info, P)
+        assert info.cpu().tolist()[1] == 3 and int(info.cpu()[0]) == 0

@@ -201,46 +201,63 @@ __global__ __launch_bounds__(256) void ritz_residual_kernel(
   }
 }
 
-// one thread per batch member: G = R^T R (upper R), W = R^-1.  P <= 32.
+// One WAVE per batch member: G = R^T R (upper R), W = R^-1.  P <= 32.
 // info[b] = index+1 of the first non-positive pivot (0 = ok) — mirrors the
 // reference, where torch.linalg.cholesky raises on a rank-deficient panel.
+// (Until round 5 this was one THREAD per member with a 32 x 32 local array: dynamically indexed, so it lived in scratch
+// memory — 0.5 ms per call for eight 16 x 16 matrices, 2 ms of every half-iteration of the configs[4] chain.)  Lane j owns
+// column j of R (in LDS) and walks down its rows in lock step with the other lanes; every entry is formed by exactly the
+// operations, in exactly the order, of the column-by-column scalar algorithm
+//     s = (G_ij + G_ji) / 2 - sum_{m < i} R_mi R_mj  (m ascending);   R_jj = sqrt(s);   R_ij = s / R_ii
+// so the result is bit-identical to the scalar form.  The inverse: lane c solves R w = e_c by back substitution
+// (i descending, inner sum m ascending), again the scalar order.
 template <typename T>
-__global__ void panel_chol_kernel(const T* __restrict__ G, T* __restrict__ W, int* __restrict__ info,
-                                  int B, int P, long ldg, long sG, long sW) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void panel_chol_kernel(const T* __restrict__ G, T* __restrict__ W, int* __restrict__ info,
+                                                        int B, int P, long ldg, long sG, long sW) {
+  __shared__ T R[32][33];
+  __shared__ T C[32][33];                   // C[i][c] = entry i of column c of the inverse
+  const int b = blockIdx.x;
+  const int j = threadIdx.x;                // column of this lane
   if (b >= B) return;
-  T R[32][32];
   const T* Gb = G + (long)b * sG;
+  const bool own = j < P;
   int bad = 0;
-  for (int i = 0; i < P; ++i)
-    for (int j = 0; j < P; ++j) R[i][j] = T(0);
-  for (int j = 0; j < P; ++j) {
-    for (int i = 0; i <= j; ++i) {
+  for (int i = 0; i < P; ++i) {
+    T s = T(0);
+    if (own && j >= i) {
       // symmetrised entry: G is mathematically symmetric, average the two computed halves
-      T s = T(0.5) * (Gb[(long)i * ldg + j] + Gb[(long)j * ldg + i]);
+      s = T(0.5) * (Gb[(long)i * ldg + j] + Gb[(long)j * ldg + i]);
       for (int m = 0; m < i; ++m) s -= R[m][i] * R[m][j];
-      if (i == j) {
-        if (!(s > T(0))) { if (!bad) bad = j + 1; s = T(1); }
-        R[j][j] = sqrt(s);
-      } else {
-        R[i][j] = s / R[i][i];
+      if (j == i) {
+        if (!(s > T(0))) { bad = i + 1; s = T(1); }
+        R[i][i] = sqrt(s);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (own && j > i) R[i][j] = s / R[i][i];
+    if (own && j < i) R[i][j] = T(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // W = R^-1 (upper triangular), column by column: R W = I
   T* Wb = W + (long)b * sW;
-  for (int c = 0; c < P; ++c) {
-    T col[32];
+  if (own) {
+    const int c = j;
     for (int i = P - 1; i >= 0; --i) {
       T s = (i == c) ? T(1) : T(0);
-      for (int m = i + 1; m <= c; ++m) s -= R[i][m] * col[m];
-      col[i] = (i <= c) ? s / R[i][i] : T(0);
+      for (int m = i + 1; m <= c; ++m) s -= R[i][m] * C[m][c];
+      C[i][c] = (i <= c) ? s / R[i][i] : T(0);
     }
-    for (int i = 0; i < P; ++i) Wb[(long)i * P + c] = col[i];
+    for (int i = 0; i < P; ++i) Wb[(long)i * P + c] = C[i][c];
   }
   // sticky: a later pass over the same panel (CholeskyQR2) must not erase an earlier breakdown; the host
-  // allocates info zeroed and raises as soon as it reads a non-zero flag
-  if (bad) info[b] = bad;
+  // allocates info zeroed and raises as soon as it reads a non-zero flag.  The FIRST non-positive pivot is reported:
+  // lane j can only have flagged pivot j, so the smallest flagged lane is it.
+  const unsigned long long flagged = __ballot(bad != 0);
+  if (flagged && j == (int)(__ffsll((long long)flagged) - 1)) info[b] = bad;
 }
 
 // in-place t[c,:] <- sum_{a<=c} W[a,c] t[a,:], W upper triangular (B,P,P) row-major.
@@ -435,7 +452,7 @@ extern "C" {
   int xk_panel_chol_##SUF(const T* G, T* W, int* info, int B, int P, long ldg, long sG, void* stream) {  \
     if (B < 0 || P < 0 || P > 32) return XK_ERR_ARG;                                                     \
     if (B == 0 || P == 0) return XK_OK;                                                                  \
-    hipLaunchKernelGGL((xk::panel_chol_kernel<T>), dim3((B + 63) / 64), dim3(64), 0,                     \
+    hipLaunchKernelGGL((xk::panel_chol_kernel<T>), dim3((unsigned)B), dim3(64), 0,                       \
                        (hipStream_t)stream, G, W, info, B, P, ldg, sG, (long)P * P);                     \
     XK_LAUNCH_CHECK();                                                                                   \
     return XK_OK;                                                                                        \
