@@ -42,7 +42,8 @@ def parse(spec):
             "streams": ("auto" if f[1] == "auto" else int(f[1])) if len(f) > 1 else 1,
             "reserve": int(f[2]) if len(f) > 2 else "auto",
             "early": (int(f[3]), int(f[4])) if len(f) > 4 and int(f[4]) > 0 else None,   # (reserved CUs, basis width) of the early phase
-            "pat": int(f[5]) if len(f) > 5 else 0}                       # which mask bits the panel streams give up (kernels.CU_MASK_PATTERN)
+            "pat": int(f[5]) if len(f) > 5 else 0,                       # which mask bits the panel streams give up (kernels.CU_MASK_PATTERN)
+            "groups": int(f[6]) if len(f) > 6 else "auto"}               # batch groups of the pipeline
 
 
 variants = [parse(v) for v in args.variants]
@@ -55,7 +56,7 @@ def call(v, events):
     tr = {"k1_events": events}
     with torch.no_grad():
         ev, _ = symeig(A, neig=p, mode="lowest", method="davidson", min_eps=1e-8, v_init="randn", rng_device="device",
-                       max_niter=200, reserve_cus=v["reserve"], reserve_early=v["early"],
+                       max_niter=200, reserve_cus=v["reserve"], reserve_early=v["early"], groups=v["groups"],
                        k1_streams=("auto" if v["streams"] == "auto" else v["streams"] == 2), trace=tr)
     return ev, tr
 
@@ -87,7 +88,7 @@ for v in variants:
     per = r["periods"]
     avg = sum(per) / len(per)
     print(json.dumps({"variant": v["name"], "opts": v["opts"], "k1_streams": v["streams"], "reserve_cus": v["reserve"],
-                      "reserve_early": v["early"], "cu_mask_pattern": v["pat"], "batch": B, "N": N, "ms_per_call_median": round(ms, 2), "ms_per_call_all": [round(t, 2) for t in r["ms"]],
+                      "reserve_early": v["early"], "cu_mask_pattern": v["pat"], "groups": v["groups"], "batch": B, "N": N, "ms_per_call_median": round(ms, 2), "ms_per_call_all": [round(t, 2) for t in r["ms"]],
                       "k1_launches": len(per), "k1_period_avg_ms": round(avg * 1e3, 4),
                       "k1_period_p10_p50_p90_ms": [round(bench._pct(per, q) * 1e3, 3) for q in (0.1, 0.5, 0.9)],
                       "k1_own_interval_avg_ms": round(sum(r["raw"]) / len(r["raw"]) * 1e3, 4),
