@@ -171,8 +171,8 @@ def test_dense_symm_is_bit_reproducible(dev, B, N, P, dtype):
 
 @pytest.mark.parametrize("B,N,P,dtype", [(3, 4096, 6, torch.float64), (2, 5000, 5, torch.float64), (2, 130, 3, torch.float64),
                                          (2, 6144, 6, torch.float32), (1, 3072, 7, torch.float64), (2, 2, 2, torch.float64)])
-@pytest.mark.parametrize("slots", [0, 1, 3, 8])
-@pytest.mark.parametrize("run,tile", [(1, 1024), (2, 512), (3, 0), (1, 2048), (2, 2048), (8, 2048)])
+@pytest.mark.parametrize("slots,run,tile", [(0, 1, 1024), (1, 1, 1024), (3, 2, 512), (8, 3, 0), (0, 1, 2048), (1, 2, 2048),
+                                            (3, 8, 2048), (8, 1, 2048), (3, 1, 1024), (0, 3, 0)])
 def test_dense_symm_resident_launch_is_bit_identical(dev, B, N, P, dtype, slots, run, tile):
     # the resident form of K1s (opts bit 4: `slots` workgroups — 0 = two per compute unit — take the runs from a queue)
     # must give the bits of the one-workgroup-per-run launch whatever workgroup serves which run and however many
