@@ -724,3 +724,27 @@ def test_panel_chol_wave_per_member_matches_the_scalar_algorithm(dev, B, P, dtyp
         Gb[1, :, 2] = 0.0
         K.panel_chol(Gb.to(dev), W2, info, P)
         assert info.cpu().tolist()[1] == 3 and int(info.cpu()[0]) == 0
+
+
+def test_pipeline_with_resident_launches_and_reserve_schedule_equals_one_group(dev, monkeypatch):
+    """(r05) The two-group pipeline with RESIDENT panel launches on per-group CU-masked streams, and the panel stream
+    changing with the basis width (`reserve_schedule`: more units for the chains once the basis is long), is the same
+    iteration as the one-group run: iteration count, eigenvalues (closed form), residual history."""
+    from xitorch_amd import synthetic
+    B, N, p = 4, 2048, 6
+    mat = synthetic.dense_symmetric(B, N, "S2", dtype=torch.float64, device=dev)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    assert A.symmetric_storage
+    from xitorch_amd.linalg import _panel
+    monkeypatch.setattr(_panel, "K1S_MIN_BYTES", 0.0)            # (the upper-triangle kernel also for this small batch)
+    monkeypatch.setattr(K, "K1S_OPTS", K.K1S_PERSIST)            # resident launches whatever the launch size
+    tr1, tr2 = {}, {}
+    ev1, X1 = davidson(A, p, "lowest", min_eps=1e-8, overlap=False, trace=tr1)
+    ev2, X2 = davidson(A, p, "lowest", min_eps=1e-8, overlap=True, k1_streams=True,
+                       reserve_schedule=[(0, 32), (60, 64), (150, 96)], trace=tr2)
+    assert tr2["groups"] == 2 and tr1["groups"] == 1 and tr2["panel_kernel"] == "K1s"
+    assert tr1["niter"] == tr2["niter"] and tr2["basis_size"] > 150
+    exact = synthetic.spectrum("S2", N, device=dev)[:p]
+    assert (ev2 - exact).abs().max().item() <= 1e-10 and (ev1 - ev2).abs().max().item() <= 1e-11
+    assert max(abs(a - b) for a, b in zip(tr1["resid_history"], tr2["resid_history"])) <= 1e-9
+    assert (mat @ X2 - X2 * ev2.unsqueeze(-2)).abs().max().item() <= 1e-7

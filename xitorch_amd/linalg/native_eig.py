@@ -105,7 +105,7 @@ class _Group:
         self._compress = None                     # (Yt (B, pk, k), lam_all (B, pk)) of a pending restart
         self.nrestart = 0
         self.k1_stream = None                     # two-group pipeline: the (CU-masked) stream of the panel products
-        self.k1_stream_early, self.k1_switch = None, 0   # (optional) a wider-masked stream while the basis is small
+        self.k1_sched = None                      # (optional) [(basis width from, stream)]: the panel stream by basis width
         self.pg = None                            # sharded runs: the process group whose ranks decide together
         self.timeline, self.tag = None, 0         # debugging: (tag, label, start event, end event) per phase
         self.B, self.N, self.Npad, self.p = B, N, Npad, p
@@ -232,8 +232,11 @@ class _Group:
             return
         n0 = len(self.opA.events) if (self.timeline is not None and self.opA.events is not None) else None
         k1s = self.k1_stream
-        if self.k1_stream_early is not None and self.k < self.k1_switch:
-            k1s = self.k1_stream_early          # small basis = light chain: the panel stream may take more of the chip
+        if self.k1_sched is not None:
+            # the chain beside a launch grows with the basis: the panel stream leaves it more units as the run gets long
+            for kfrom, st in self.k1_sched:
+                if self.k >= kfrom:
+                    k1s = st
         self.opA.apply_on(X, out, k1s)
         if n0 is not None and len(self.opA.events) > n0:            # timeline: the launch's own events
             e0, e1 = self.opA.events[-1][:2]
@@ -636,11 +639,11 @@ class _GuardPolicy:
 
 class _Plan:
     """What `_plan_groups` decides for one davidson call: how many batch groups, which streams."""
-    __slots__ = ("two", "ngrp", "reserve_cus", "spans", "ops", "streams", "k1_streams", "k1_early", "distributed")
+    __slots__ = ("two", "ngrp", "reserve_cus", "spans", "ops", "streams", "k1_streams", "k1_sched", "distributed")
 
 
 def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, reserve_cus, k1_streams_opt,
-                 reserve_early, process_group):
+                 reserve_schedule, process_group):
     """The pipeline policy of one davidson call (no kernel is launched here): one batch group on the caller's stream,
     or `ngrp` groups whose small-kernel chains run on their own hardware queues while their operator-panel products
     go to CU-masked streams (see `_davidson`'s `overlap` / `groups` / `reserve_cus` / `k1_streams` options)."""
@@ -660,6 +663,7 @@ def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, 
             ngrp = 2
         else:
             ngrp = max(2, min(int(groups), B))
+    reserve_auto = reserve_cus == "auto"
     if reserve_cus == "auto":
         wide_symm = whole.kind == "dense" and whole.symm and dtype == torch.float32 and \
             K.SYMM_WIDE_MIN_P <= p <= K.SYMM_WIDE_MAX_P and N >= K.SYMM_WIDE_MIN_N and N % 64 == 0
@@ -671,7 +675,7 @@ def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, 
             total_cus = torch.cuda.get_device_properties(device).multi_processor_count
             if K.k1s_auto_opts(B // ngrp, N, dtype, max(1, total_cus - 32), pipelined=True) & K.K1S_PERSIST:
                 reserve_cus = 32
-    grp_streams, k1_streams, k1_early = None, [None], None
+    grp_streams, k1_streams, k1_sched = None, [None], None
     if two:
         try:
             grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
@@ -697,8 +701,17 @@ def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, 
                 split_k1 = bool(K._k1sw_opts(k1_stream, B // ngrp, N, pipelined=True) & K.K1SW_PERSIST)
             if split_k1:
                 k1_streams = [K.masked_stream(device, reserve_cus, slot=64 + g) for g in range(ngrp)]
-                if reserve_early is not None and int(reserve_early[0]) != int(reserve_cus):
-                    k1_early = [K.masked_stream(device, int(reserve_early[0]), slot=64 + g) for g in range(ngrp)]
+                sched = reserve_schedule
+                if sched == "auto":
+                    # un-restarted runs on slowly converging spectra reach bases of several hundred vectors; the chain
+                    # of one group (five passes over the basis + the Rayleigh-Ritz solve) then outlasts the other
+                    # group's panel product and wants the units back (S2, 64 x 16384^2, basis to 582, one box: 1.72 s
+                    # with 32 units throughout, 1.58 with 64, 1.67 with 96, 1.66 with 32 / 64 / 96 from 0 / 160 / 320
+                    # vectors: profiles/r05_c2_S2_schedule.jsonl)
+                    sched = [(0, 32), (132, 64)] if (reserve_auto and reserve_cus == 32) else None
+                if sched:
+                    k1_sched = [(int(kf), [K.masked_stream(device, int(reserve_cus if cu is None else cu), slot=64 + g)
+                                           for g in range(ngrp)]) for (kf, cu) in sched]
         except NativeLibraryError as err:            # no CU-mask support: same kernels, one group, one stream
             import warnings
             warnings.warn("xitorch_amd davidson: CU-masked streams unavailable (%s); running one batch group" % err)
@@ -719,7 +732,7 @@ def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, 
             else:
                 ngrp = g_common
                 grp_streams, k1_streams = grp_streams[:ngrp], k1_streams[:ngrp]
-                k1_early = k1_early[:ngrp] if k1_early is not None else None
+                k1_sched = [(kf, sts[:ngrp]) for (kf, sts) in k1_sched] if k1_sched is not None else None
     if two:
         cuts = [(B * g) // ngrp for g in range(ngrp + 1)]
         spans = [(cuts[g], cuts[g + 1]) for g in range(ngrp)]
@@ -729,12 +742,12 @@ def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, 
         # stream is not used for a group: it usually is the legacy null stream, which synchronises implicitly
         # with every blocking stream and serialises the pipeline (measured: 280 instead of 224 ms)
         streams = grp_streams
-        for st in streams + list(set(k1_streams)) + list(k1_early or []):
+        for st in streams + list(set(k1_streams)) + [t for (_, sts) in (k1_sched or []) for t in sts]:
             st.wait_stream(cur)
     else:
-        spans, ops, streams, k1_streams, k1_early = [(0, B)], [whole], [torch.cuda.current_stream()], [None], None
+        spans, ops, streams, k1_streams, k1_sched = [(0, B)], [whole], [torch.cuda.current_stream()], [None], None
     plan.two, plan.ngrp, plan.reserve_cus, plan.spans, plan.ops, plan.streams = two, ngrp, reserve_cus, spans, ops, streams
-    plan.k1_streams, plan.k1_early, plan.distributed = k1_streams, k1_early, distributed
+    plan.k1_streams, plan.k1_sched, plan.distributed = k1_streams, k1_sched, distributed
     return plan
 
 
@@ -771,7 +784,8 @@ def _pc_slice(pc_full, b0, b1):
 def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn", max_addition=None,
               min_eps=1e-6, verbose=False, V0=None, orth_passes="auto", process_group=None, trace=None,
               rng_device="cpu", small_eigh="native", overlap="auto", precond=None, reserve_cus="auto", restart=None,
-              groups="auto", chain="calls", basis_capacity=None, k1_streams="auto", reserve_early=None, **unused):
+              groups="auto", chain="calls", basis_capacity=None, k1_streams="auto", reserve_schedule="auto",
+              reserve_early=None, **unused):
     """
     Block Davidson method for the lowest / uppermost eigenpairs of a large Hermitian operator,
     running on MI355X HIP kernels.
@@ -830,9 +844,12 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         when its launches are resident (``kernels.k1s_auto_opts``: workgroups that take tile runs from a queue hold the
         machine until the queue is empty, so the other group's launch fills the slots the tail frees: 217.6 -> 211.9 ms
         per BASELINE configs[1] call); otherwise both groups share one masked stream.  ``True`` / ``False`` force it
-    reserve_early: tuple or None
-        (extension, measurement) ``(cus, k)``: while the basis holds fewer than ``k`` vectors the panel products run on
-        streams that leave only ``cus`` compute units to the other group's (then still light) chain
+    reserve_schedule: str, list or None
+        (extension, r05) compute units left to the chains BY BASIS WIDTH, with per-group panel streams: a list of
+        ``(basis width from, units)``.  ``"auto"`` (default): ``[(0, 32), (132, 64)]`` when ``reserve_cus`` is
+        ``"auto"`` — the chain of a group grows with the basis, and on un-restarted runs to several hundred vectors it
+        outlasts the other group's panel product; ``None``: ``reserve_cus`` throughout.  ``reserve_early=(cus, k)``
+        (measurement) = ``[(0, cus), (k, reserve_cus)]``
     chain: str
         (extension) ``"calls"`` (default): every stage between two operator-panel products (rotation + residual +
         status, orthonormalisation of the new block, extension of T) is enqueued by one C call
@@ -910,9 +927,10 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
     # ---- batch groups: one, or two pipelined on their own streams (policy: `_plan_groups`) --------------------------
     whole = _PanelOperator(A, bdims, B, N)
     plan = _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, reserve_cus, k1_streams,
-                        reserve_early, process_group)
+                        ([(0, int(reserve_early[0])), (int(reserve_early[1]), None)] if reserve_early is not None
+                         else reserve_schedule), process_group)
     two, spans, ops, streams = plan.two, plan.spans, plan.ops, plan.streams
-    k1_streams, k1_early, distributed = plan.k1_streams, plan.k1_early, plan.distributed
+    k1_streams, k1_sched, distributed = plan.k1_streams, plan.k1_sched, plan.distributed
     for op in ops:
         op.events = events                       # bench.py: per-launch HIP events of the panel product
     G = len(spans)
@@ -929,8 +947,8 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
                          precond=_pc_slice(pc_full, b0, b1), restart=restart, capacity=basis_capacity)
             grp.k1_stream = k1_streams[g]
-            if two and k1_early is not None:
-                grp.k1_stream_early, grp.k1_switch = k1_early[g], int(reserve_early[1])
+            if two and k1_sched is not None:
+                grp.k1_sched = [(kf, sts[g]) for (kf, sts) in k1_sched]
             grp.adaptive = adaptive
             # (panels wider than 32 need the chunked orthonormalisation of xk_davidson_orth)
             grp.fast = (chain != "kernels") or p > 32 or nguess > 32
@@ -1043,7 +1061,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         raise RuntimeError("xitorch_amd davidson: no finite residual was produced")
     if two:
         cur = torch.cuda.current_stream()
-        for st in streams + list(set(k1_streams)) + list(k1_early or []):
+        for st in streams + list(set(k1_streams)) + [t for (_, sts) in (k1_sched or []) for t in sts]:
             cur.wait_stream(st)
         evals = torch.cat([grp.best_evals for grp in groups], dim=0)
         Xall = torch.cat([grp.Xbuf[grp.best_slot] for grp in groups], dim=0)
