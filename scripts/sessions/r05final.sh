@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r05final; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 | tee $O/gputests_tail.txt
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -3 | tee $O/gputests_tail.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
 SECONDS=0
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2>$O/bench_err.txt; echo "bench wall seconds: $SECONDS" | tee $O/bench_wall.txt; tail -1 $O/bench_err.txt; cut -c1-300 $O/bench_line.json

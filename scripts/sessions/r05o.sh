@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05o: work-item size of the full-matrix column kernel K1 (dense_rmm_cols): 32 operators of order 16384 are 2048 workgroups
+# r05o: TRIAL BUILD (the -DXK_RMM_TARGET macro is not in the tree: see git history at e6844c9) — work-item size of the full-matrix column kernel K1 (dense_rmm_cols): 32 operators of order 16384 are 2048 workgroups
 # of 32 MB on ~1536 resident slots = 1.33 rounds; trial builds with more row slabs (-DXK_RMM_TARGET = workgroups aimed at)
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r05o; mkdir -p $O scripts/_ab

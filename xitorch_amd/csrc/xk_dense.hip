@@ -390,10 +390,7 @@ static int rmm_cols_p(const T* A, const T* X, T* Y, T* ws, long ws_elems, int B,
   }
   const int ct = (N + 256 * VN - 1) / (256 * VN);
   // enough slabs to put >= ~8 blocks on every CU, but never below 64 rows/slab
-#ifndef XK_RMM_TARGET
-#define XK_RMM_TARGET 2048
-#endif
-  int nslab = (XK_RMM_TARGET + B * ct - 1) / (B * ct);
+  int nslab = (2048 + B * ct - 1) / (B * ct);
   int max_slab = (M + 63) / 64;
   if (nslab > max_slab) nslab = max_slab;
   if (nslab < 1) nslab = 1;
