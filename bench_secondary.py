@@ -30,8 +30,17 @@ PEAK_F32 = 157.3         # TFLOP/s dense fp32 MFMA
 
 
 def _avg_ms(events):
-    ms = [a.elapsed_time(b) for (a, b) in events]
-    return (sum(ms) / len(ms), len(ms)) if ms else (float("nan"), 0)
+    """average COMPLETION PERIOD of the launches (bench.py::_k1_periods: e1_i - max(e0_i, e1_{i-1}) in completion order;
+    the plain e1 - e0 when the launches do not overlap — resident panel launches of two batch groups do)"""
+    if not events:
+        return float("nan"), 0
+    base = events[0][0]
+    iv = sorted(((base.elapsed_time(a), base.elapsed_time(b)) for (a, b) in events), key=lambda t: t[1])
+    per, prev = [], None
+    for s0, e0 in iv:
+        per.append(e0 - (s0 if prev is None or s0 > prev else prev))
+        prev = e0
+    return sum(per) / len(per), len(per)
 
 
 def _timed(step, steps, warmup, fence, group, dev):
