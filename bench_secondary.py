@@ -447,7 +447,10 @@ def cpu_baseline_c3(threads, B=8, N=65536, hb=63, budget_s=8.0):
             "sample": "oracle bicgstab (torch-CPU restatement of solve.py:192-324) on the banded operator bw=%d N=%d, "
                       "batch=%d of the config's 256: forward solve + adjoint solve of the implicit backward, rtol=1e-10; "
                       "median of %d runs (%.2f s each, %d iterations forward)" % (2 * hb + 1, N, B, n, t, tr.get("niter", -1)),
-            "seconds": t, "max_err_vs_manufactured_solution": (x - xs).abs().max().item()}
+            "seconds": t, "max_err_vs_manufactured_solution": (x - xs).abs().max().item(),
+            "full_config_seconds_extrapolated": t * 256.0 / B,
+            "extrapolation": "x %.0f to the config's 256 systems (members are independent; the cost is linear in the "
+                             "batch at fixed N and band width, the sample has the config's N and bw)" % (256.0 / B)}
 
 
 def cpu_baseline_c4(threads, B=2, N=8192, budget_s=8.0):
@@ -478,7 +481,11 @@ def cpu_baseline_c4(threads, B=2, N=8192, budget_s=8.0):
             "sample": "oracle broyden1 (alpha=-1, max_rank=32, f_tol=1e-8) on tanh(A y + 0.1) + y/2, N=%d batch=%d of the "
                       "shard's 64, + the implicit backward's J^H solve (oracle bicgstab rtol=1e-10, J in closed form); "
                       "median of %d runs (%.2f s each, nfev=%s)" % (N, B, n, t, tr.get("nfev")),
-            "seconds": t, "fnorm_at_returned_root": fcn(y, A).norm().item()}
+            "seconds": t, "fnorm_at_returned_root": fcn(y, A).norm().item(),
+            "full_config_seconds_extrapolated": t * 512.0 / B,
+            "extrapolation": "x %.0f to the per-GPU shard of 64 members, x %.0f to the config's 512 (the batch is ONE flat "
+                             "system in the reference, so its iteration count is that of the slowest member; the dense "
+                             "products are linear in the batch; the sample has the config's N)" % (64.0 / B, 512.0 / B)}
 
 
 def cpu_baseline_c5(threads, p, B=1, N=8192, budget_s=8.0):
@@ -499,4 +506,8 @@ def cpu_baseline_c5(threads, p, B=1, N=8192, budget_s=8.0):
             "sample": "oracle davidson (torch-CPU restatement of symeig.py:100-227) fp32 lowest-%d, dense symmetric %s "
                       "N=%d batch=%d (the shard is 16 x 32768^2: 68.7 GB), min_eps=2e-3; median of %d runs (%.2f s each, "
                       "%s iterations)" % (p, kind, N, B, n, t, tr.get("niter")),
-            "seconds": t, "max_eval_err_vs_closed_form": (ev.double() - exact).abs().max().item()}
+            "seconds": t, "max_eval_err_vs_closed_form": (ev.double() - exact).abs().max().item(),
+            "full_config_seconds_extrapolated": t * (32768.0 / N) ** 2 * 16.0 / B,
+            "extrapolation": "x %.0f to the per-GPU shard (16 operators of 32768^2: the panel product is O(B N^2) per "
+                             "iteration; the iteration count of the closed-form spectrum is the same at both orders), x 8 "
+                             "more to the config's 128" % ((32768.0 / N) ** 2 * 16.0 / B)}

@@ -83,14 +83,7 @@ def exacteig_inputs(case):
     return A, M
 
 
-def random_symmetric(n, min_eival, max_eival, seed):
-    """Prescribed linspace spectrum in a seeded random orthogonal basis — restates what
-    xitorch/_utils/tensor.py:46-76 (create_random_square_matrix, hermitian branch) computes."""
-    ev = torch.linspace(min_eival, max_eival, n, dtype=f64)
-    g = torch.Generator().manual_seed(seed)
-    q, _ = torch.linalg.qr(torch.randn((n, n), dtype=f64, generator=g))
-    mat = q.transpose(-2, -1) @ torch.diag_embed(ev) @ q
-    return (mat + mat.transpose(-2, -1)) * 0.5
+from xitorch_amd.synthetic import random_symmetric  # noqa: E402,F401  (one definition: bench.py uses it too)
 
 
 def davidson_matrix(case):

@@ -46,6 +46,19 @@ def _worker(rank, world, port, results):
             out[overlap] = dict(niter=(tr_s["niter"], tr_f["niter"]), groups=tr_s["groups"],
                                 err=(ev_s - ev_f[lo:hi]).abs().max().item(), resid=R.abs().max().item(),
                                 hist=max(abs(a - b) for a, b in zip(tr_s["resid_history"], tr_f["resid_history"])))
+        # ---- (r06) NO `V0=`: every rank draws the start block of the WHOLE batch from the reference's
+        # seed and keeps its own members, so member b of the sharded run is member b of the unsharded run — same
+        # iterates, same iteration count — for the CPU draw (the reference's CPU path) and the device draw
+        nov = {}
+        for rdev in ("cpu", "device"):
+            tr_f, tr_s = {}, {}
+            ev_f, _ = davidson(xa.LinearOperator.m(mat, True), neig, "lowest", min_eps=1e-8, trace=tr_f, overlap=False,
+                               rng_device=rdev)
+            ev_s, _ = davidson(xa.LinearOperator.m(mat[lo:hi].contiguous(), True), neig, "lowest", min_eps=1e-8,
+                               trace=tr_s, overlap=False, process_group=dist.group.WORLD, rng_device=rdev)
+            nov[rdev] = dict(niter=(tr_s["niter"], tr_f["niter"]), err=(ev_s - ev_f[lo:hi]).abs().max().item(),
+                             hist=max(abs(a - b) for a, b in zip(tr_s["resid_history"], tr_f["resid_history"])))
+        out["no_v0"] = nov
         # ---- (r05) uneven shards: 3 operators over 2 ranks = 2 + 1.  With overlap=True rank 0 could run two
         # batch groups and rank 1 only one — one status all-reduce per group and iteration would pair up collectives of
         # different steps (or hang).  The ranks agree on the number of groups before any group exists.
@@ -147,6 +160,8 @@ def test_sharded_davidson_two_ranks_one_gpu():
             assert r["groups"] == (2 if overlap else 1)
             assert r["err"] < 1e-10 * 160 and r["resid"] < 1e-7, r
             assert r["hist"] < 1e-6, r                           # the all-reduced residual IS the global one
+        for rdev, r in results[rank]["no_v0"].items():
+            assert r["niter"][0] == r["niter"][1] and r["err"] < 1e-12 * 160 and r["hist"] < 1e-9, (rdev, r)
         r = results[rank]["uneven"]
         assert r["groups"] == 1 and r["niter"][0] == r["niter"][1] and r["err"] < 1e-10 * 160, r
         for meth, r in results[rank]["krylov"].items():

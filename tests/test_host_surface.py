@@ -523,3 +523,38 @@ def test_rayleigh_ritz_solver_limits_by_order_and_precision():
     assert ws(B, k, 0) > B * k * k * 3
     assert ws(B, 24, 0) >= B * 24 * 24                                # below order 35 there is no two-stage form
     assert ws(2 * B, k, 0) == 2 * ws(B, k, 0) or ws(2 * B, k, 0) > ws(B, k, 0)
+
+
+def test_k1s_form_choice_respects_the_descriptor_limit_of_the_8_wave_tiles():
+    """Host-side choice of the K1s launch form (kernels.k1s_auto_opts, no device needed): the 8-wave form addresses 2048
+    rows through ONE buffer descriptor, so 2048 * lda * 8 bytes must stay below 2 GiB (xk_symm.hip returns
+    XK_ERR_UNSUPPORTED beyond) — one exactly symmetric fp64 operator of order 131072 fits in HBM and must keep the
+    4-wave form instead of failing."""
+    from xitorch_amd import kernels as K
+    o = K.k1s_auto_opts(64, 16384, torch.float64, 256)
+    assert (o & K.K1S_PERSIST) and (o & K.K1S_WIDE8)                   # the headline's form is unchanged
+    for n in (131072, 150016, 188416):
+        o = K.k1s_auto_opts(1, n, torch.float64, 256)
+        assert (o & K.K1S_PERSIST) and not (o & K.K1S_WIDE8), n
+    assert K.k1s_auto_opts(1, 131064, torch.float64, 256) & K.K1S_WIDE8   # just below the limit: 8-wave tiles
+    # a padded leading dimension counts, not the order
+    assert not (K.k1s_auto_opts(4, 65536, torch.float64, 256, lda=131072) & K.K1S_WIDE8)
+    assert K.k1s_auto_opts(4, 65536, torch.float64, 256, lda=65536) & K.K1S_WIDE8
+    # fp32 never takes the 8-wave form
+    assert not (K.k1s_auto_opts(64, 16384, torch.float32, 256) & K.K1S_WIDE8)
+
+
+def test_sharded_start_block_is_the_slice_of_the_global_draw():
+    """ On a batch-sharded run every rank draws the start block of the WHOLE batch from the
+    reference's seed (symeig.py:236-246) and keeps its members: member b of an N-GPU run starts from the vectors
+    member b of the one-GPU run starts from."""
+    from xitorch_amd.linalg.native_eig import _initial_block
+    cpu = torch.device("cpu")
+    full = _initial_block("randn", None, [5], 5, 40, 3, torch.float64, cpu, "cpu")            # (5, 3, 40)
+    for off, b in ((0, 2), (2, 2), (4, 1)):
+        part = _initial_block("randn", None, [b], b, 40, 3, torch.float64, cpu, "cpu", shard=(off, 5))
+        assert torch.equal(part, full[off:off + b])
+    # unsharded / single-rank arguments leave the draw as it was
+    assert torch.equal(_initial_block("randn", None, [5], 5, 40, 3, torch.float64, cpu, "cpu", shard=(0, 5)), full)
+    r = _initial_block("rand", None, [2], 2, 40, 3, torch.float64, cpu, "cpu", shard=(3, 5))
+    assert torch.equal(r, _initial_block("rand", None, [5], 5, 40, 3, torch.float64, cpu, "cpu")[3:5])

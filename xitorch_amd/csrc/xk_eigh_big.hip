@@ -692,6 +692,19 @@ static void big_launch_step(const T* Tin, T* S, T* aux, long aux_stride, int B, 
   constexpr int LB = NT > 12 ? 256 : 512;
   if (nt > LB) nt = LB;
   const size_t lds = (size_t)step_lds_elems(k, nt / 64) * sizeof(T);
+  if (lds > 65536) {
+    // dynamic LDS beyond 64 KB is an opt-in (fp64 orders from 819 on): once per instantiation and process
+    static bool opted[2] = {false, false};
+    if (!opted[j < 0]) {
+      if (j < 0)
+        (void)hipFuncSetAttribute((const void*)tridiag_step_kernel<T, NT, true, LB>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      else
+        (void)hipFuncSetAttribute((const void*)tridiag_step_kernel<T, NT, false, LB>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      opted[j < 0] = true;
+    }
+  }
   if (j < 0)
     hipLaunchKernelGGL((tridiag_step_kernel<T, NT, true, LB>), dim3(W, B), dim3(nt), lds, st, Tin, S, aux, aux_stride, k,
                        j, W, ldt, sT, XK_BIG_SKIP);

@@ -632,7 +632,7 @@ K1S_PERSIST = 16      # opts bit 4: resident workgroups taking runs from a queue
 K1S_WIDE8 = 32        # opts bit 5 (fp64): 8-wave workgroups on 2048 x 2048 tiles, one per compute unit
 
 
-def k1s_auto_opts(B, N, dtype, cus, pipelined=False):
+def k1s_auto_opts(B, N, dtype, cus, pipelined=False, lda=None):
     """The form of one K1s launch over B operators of order N on `cus` compute units (r05, profiles/r05_k1s_*):
       * resident launch (workgroups take runs from a queue) from two rounds of workgroups on — below that the launch is
         one wave of workgroups either way; inside the eigensolver's two-group pipeline this is what lets the other
@@ -640,7 +640,9 @@ def k1s_auto_opts(B, N, dtype, cus, pipelined=False):
       * fp64: 8-wave workgroups on 2048 x 2048 tiles (half the partial-sum bytes written and folded) once the launch has
         enough of them: a tile is 32 MB, so alone on the GPU it needs ~8 per compute unit to beat the 4-wave form
         (64 x 16384^2: 10.91 vs 11.31 ms; 32 x 16384^2: 5.55 vs 5.45), inside the pipeline — tails overlapped — about 2
-        (32 operators per launch: 216.7 -> 209.9 ms per call)."""
+        (32 operators per launch: 216.7 -> 209.9 ms per call).  The 8-wave form addresses 2048 rows through one buffer
+        descriptor: `lda` (elements; N when not given) must keep 2048 * lda * 8 bytes below 2 GiB (xk_symm.hip's
+        launch check) — a wider operator keeps the 4-wave form, whose descriptor spans 1024 rows."""
     if B <= 0 or N <= 0:
         return 0
     f64 = dtype == torch.float64
@@ -653,18 +655,19 @@ def k1s_auto_opts(B, N, dtype, cus, pipelined=False):
     if f64 and (o & K1S_PERSIST):
         n8 = (N + 2047) // 2048
         # (pipelined, 16 operators per launch = 576 tiles on 192-224 units: 108.8 -> 107.6 ms per call)
-        if B * n8 * (n8 + 1) // 2 >= (2 if pipelined else 8) * cus:
+        fits = 2048 * int(N if lda is None else lda) * 8 <= 0x7fffffe0
+        if fits and B * n8 * (n8 + 1) // 2 >= (2 if pipelined else 8) * cus:
             o |= K1S_WIDE8
     return o
 
 
-def _k1s_opts(stream, opts=None, shape=None, pipelined=False):
+def _k1s_opts(stream, opts=None, shape=None, pipelined=False, lda=None):
     """`opts` of one K1s launch on `stream`: the forced flag bits (argument or module) or the shipped choice for the
     launch's `shape` = (B, N, dtype), plus — for the resident form — the workgroup count (bits 16..27) that fills the
     compute units `stream` may use, two workgroups each."""
     o = K1S_OPTS if opts is None else int(opts)
     if o is None:
-        o = k1s_auto_opts(shape[0], shape[1], shape[2], stream_cus(stream), pipelined) if shape is not None else 0
+        o = k1s_auto_opts(shape[0], shape[1], shape[2], stream_cus(stream), pipelined, lda) if shape is not None else 0
     if (o & K1S_PERSIST) and not (o >> 16):
         o |= min(0xfff, 2 * stream_cus(stream)) << 16
     return o
@@ -691,7 +694,7 @@ def dense_symm(A, X, out=None, opts=None):
     ws = _workspace(nws, X.dtype, X.device)
     rc = fn("xk_dense_symm_" + suffix(X.dtype))(ptr(A), ptr(X), ptr(out), ptr(ws), nws, B, N, P, lda, sA,
                                                  ldx, sX, ldy, sY,
-                                                 _k1s_opts(torch.cuda.current_stream(), opts, (B, N, X.dtype)),
+                                                 _k1s_opts(torch.cuda.current_stream(), opts, (B, N, X.dtype), lda=lda),
                                                  stream_ptr())
     check(rc, "xk_dense_symm")
     return out
@@ -852,7 +855,7 @@ def dense_symm_split(A, X, out, tiles_stream, timed=False):
     ready, done = sync_events(cur)                          # re-recorded on every launch: no event is created here
     ready.record(cur)
     sfx = suffix(X.dtype)
-    kopts = _k1s_opts(tiles_stream, None, (B, N, X.dtype), pipelined=True)
+    kopts = _k1s_opts(tiles_stream, None, (B, N, X.dtype), pipelined=True, lda=lda)
     e0 = e1 = None
     with torch.cuda.stream(tiles_stream):
         tiles_stream.wait_event(ready)

@@ -61,7 +61,22 @@ def _gram(Vrows, k, panel, p, N):
     return K.dense_mm(Vrows[:, :k, :N], panel[:, :p, :N])
 
 
-def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device="cpu"):
+def _shard_of_global_batch(B, device, process_group):
+    """(offset, total) of this rank's B members in the group's global batch: the ranks hold consecutive blocks in rank
+    order (how `dist.shard_range` deals a batch out); one all-gather of the local counts, once per call."""
+    world = torch.distributed.get_world_size(process_group)
+    rank = torch.distributed.get_rank(process_group)
+    mine = torch.tensor([float(B)], dtype=torch.float64, device=device)
+    allb = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(allb, mine, group=process_group)
+    counts = [int(round(v.item())) for v in allb]
+    return sum(counts[:rank]), sum(counts)
+
+
+def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device="cpu", shard=None):
+    """The start block (reference: symeig.py:236-246).  `shard` = (offset, total) on a batch-sharded run: the random
+    kinds draw the block of the WHOLE batch from seed 12421 and keep this rank's members, so that member b of an
+    N-GPU run starts from the same vectors as member b of the one-GPU run (same iterates, same iteration count)."""
     if V0 is not None:
         if V0.shape[-2] != N:
             raise RuntimeError("V0 must have shape (*batch, %d, nguess), got %s" % (N, tuple(V0.shape)))
@@ -79,10 +94,14 @@ def _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device="c
     rdev = torch.device("cpu") if rng_device == "cpu" else device
     if kind == "eye":
         V = torch.eye(N, nguess, dtype=dtype, device=rdev).unsqueeze(0).repeat(B, 1, 1)
-    elif kind == "randn":
-        V = torch.randn((*bdims, N, nguess), dtype=dtype, device=rdev).reshape(B, N, nguess)
-    elif kind in ("rand", "random"):
-        V = torch.rand((*bdims, N, nguess), dtype=dtype, device=rdev).reshape(B, N, nguess)
+    elif kind in ("randn", "rand", "random"):
+        draw = torch.randn if kind == "randn" else torch.rand
+        if shard is not None and shard[1] != B:
+            off, total = shard
+            # (the generators fill a tensor as a function of its whole size: draw the whole batch, keep the shard)
+            V = draw((total, N, nguess), dtype=dtype, device=rdev)[off:off + B].clone()
+        else:
+            V = draw((*bdims, N, nguess), dtype=dtype, device=rdev).reshape(B, N, nguess)
     else:
         raise ValueError("Unknown v_init type: %s" % kind)
     return V.to(device).transpose(-2, -1)
@@ -936,7 +955,10 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
     G = len(spans)
     pc_full = _preconditioner(precond, whole, M, bdims, B, N, dtype, device)
 
-    V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device)       # (B, nguess, N)
+    shard = None
+    if distributed and V0 is None and v_init.lower() in ("randn", "rand", "random"):
+        shard = _shard_of_global_batch(B, device, process_group)
+    V0p = _initial_block(v_init, V0, bdims, B, N, nguess, dtype, device, rng_device, shard)       # (B, nguess, N)
     if two:
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())

@@ -122,3 +122,14 @@ def root_matrix(nbatch, n, dtype=torch.float64, device="cpu", batch_offset=0):
     A_b = (0.5 / sqrt(n)) * dense_symmetric(kind="S2"), i.e. eigenvalues in (0, 0.5]."""
     return dense_symmetric(nbatch, n, "S2", dtype, device, batch_offset=batch_offset,
                            scale=0.5 / math.sqrt(n))
+
+
+def random_symmetric(n, min_eival, max_eival, seed):
+    """One dense symmetric fp64 matrix with a prescribed linspace spectrum in a seeded random orthogonal basis — the
+    shape of the reference's test / benchmark matrices (xitorch/_utils/tensor.py:46-76, hermitian branch;
+    benchmarks/benchmarks_solve.py:37-59).  BASELINE configs[0] in bench.py and the golden cases use it."""
+    ev = torch.linspace(min_eival, max_eival, n, dtype=torch.float64)
+    g = torch.Generator().manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn((n, n), dtype=torch.float64, generator=g))
+    mat = q.transpose(-2, -1) @ torch.diag_embed(ev) @ q
+    return (mat + mat.transpose(-2, -1)) * 0.5
