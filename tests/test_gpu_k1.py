@@ -504,13 +504,14 @@ def test_small_eigh_big_two_stage_vs_lapack(dev, B, k, p, uppest, dtype):
 
 @pytest.mark.parametrize("B,N,P", [(2, 1024, 16), (1, 2048, 9), (3, 1088, 12), (1, 4096, 16), (2, 2304, 13),
                                    (1, 8192, 16), (2, 1472, 16)])
-@pytest.mark.parametrize("form", [0, 1, 3])
+@pytest.mark.parametrize("form", [0, 1, 3, 9])
 def test_dense_symm_wide_mfma_vs_oracle(dev, B, N, P, form, monkeypatch):
     """K1sw (r04): exactly symmetric fp32 storage, 9 .. 16 panel columns: the upper triangle is streamed once and both
     y_I += A_IJ x_J and y_J += A_IJ^T x_I run on the matrix cores (torch.matmul(mat, x), linop.py:695-696, inside the
     eigensolver of BASELINE configs[4]).  Against the oracle's operator; orders that are not multiples of the 256-column
     strip or the 512-row tile; only the triangle (plus the 64 x 64 diagonal blocks) may be read; bit-reproducible.
-    form 1 / 3: the workgroup-cooperative kernel (opts bit 0 of the C ABI; bit 1 = wave priority), 3 is what ships."""
+    form 1 / 3: the workgroup-cooperative kernel (opts bit 0 of the C ABI; bit 1 = wave priority); form 9 (r06, bits 0 + 3):
+    the column part straight from the load registers + a ring of four 16 x 64 blocks in flight per wave."""
     monkeypatch.setattr(K, "K1SW_OPTS", form)
     g = torch.Generator().manual_seed(N + P)
     R = torch.randn(B, N, N, dtype=torch.float32, generator=g)

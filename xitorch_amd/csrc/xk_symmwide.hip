@@ -468,6 +468,249 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6 form (opts bit 3): the column part straight from the load registers, a ring of four blocks in flight.
+//
+// What the counters of the form above say (profiles/r04_k1sw_coop_pmc_probe.json, profiles/r06_k1sw_*.json): the matrix
+// pipe is 0.48-0.54 busy with three waves per SIMD, waves wait for ISSUE, not for counters; in the instruction stream every
+// operand of both products comes out of LDS (48 DS operations per 64 MFMAs, the column part as ds_read -> lgkmcnt(0) ->
+// 4 MFMAs), and a wave has ONE 8 KB register buffer, re-issued only after the previous one went through its LDS turn.
+//
+// Here a load instruction fetches 4 rows x 256 B in the B-operand layout of the COLUMN part
+//        lane (n = lane & 15, q = lane >> 4), load s:  A[rb + 4 q + s][c0 + 4 n .. 4 n + 3]
+// so  y_J += A_IJ^T x_I  is  D[panel][column 4 n + e] += sum_q x[rb + 4 q + s][panel] * A[rb + 4 q + s][c0 + 4 n + e]:
+// v_mfma_f32_16x16x4_f32 with the loaded register as B and x_I as A, 16 MFMAs per 16 x 64 block on four independent
+// accumulators, no LDS, no wait but the load's own.  (The contraction order inside a block is free: rows rb + 4 q + s
+// for fixed s share an instruction, which also makes x_I of a 16-row block ONE 16-byte load per lane.)  The row part
+// needs the block with rows on the lane index: 4 ds_write_b128 + 4 ds_read_b128 per block (lane (m, q) reads row m,
+// columns 4 (q + 4 u) .. + 3 = the A operands of four k-steps), a third of the DS operations, software-pipelined one
+// block behind (the reads of block j - 1 are covered by the 16 column MFMAs of block j).  A ring of four blocks =
+// 16 loads = 16 KB in flight per wave, two waves per SIMD (256 registers): 128 KB per compute unit, K1s' figure.
+// Work split, partial slots, fold, diagonal rule (the 64 x 64 diagonal block: row part on both triangles, no column
+// part; blocks left of it: out-of-range loads, no traffic, and — new — no MFMAs either) as in the form above.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef XK_SW8_PROBE
+#define XK_SW8_PROBE 0     // 1: no MFMA (traffic + LDS turn + partials), 2: no matrix loads (MFMA + LDS), scripts/k1sw_probe.py
+#endif
+constexpr int SW8_RING = 4;                        // blocks (16 rows x 64 columns, four 1 KB loads) in flight per wave
+constexpr int SW8_PITCH = 272;                     // bytes per LDS row of a block: 16 slots of 16 B + one slot of padding
+constexpr int SW8_BUF = 16 * SW8_PITCH;            // 4352 B: one block in row layout
+constexpr int SW8_PARK = 4 * 64 * 16;              // the band's four row-sum blocks of this wave (4096 B)
+constexpr int SW8_WAVE_LDS = 2 * SW8_BUF + SW8_PARK;   // 12800 B per wave, 51200 per workgroup
+
+__global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
+    const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ rowP, float* __restrict__ colP,
+    int N, int pc, long lda, long sA, long ldx, long sX, int NSS, int NT, int TR, int tiles_per_op) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x;
+  const int b = __builtin_amdgcn_readfirstlane((int)((unsigned)item / (unsigned)tiles_per_op));
+  int ti = __builtin_amdgcn_readfirstlane((int)((unsigned)item - (unsigned)b * tiles_per_op));
+  int S = 0;
+  for (;;) {
+    const int cnt = sw7_tiles_of_sstrip(S, N, TR);
+    if (ti < cnt) break;
+    ti -= cnt;
+    ++S;
+  }
+  S = __builtin_amdgcn_readfirstlane(S);
+  const int I = __builtin_amdgcn_readfirstlane(ti);
+  // this wave's two column groups of 64: sbase + 64 wave and sbase + 256 + 64 wave (the four waves together: 2 x 1 KB
+  // contiguous per matrix row)
+  const int sbase = S * SW7_SS;
+  const int cg0 = sbase + 64 * wave;
+  const int r_begin = I * TR;
+  int r_end = r_begin + TR;
+  r_end = r_end < N ? r_end : N;
+  r_end = r_end < (S + 1) * SW7_SS ? r_end : (S + 1) * SW7_SS;
+  if (r_begin >= r_end) return;
+  char* wbase = smem + wave * SW8_WAVE_LDS;
+  char* park = wbase + 2 * SW8_BUF;
+  const float* Ab = A + (long)b * sA;
+  const float* Xb = X + (long)b * sX;
+  const int nn = lane & 15, kq = lane >> 4;
+  // (lanes of panel columns >= pc read column 0 instead: an output element (panel, .) depends on that panel's operand
+  //  lanes only, and the stores below are guarded — no select after a load, which would put a wait next to it)
+  const bool cok = nn < pc;
+  const float* Xc = Xb + (long)(cok ? nn : 0) * ldx;
+  const unsigned ldab = (unsigned)(lda * 4L);
+  const unsigned lane_off = (unsigned)(4 * kq) * ldab + (unsigned)nn * 16u + (unsigned)wave * 256u;
+  constexpr unsigned POISON = 0x7ffffff0u;
+  const unsigned wr_off = (unsigned)(4 * kq) * SW8_PITCH + (unsigned)nn * 16u;     // + s rows
+  const unsigned rd_off = (unsigned)nn * SW8_PITCH + (unsigned)kq * 16u;           // + 64 u bytes
+
+  // x_J of the wave's two groups in the row part's B-operand layout: xj[g][u] = X[panel nn][cg + 4 (kq + 4 u) .. + 3]
+  sw_f32x4 xj[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = cg0 + 256 * g + 4 * (kq + 4 * u);
+      const bool ok = cok && (cg0 + 256 * g < N);
+      xj[g][u] = *reinterpret_cast<const sw_f32x4*>(Xc + (ok ? c : 0));
+    }
+  sw_f32x4 acc_col[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc_col[g][e] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto band_rsrc = [&](int row0) {
+    return sw_rsrc(Ab + (long)row0 * lda + sbase, ((long)(SW_ROWS - 1) * lda + (N - sbase)) * 4L);
+  };
+  // the band's x_I in the column part's A-operand layout: xi[i] = X[panel nn][row0 + 16 i + 4 kq .. + 3]
+  auto load_xi = [&](sw_f32x4 (&xi)[4], int row0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xi[i] = *reinterpret_cast<const sw_f32x4*>(Xc + row0 + 16 * i + 4 * kq);
+  };
+  // block j of a band = row block i = j >> 1, column group g = j & 1: four loads of 4 rows x 256 B
+  auto issue = [&](sw_f32x4 (&a)[4], const SwRsrc& ra, unsigned vo, int j) {
+    const int i = j >> 1, g = j & 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#if XK_SW8_PROBE == 2
+      a[s] = sw_f32x4{(float)vo, (float)s, (float)j, 1.f};
+#else
+      const unsigned so = (unsigned)(16 * i + s) * ldab + (unsigned)g * 1024u;
+      a[s] = __builtin_bit_cast(sw_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)vo, (int)so, 2));
+#endif
+    }
+  };
+  // per band: which of the wave's two groups exist (on / right of the diagonal block) and which carry the column part
+  auto live_of = [&](int row0, int g) { const int c0 = cg0 + 256 * g; return (c0 >= row0) && (c0 < N); };
+  auto both_of = [&](int row0, int g) { const int c0 = cg0 + 256 * g; return (c0 >= row0 + SW_ROWS) && (c0 < N); };
+
+  sw_f32x4 ring[SW8_RING][4];
+  sw_f32x4 xi[4], xin[4];
+  {
+    const SwRsrc r0 = band_rsrc(r_begin);
+    load_xi(xi, r_begin);
+#pragma unroll
+    for (int j = 0; j < SW8_RING; ++j)
+      issue(ring[j], r0, live_of(r_begin, j & 1) ? lane_off : POISON, j);
+  }
+  for (int row0 = r_begin; row0 < r_end; row0 += SW_ROWS) {
+    const SwRsrc ra = band_rsrc(row0);
+    const bool more = row0 + SW_ROWS < r_end;
+    const int rown = more ? row0 + SW_ROWS : row0;
+    const SwRsrc rn = band_rsrc(rown);
+    bool live[2], both[2];
+    unsigned vo[2], von[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      live[g] = live_of(row0, g);
+      both[g] = both_of(row0, g);
+      vo[g] = live[g] ? lane_off : POISON;
+      von[g] = (more && live_of(rown, g)) ? lane_off : POISON;
+    }
+    sw_f32x4 acc_row[2];
+    sw_f32x4 w[4];
+#pragma unroll
+    for (int j = 0; j <= 8; ++j) {
+      // ---- (1) block j - 1 back from LDS in row layout: lane (m = nn, q) <- row m, columns 4 (q + 4 u) .. + 3
+      const bool rowpart = j > 0 && live[(j - 1) & 1];
+      if (rowpart) {
+        const char* rb = wbase + ((j - 1) & 1) * SW8_BUF + rd_off;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const sw_f32x4*>(rb + 64 * u);
+      }
+      if (j < 8) {
+        const int i = j >> 1, g = j & 1;
+        sw_f32x4(&blk)[4] = ring[j & (SW8_RING - 1)];
+        if (live[g]) {
+          // ---- (2) block j into LDS: lane (n, q), load s -> row 4 q + s, slot n
+          char* wb = wbase + (j & 1) * SW8_BUF + wr_off;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) *reinterpret_cast<sw_f32x4*>(wb + s * SW8_PITCH) = blk[s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#if XK_SW8_PROBE != 1
+        if (both[g]) {
+          // ---- (3) column part of block j from the load registers: k-step s, four column phases e
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc_col[g][e] = sw_mma(xi[i][s], blk[s][e], acc_col[g][e]);
+        }
+#else
+        if (both[g]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc_col[g][e][0] += blk[e][e] * xi[i][e];
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (4) the ring slot is free: block j + 4 (of this band, or of the next one)
+        if (j + SW8_RING < 8) issue(blk, ra, vo[(j + SW8_RING) & 1], j + SW8_RING);
+        else issue(blk, rn, von[(j + SW8_RING) & 1], j + SW8_RING - 8);
+        if (j == 3 && more) load_xi(xin, rown);      // (before the next band's blocks enter the in-order queue)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- (5) row part of block j - 1: k-steps (u, e), two alternating accumulator chains
+      if (j > 0) {
+        const int ip = (j - 1) >> 1, gp = (j - 1) & 1;
+        if (gp == 0) {
+          acc_row[0] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
+          acc_row[1] = sw_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (rowpart) {
+#if XK_SW8_PROBE != 1
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc_row[e & 1] = sw_mma(w[u][e], xj[gp][u][e], acc_row[e & 1]);
+#else
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc_row[u & 1][u] += w[u][u] * xj[gp][u][u];
+#endif
+        }
+        if (gp == 1) {
+          sw_f32x4 sum;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum[r] = acc_row[0][r] + acc_row[1][r];
+          *reinterpret_cast<sw_f32x4*>(park + (unsigned)(ip * 64 + lane) * 16u) = sum;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- the four waves' row sums of this band: wave w adds up row block w of the four parks
+    __syncthreads();
+    {
+      sw_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const sw_f32x4 v = *reinterpret_cast<const sw_f32x4*>(smem + q * SW8_WAVE_LDS + 2 * SW8_BUF +
+                                                               (unsigned)(wave * 64 + lane) * 16u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] += v[r];
+      }
+      if (cok) {
+        float* rp = rowP + (((long)b * NSS + S) * 16 + nn) * (long)N + row0 + 16 * wave + 4 * kq;
+        __builtin_nontemporal_store(sum, reinterpret_cast<sw_f32x4*>(rp));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xi[i] = xin[i];
+  }
+  // ---- the tile's column sums: lane (n, q), accumulator e, register r = panel 4 q + r, column cg + 4 n + e
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c0 = cg0 + 256 * g;
+    if (c0 < N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int panel = 4 * kq + r;
+        if (panel < pc) {
+          float* cp = colP + (((long)b * NT + I) * 16 + panel) * (long)N + c0 + 4 * nn;
+          const sw_f32x4 v = {acc_col[g][0][r], acc_col[g][1][r], acc_col[g][2][r], acc_col[g][3][r]};
+          __builtin_nontemporal_store(v, reinterpret_cast<sw_f32x4*>(cp));
+        }
+      }
+    }
+  }
+}
+
 // Y[b][c][n] = sum of the row partials of the strips that hold row n (strip n / WS and every strip right of it) and of
 // the column partials of the row tiles that hold column n (tiles 0 .. n / TR), each list in ascending order
 __global__ __launch_bounds__(256) void symm_wide_fold(const float* __restrict__ rowP, const float* __restrict__ colP,
@@ -530,7 +773,16 @@ static int symm_wide(const float* A, const float* X, float* Y, float* ws, long w
       const long nitems_l = (long)B * tiles;
       if (nitems_l > 0x7fffffffL) return XK_ERR_UNSUPPORTED;
       const int nitems = (int)nitems_l;
-      if (opts & 4) {
+      if (opts & 8) {
+        static bool opted = false;
+        if (!opted) {
+          (void)hipFuncSetAttribute((const void*)dense_symm_wide8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    4 * SW8_WAVE_LDS);
+          opted = true;
+        }
+        hipLaunchKernelGGL(dense_symm_wide8_kernel, dim3((unsigned)nitems), dim3(256), 4 * (size_t)SW8_WAVE_LDS, st, A, X,
+                           rowP, colP, N, P, lda, sA, ldx, sX, NSS, NT, TR, tiles);
+      } else if (opts & 4) {
         // resident launch: queue word in the last 64 bytes of the workspace, reset in stream order before the launch
         if (ws_elems < nrow + ncol + SW_QUEUE_ELEMS) return XK_ERR_ARG;
         unsigned* queue = reinterpret_cast<unsigned*>(ws + (ws_elems - SW_QUEUE_ELEMS));
@@ -604,7 +856,7 @@ long xk_dense_symm_wide_workspace_elems(int B, int N) {
 
 int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
                            long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream) {
-  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfffc) > 4 || opts > 0x0fffffff || ((opts & 4) && !(opts & 1))) return XK_ERR_ARG;
+  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfff0) != 0 || opts > 0x0fffffff || ((opts & 12) && !(opts & 1)) || (opts & 12) == 12) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
   return xk::symm_wide(A, X, Y, ws, ws_elems, B, N, P, lda, sA, ldx, sX, ldy, sY, opts, 0, (hipStream_t)stream);
 }
@@ -613,14 +865,14 @@ int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, 
 // fold on the group's own stream); `ws` must stay untouched in between
 int xk_dense_symm_wide_tiles_f32(const float* A, const float* X, float* ws, long ws_elems, int B, int N, int P,
                                  long lda, long sA, long ldx, long sX, int opts, void* stream) {
-  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfffc) > 4 || opts > 0x0fffffff || ((opts & 4) && !(opts & 1))) return XK_ERR_ARG;
+  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfff0) != 0 || opts > 0x0fffffff || ((opts & 12) && !(opts & 1)) || (opts & 12) == 12) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
   return xk::symm_wide(A, X, nullptr, ws, ws_elems, B, N, P, lda, sA, ldx, sX, 0, 0, opts, 1, (hipStream_t)stream);
 }
 
 int xk_dense_symm_wide_fold_f32(float* Y, const float* ws, long ws_elems, int B, int N, int P, long ldy, long sY,
                                 int opts, void* stream) {
-  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfffc) > 4 || opts > 0x0fffffff || ((opts & 4) && !(opts & 1))) return XK_ERR_ARG;
+  if (B < 0 || N < 0 || opts < 0 || (opts & 0xfff0) != 0 || opts > 0x0fffffff || ((opts & 12) && !(opts & 1)) || (opts & 12) == 12) return XK_ERR_ARG;
   if (B == 0 || N == 0) return XK_OK;
   return xk::symm_wide((const float*)ws, (const float*)ws, Y, (float*)ws, ws_elems, B, N, P, N, 0, N, 0, ldy, sY, opts,
                        2, (hipStream_t)stream);

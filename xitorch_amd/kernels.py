@@ -703,7 +703,9 @@ def dense_symm(A, X, out=None, opts=None):
 # --------------------------------------------------------------------------- K1sw symmetric storage, wide panels (MFMA)
 SYMM_WIDE_MIN_P, SYMM_WIDE_MAX_P = 9, 16
 SYMM_WIDE_MIN_N = 1024        # below this the tiles are too few to fill the chip: K1w / K1s serve
-K1SW_OPTS = 3                 # bit 0: workgroup-cooperative form (3 waves per SIMD), bit 1: s_setprio around its MFMA block; 0: one wave per tile (include/xitorch_amd.h)
+K1SW_OPTS = 9                 # bit 0: workgroup-cooperative forms; + bit 3 (shipped, r06): column part from the load registers, ring of
+                              # four blocks, 2 waves per SIMD; + bit 1 (r05, 3 waves per SIMD): s_setprio around the MFMA block; 0: one wave
+                              # per tile (include/xitorch_amd.h)
 K1SW_PERSIST = 4              # bit 2 (with bit 0): resident workgroups taking super-tiles from a queue, three per compute unit
 K1SW_RESIDENT = False         # False (shipped): one workgroup per super-tile.  True / "auto" (inside the two-group pipeline, from
                               # 4 rounds of workgroups): resident launches + one panel stream per group — measured on the
@@ -714,7 +716,7 @@ K1SW_RESIDENT = False         # False (shipped): one workgroup per super-tile.  
 
 def _k1sw_opts(stream, B, N, pipelined=False):
     o = int(K1SW_OPTS)
-    if not (o & 1):
+    if not (o & 1) or (o & 8):
         return o
     cus = stream_cus(stream)
     tr = 1024 if N >= 8192 else (512 if N >= 2048 else 256)
