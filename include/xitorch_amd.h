@@ -126,7 +126,11 @@ int xk_dense_symm_fold_f32(float* Y, const float* ws, long ws_elems, int B, int 
  * through LDS; + 2 = raised wave priority around its MFMA block; 3 is what the Python host passes: 3.58 ms against 3.97 ms
  * for 8 x 32768^2, profiles/r04_k1sw_forms.jsonl); + 4 (round 5, with 1): resident launch — bits 16..27 workgroups (0 =
  * three per compute unit) take the super-tiles from a queue in the last 64 bytes of `ws` (reset by the call), bit-identical
- * to opts 1 / 3.  _tiles and _fold of one product take the same opts. */
+ * to opts 1 / 3; + 8 (round 6, with 1, not with 2 / 4; 9 is what the Python host passes): the column part straight from the
+ * load registers (a load = 4 rows x 256 B in the column part's B-operand layout), the row part through ds_write_b128 /
+ * ds_read_b128 one block behind, a ring of four 16 x 64 blocks = 16 KB in flight per wave, two waves per SIMD — same
+ * work split, partial slots and fold as opts 1: 3.62 -> 2.94 ms for 8 x 32768^2 (profiles/r06_k1sw_forms.json).
+ * _tiles and _fold of one product take the same opts. */
 long xk_dense_symm_wide_workspace_elems(int B, int N);
 int xk_dense_symm_wide_f32(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P,
                            long lda, long sA, long ldx, long sX, long ldy, long sY, int opts, void* stream);

@@ -7,12 +7,17 @@ import os, sys, json, subprocess, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "scripts", "_probe")
 SRC = os.path.join(ROOT, "xitorch_amd", "csrc")
+# trial builds of the r06 form (tile kernel only; never loaded by the package)
+VARIANTS = [("pitch272", ["-DXK_SW8_SWZ=0"]), ("prio", ["-DXK_SW8_PRIO=1"]), ("tr512", ["-DXK_SW_TR_BIG=512"]),
+            ("tr2048", ["-DXK_SW_TR_BIG=2048"])]
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     procs = []
-    for mode in (1, 2):
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", SRC,
-               "-DXK_SW8_PROBE=%d" % mode, os.path.join(SRC, "xk_symmwide.hip"), "-o", os.path.join(OUT, "k1sw8_probe%d.so" % mode)]
+    builds = [("k1sw8_probe1.so", ["-DXK_SW8_PROBE=1"]), ("k1sw8_probe2.so", ["-DXK_SW8_PROBE=2"])]
+    builds += [("k1sw8_var_%s.so" % name, flags) for name, flags in VARIANTS]
+    for lib, flags in builds:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", SRC] + flags + \
+              [os.path.join(SRC, "xk_symmwide.hip"), "-o", os.path.join(OUT, lib)]
         procs.append(subprocess.Popen(cmd))
     sys.exit(max(p.wait() for p in procs))
 sys.path.insert(0, ROOT)
@@ -54,7 +59,9 @@ ref = torch.matmul(X[:1].double(), A[:1].double())
 rec["rel_err_opts9_vs_fp64"] = ((outs[9][:1].double() - ref).abs().max() / ref.abs().max()).item()
 rec["rel_err_opts3_vs_fp64"] = ((outs[3][:1].double() - ref).abs().max() / ref.abs().max()).item()
 rec["rel_diff_opts9_vs_opts3"] = ((outs[9] - outs[3]).abs().max() / outs[3].abs().max()).item()
-for name, path, forms in (("tiles", None, (3, 9)), ("no_mfma", "k1sw8_probe1.so", (9,)), ("no_matrix_loads", "k1sw8_probe2.so", (9,))):
+plan = [("tiles", None, (3, 9)), ("no_mfma", "k1sw8_probe1.so", (9,)), ("no_matrix_loads", "k1sw8_probe2.so", (9,))]
+plan += [("variant_" + name, "k1sw8_var_%s.so" % name, (9,)) for name, _ in VARIANTS]
+for name, path, forms in plan:
     if path is None:
         f = K.fn("xk_dense_symm_wide_tiles_f32")
     else:

@@ -25,6 +25,10 @@
 // 64 x 64 block of a band is used WHOLE (both triangles are in storage and equal) for the row part and not at all for
 // the column part, so no masks exist anywhere; sub-tiles left of it are "loaded" through an out-of-range buffer offset
 // (hardware zeros, no traffic).  Extra traffic of the partials: about 19 % of the triangle bytes at N = 32768.
+//
+// Three forms live here (opts of the C entry points): the one-wave-per-tile form just described (0), the workgroup-
+// cooperative form of round 4 (bit 0: 1024 x 512 super-tiles, three waves per SIMD, partials 7 % of the triangle bytes)
+// and the round 6 form (bits 0 + 3, shipped): same super-tiles, the column part fed straight from the load registers.
 #include "xk_common.h"
 
 namespace xk {
@@ -492,9 +496,15 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
 #ifndef XK_SW8_PROBE
 #define XK_SW8_PROBE 0     // 1: no MFMA (traffic + LDS turn + partials), 2: no matrix loads (MFMA + LDS), scripts/k1sw_probe.py
 #endif
+#ifndef XK_SW8_SWZ
+#define XK_SW8_SWZ 1       // 1: 256-byte LDS rows, 16-byte slot index XOR row (no bank conflicts either way); 0: 272-byte pitch
+#endif
+#ifndef XK_SW8_PRIO
+#define XK_SW8_PRIO 0      // 1: s_setprio 1 around the MFMA blocks (trial builds, scripts/k1sw_r06.py)
+#endif
 constexpr int SW8_RING = 4;                        // blocks (16 rows x 64 columns, four 1 KB loads) in flight per wave
-constexpr int SW8_PITCH = 272;                     // bytes per LDS row of a block: 16 slots of 16 B + one slot of padding
-constexpr int SW8_BUF = 16 * SW8_PITCH;            // 4352 B: one block in row layout
+constexpr int SW8_PITCH = XK_SW8_SWZ ? 256 : 272;  // bytes per LDS row of a block (16 slots of 16 B)
+constexpr int SW8_BUF = 16 * 272;                  // 4352 B: one block in row layout
 constexpr int SW8_PARK = 4 * 64 * 16;              // the band's four row-sum blocks of this wave (4096 B)
 constexpr int SW8_WAVE_LDS = 2 * SW8_BUF + SW8_PARK;   // 12800 B per wave, 51200 per workgroup
 
@@ -537,8 +547,17 @@ __global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
   const unsigned ldab = (unsigned)(lda * 4L);
   const unsigned lane_off = (unsigned)(4 * kq) * ldab + (unsigned)nn * 16u + (unsigned)wave * 256u;
   constexpr unsigned POISON = 0x7ffffff0u;
+#if XK_SW8_SWZ
+  // slot of (row r, 16-byte column chunk c) = c ^ r.  A ds_read_b128 is served in groups of 16 lanes made of 8 lanes of
+  // one q and 8 of q ^ 1 whose row sets are {0-3, 12-15} and {4-11}: chunks q + 4 u and (q ^ 1) + 4 u differ in bit 0
+  // only, so the 16 slots of a group are distinct; a ds_write_b128 group is 8 consecutive lanes of one row: 8 slots.
+  const unsigned wr_off = (unsigned)(4 * kq) * SW8_PITCH + (unsigned)((nn ^ (4 * kq)) * 16);     // row 4 q + s: ^ s below
+  const unsigned rd_off = (unsigned)nn * SW8_PITCH + (unsigned)((kq ^ (nn & 3)) * 16);           // chunk q + 4 u: ^ below
+  const unsigned rd_hi = (unsigned)(nn & 12);
+#else
   const unsigned wr_off = (unsigned)(4 * kq) * SW8_PITCH + (unsigned)nn * 16u;     // + s rows
   const unsigned rd_off = (unsigned)nn * SW8_PITCH + (unsigned)kq * 16u;           // + 64 u bytes
+#endif
 
   // x_J of the wave's two groups in the row part's B-operand layout: xj[g][u] = X[panel nn][cg + 4 (kq + 4 u) .. + 3]
   sw_f32x4 xj[2][4];
@@ -613,25 +632,35 @@ __global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
       if (rowpart) {
         const char* rb = wbase + ((j - 1) & 1) * SW8_BUF + rd_off;
 #pragma unroll
+#if XK_SW8_SWZ
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const sw_f32x4*>(rb + ((unsigned)(4 * u) ^ rd_hi) * 16u);
+#else
         for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const sw_f32x4*>(rb + 64 * u);
+#endif
       }
       if (j < 8) {
         const int i = j >> 1, g = j & 1;
         sw_f32x4(&blk)[4] = ring[j & (SW8_RING - 1)];
         if (live[g]) {
           // ---- (2) block j into LDS: lane (n, q), load s -> row 4 q + s, slot n
-          char* wb = wbase + (j & 1) * SW8_BUF + wr_off;
+          char* wb = wbase + (j & 1) * SW8_BUF;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) *reinterpret_cast<sw_f32x4*>(wb + s * SW8_PITCH) = blk[s];
+#if XK_SW8_SWZ
+          for (int s = 0; s < 4; ++s) *reinterpret_cast<sw_f32x4*>(wb + (wr_off ^ (unsigned)(16 * s)) + s * SW8_PITCH) = blk[s];
+#else
+          for (int s = 0; s < 4; ++s) *reinterpret_cast<sw_f32x4*>(wb + wr_off + s * SW8_PITCH) = blk[s];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #if XK_SW8_PROBE != 1
         if (both[g]) {
           // ---- (3) column part of block j from the load registers: k-step s, four column phases e
+          if (XK_SW8_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc_col[g][e] = sw_mma(xi[i][s], blk[s][e], acc_col[g][e]);
+          if (XK_SW8_PRIO) __builtin_amdgcn_s_setprio(0);
         }
 #else
         if (both[g]) {
@@ -655,10 +684,12 @@ __global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
         }
         if (rowpart) {
 #if XK_SW8_PROBE != 1
+          if (XK_SW8_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc_row[e & 1] = sw_mma(w[u][e], xj[gp][u][e], acc_row[e & 1]);
+          if (XK_SW8_PRIO) __builtin_amdgcn_s_setprio(0);
 #else
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc_row[u & 1][u] += w[u][u] * xj[gp][u][u];
@@ -749,7 +780,10 @@ __global__ __launch_bounds__(256) void symm_wide_fold(const float* __restrict__ 
 
 static int symm_wide_tr(int N) { return N >= 4096 ? 512 : 256; }
 
-static int symm_wide7_tr(int N) { return N >= 8192 ? 1024 : (N >= 2048 ? 512 : 256); }
+#ifndef XK_SW_TR_BIG
+#define XK_SW_TR_BIG 1024  // rows of a super-tile from order 8192 on (trial builds: 512 / 2048)
+#endif
+static int symm_wide7_tr(int N) { return N >= 8192 ? XK_SW_TR_BIG : (N >= 2048 ? 512 : 256); }
 
 static int symm_wide(const float* A, const float* X, float* Y, float* ws, long ws_elems, int B, int N, int P, long lda,
                      long sA, long ldx, long sX, long ldy, long sY, int opts, int phase, hipStream_t st) {
