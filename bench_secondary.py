@@ -411,6 +411,104 @@ if __name__ == "__main__":
     sys.exit("run through bench.py: python bench.py --config c3|c3g|c4|c5|c5w")
 
 
+# ------------------------------------------------------------------------------------------------- c0 + the `configs` block
+def config_c0(args, dev, cpu):
+    """BASELINE configs[0] on the GPU: symeig lowest-6 of ONE dense symmetric 512 x 512 fp64 operator (the reference's
+    benchmarks_solve.py shape), `davidson` and the reference's default `exacteig`, as a bench record."""
+    from xitorch_amd import LinearOperator as _LO, synthetic as _syn
+    from xitorch_amd.linalg import symeig as _symeig
+    m1 = _syn.random_symmetric(512, -1.0, 1.0, 123)
+    Ag = _LO.m(m1.to(dev), is_hermitian=True)
+    ref = torch.linalg.eigvalsh(m1)[:6]
+
+    def timed(method, steps):
+        def call():
+            tr = {}
+            with torch.no_grad():
+                kw = dict(method="davidson", min_eps=1e-8, trace=tr) if method == "davidson" else {}
+                ev, _ = _symeig(Ag, neig=6, mode="lowest", **kw)
+            torch.cuda.synchronize()
+            return ev, tr
+        call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ev, tr = call()
+        return (time.perf_counter() - t0) / steps, ev, tr
+    t_d, ev_d, tr_d = timed("davidson", max(args.cfg_steps, 5))
+    t_x, ev_x, _ = timed("exacteig", max(args.cfg_steps, 5))
+    napply = tr_d.get("napply") or tr_d.get("niter") or 1
+    by = 512 * 512 * 8 + 2 * 512 * 6 * 8
+    rec = {"metric": "eigpairs/s of symeig lowest-6, dense symmetric N=512 batch=1 fp64",
+           "value": 6 / t_d, "unit": "eigpairs/s", "ms_per_step": t_d * 1e3, "steps": max(args.cfg_steps, 5), "dtype": "f64",
+           "config": {"workload": "BASELINE configs[0]: linalg.symeig lowest-6 of one dense symmetric 512 x 512 fp64 operator "
+                                  "(benchmarks_solve.py shape), method=davidson, min_eps=1e-8",
+                      "iterations_per_step": tr_d.get("niter"), "basis_size": tr_d.get("basis_size")},
+           "exacteig": {"value": 6 / t_x, "unit": "eigpairs/s", "ms_per_step": t_x * 1e3,
+                        "note": "the reference's default method (symeig method=None) on the native dense eigensolver",
+                        "max_abs_err_vs_lapack": (ev_x.cpu() - ref).abs().max().item()},
+           "roofline": {"bound": "latency", "kernel": "panel product of ONE 2 MB operator (xk_dense_mm)", "peak": 8000.0,
+                        "unit": "GB/s", "algorithmic_bytes_per_launch": by, "launches_per_step": napply,
+                        "achieved": by * napply / t_d / 1e9, "frac": by * napply / t_d / 1e9 / 8000.0, "traffic": None,
+                        "avg_launch_ms": None,
+                        "note": "one 512 x 512 operator is 2 MB: the call is a chain of a few hundred small launches, "
+                                "bound by launch latency, not by HBM; achieved = all panel bytes of the call / the call"},
+           "check": {"ok": bool((ev_d.cpu() - ref).abs().max().item() < 1e-9),
+                     "max_abs_err_vs_lapack": (ev_d.cpu() - ref).abs().max().item()}}
+    if cpu and "config1_n512_b1" in cpu and "cpu_davidson_ms" in cpu["config1_n512_b1"]:
+        c1 = cpu["config1_n512_b1"]
+        rec["cpu_baseline"] = {"value": c1["cpu_davidson_eigpairs_per_s"], "unit": "eigpairs/s", "cores": cpu.get("cores"),
+                               "kind": "port", "sample": "the config itself (oracle davidson, %d threads): %.1f ms per call; "
+                               "oracle exacteig: %.1f ms per call" % (cpu.get("cores", 0), c1["cpu_davidson_ms"],
+                                                                     c1["cpu_exacteig_ms"]),
+                               "exacteig_value": c1["cpu_exacteig_eigpairs_per_s"]}
+    return rec
+
+
+def configs_block(args, dev, cpu):
+    """The other BASELINE.json configs, measured in this process after the headline (rank 0 of a one-GPU run): same
+    fences and event timing as their own bench lines (`--config c3|c4|c5w`, bench_secondary.py), `--cfg-steps` timed
+    steps each, every record with its roofline and a CPU baseline (oracle on a bounded sample)."""
+    import copy
+    import sys
+    bs = sys.modules[__name__]
+    out = {}
+
+    def fence():
+        torch.cuda.synchronize()
+    sub = copy.copy(args)
+    sub.steps, sub.warmup, sub.no_general_extra, sub.cfg_batch = args.cfg_steps, 1, True, 0
+    keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_note",
+                 "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_timed", "TFLOPs", "frac_of_fp32_matrix_peak")
+    try:
+        out["c0"] = config_c0(args, dev, cpu)
+    except Exception as err:
+        out["c0"] = {"error": repr(err)}
+    plan = [("c3", bs.config_c3, lambda: bs.cpu_baseline_c3(args.cpu_threads)),
+            ("c4", bs.config_c4, lambda: bs.cpu_baseline_c4(args.cpu_threads)),
+            ("c5w", bs.config_c5w, lambda: bs.cpu_baseline_c5(args.cpu_threads, 16))]
+    for name, fnc, cpufn in plan:
+        try:
+            torch.cuda.empty_cache()
+            line = fnc(sub, dev, None, 1, 0, fence)
+            rec = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "check") if k in line}
+            rec["steps"], rec["warmup"] = sub.steps, sub.warmup
+            rec["config"] = {k: v for k, v in line["config"].items()
+                             if k in ("workload", "global_batch", "batch_per_gpu", "forward_ms", "backward_ms",
+                                      "iterations_per_step", "niter_forward", "niter_backward", "nfev", "panel_kernel")}
+            rec["roofline"] = {k: line["roofline"].get(k) for k in keep_roof if k in line["roofline"]}
+            if not args.no_cpu_baseline:
+                try:
+                    rec["cpu_baseline"] = cpufn()
+                except Exception as err:
+                    rec["cpu_baseline"] = {"error": repr(err)}
+            out[name] = rec
+        except Exception as err:            # a secondary record never costs the headline line
+            out[name] = {"error": repr(err)}
+        torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- CPU baselines
 # The oracle (CPU restatement of the reference's loops, oracle/*.py — test infrastructure) timed on the host cores on a
 # BOUNDED sample of each config's workload.  Only bench.py's cpu_baseline leg calls these (rank 0, one GPU).
@@ -511,3 +609,57 @@ def cpu_baseline_c5(threads, p, B=1, N=8192, budget_s=8.0):
             "extrapolation": "x %.0f to the per-GPU shard (16 operators of 32768^2: the panel product is O(B N^2) per "
                              "iteration; the iteration count of the closed-form spectrum is the same at both orders), x 8 "
                              "more to the config's 128" % ((32768.0 / N) ** 2 * 16.0 / B)}
+
+
+def cpu_baseline_c0(cores):
+    """BASELINE configs[0] exactly: N=512, batch=1, lowest 6, fp64 — the reference's CPU case,
+    oracle `davidson` and `exacteig` on `cores` threads, with the native calls on the GPU beside them when there is one."""
+    from oracle import ops as oops, symeig as osym
+    from oracle.symeig import exacteig as _oexact
+    from xitorch_amd import synthetic
+    m1 = synthetic.random_symmetric(512, -1.0, 1.0, 123)
+    op1 = oops.DenseOp(m1, True)
+
+    def med(f, nmin=3, budget=4.0):
+        ts, t_all = [], time.time()
+        while len(ts) < nmin or (time.time() - t_all < budget and len(ts) < 50):
+            t0 = time.time()
+            r = f()
+            ts.append(time.time() - t0)
+        return sorted(ts)[len(ts) // 2], r
+    t_dav, (ev_d, _) = med(lambda: osym.davidson(op1, 6, "lowest", min_eps=1e-8))
+    t_ex, (ev_x, _) = med(lambda: _oexact(op1, 6, "lowest", None))
+    c1 = {"workload": "BASELINE configs[0]: symeig lowest-6, dense symmetric N=512 batch=1 fp64 "
+                      "(benchmarks_solve.py shape), oracle on %d CPU threads" % cores,
+          "cpu_davidson_ms": t_dav * 1e3, "cpu_exacteig_ms": t_ex * 1e3,
+          "cpu_davidson_eigpairs_per_s": 6 / t_dav, "cpu_exacteig_eigpairs_per_s": 6 / t_ex,
+          "max_abs_diff_davidson_vs_exacteig": (ev_d - ev_x).abs().max().item()}
+    if torch.cuda.is_available():
+        from xitorch_amd import LinearOperator as _LO
+        from xitorch_amd.linalg import symeig as _symeig
+        Ag = _LO.m(m1.cuda(), is_hermitian=True)
+
+        def gpu_call():
+            with torch.no_grad():
+                r = _symeig(Ag, neig=6, mode="lowest", method="davidson", min_eps=1e-8)
+            torch.cuda.synchronize()
+            return r
+        gpu_call()
+        t_g, (ev_g, _) = med(gpu_call, nmin=5, budget=2.0)
+
+        def gpu_exact():
+            with torch.no_grad():
+                r = _symeig(Ag, neig=6, mode="lowest")           # method=None -> exacteig, like the reference
+            torch.cuda.synchronize()
+            return r
+        gpu_exact()
+        t_gx, (ev_gx, _) = med(gpu_exact, nmin=5, budget=2.0)
+        c1.update(gpu_exacteig_ms=t_gx * 1e3, gpu_exacteig_eigpairs_per_s=6 / t_gx,
+                  max_abs_diff_gpu_exacteig_vs_cpu_exacteig=(ev_gx.cpu() - ev_x).abs().max().item(),
+                  gpu_exacteig_note="the reference's default method (symeig method=None, benchmarks_solve.py) on "
+                                    "the native dense eigensolver: only the wanted pairs are computed")
+        c1.update(gpu_davidson_ms=t_g * 1e3, gpu_davidson_eigpairs_per_s=6 / t_g,
+                  max_abs_diff_gpu_vs_cpu_exacteig=(ev_g.cpu() - ev_x).abs().max().item(),
+                  gpu_note="one 512 x 512 operator: latency-bound (a few dozen small launches per iteration), "
+                           "not what the GPU path is built for")
+    return c1
