@@ -143,10 +143,45 @@ def test_davidson_generalized_M(dev):
     assert torch.allclose(torch.matmul(Amat, Xc), torch.matmul(Mmat, Xc) * ev.cpu().unsqueeze(-2), atol=1e-7)
 
 
-def test_native_requires_device():
-    A = xa.LinearOperator.m(torch.eye(8, dtype=torch.float64), True)
-    with pytest.raises(RuntimeError):
-        davidson(A, 2, "lowest")
+def test_device_operators_never_reach_the_host_drivers(dev, monkeypatch):
+    """Device dispatch (r06): an operator in HOST memory is served by xitorch_amd/linalg/host_*.py, an operator on the HIP
+    device by the HIP kernels and by nothing else — the host drivers' call counters do not move during device calls, a
+    host driver refuses a device operator, and a device call FAILS (no silent detour) when the native library is gone."""
+    from xitorch_amd.linalg import host_eig, host_krylov, native_krylov as nk
+    from xitorch_amd.optimize import native_root as nr
+    from xitorch_amd import _capi
+    g = torch.Generator().manual_seed(3)
+    n = 96
+    R = torch.rand(2, n, n, dtype=torch.float64, generator=g)
+    S = (R + R.transpose(-2, -1)) * 0.05 + torch.eye(n, dtype=torch.float64)
+    Bm = torch.rand(2, n, 2, dtype=torch.float64, generator=g)
+    before = (dict(host_krylov.calls), dict(host_eig.calls))
+    Ad = xa.LinearOperator.m(S.to(dev), True)
+    davidson(Ad, 3, "lowest", min_eps=1e-8)
+    for meth in ("cg", "bicgstab", "gmres"):
+        getattr(nk, meth)(Ad, Bm.to(dev), rtol=1e-9)
+    nr.broyden1(lambda y: torch.matmul(S.to(dev), y.unsqueeze(-1)).squeeze(-1) - 1.0, torch.zeros(2, n, dtype=torch.float64,
+                                                                                                 device=dev), alpha=-1.0)
+    assert (dict(host_krylov.calls), dict(host_eig.calls)) == before
+    with pytest.raises(_capi.NativeLibraryError):
+        host_eig.davidson(Ad, 3, "lowest")
+    with pytest.raises(_capi.NativeLibraryError):
+        host_krylov.cg(Ad, Bm.to(dev))
+    # host memory -> host drivers (same answers)
+    Ah = xa.LinearOperator.m(S, True)
+    ev_h, _ = davidson(Ah, 3, "lowest", min_eps=1e-8)
+    ev_d, _ = davidson(Ad, 3, "lowest", min_eps=1e-8)
+    assert host_eig.calls["davidson"] == before[1]["davidson"] + 1 and (ev_h - ev_d.cpu()).abs().max().item() < 1e-10
+    # no library -> device calls raise, whatever host drivers exist
+    def gone(*a, **k):
+        raise _capi.NativeLibraryError("libxitorch_amd.so not found (simulated)")
+    monkeypatch.setattr(_capi, "fn", gone)
+    monkeypatch.setattr(K, "fn", gone)
+    monkeypatch.setattr(nk, "fn", gone)
+    with pytest.raises(_capi.NativeLibraryError):
+        nk.cg(Ad, Bm.to(dev), rtol=1e-9)
+    with pytest.raises(_capi.NativeLibraryError):
+        davidson(Ad, 3, "lowest", min_eps=1e-8)
 
 
 @pytest.mark.parametrize("B,N", [(4, 512), (5, 384)])

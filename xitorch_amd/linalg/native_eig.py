@@ -919,9 +919,15 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         nguess = neig
     bdims = list(A.shape[:-2]) if M is None else bcast_shape(A.shape[:-2], M.shape[:-2])
     dtype, device = A.dtype, torch.device(A.device)
+    if device.type == "cpu":
+        # device dispatch, like the reference (symeig.py:149): an operator in HOST memory is served by host_eig.py
+        # (the same iteration in torch ops); any device operator by the HIP kernels below and by nothing else
+        from xitorch_amd.linalg import host_eig
+        return host_eig.davidson(A, neig, mode, M, max_niter=max_niter, nguess=nguess, v_init=v_init,
+                                 max_addition=max_addition, min_eps=min_eps, verbose=verbose, V0=V0,
+                                 process_group=process_group, trace=trace, precond=precond, restart=restart)
     if device.type != "cuda":
-        raise NativeLibraryError("xitorch_amd davidson runs on a HIP device only (operator is on %s); "
-                                 "there is no CPU fallback" % device)
+        raise NativeLibraryError("xitorch_amd davidson runs on a HIP device only (operator is on %s)" % device)
     if dtype not in (torch.float64, torch.float32):
         raise NativeLibraryError("xitorch_amd davidson supports float64/float32 operators, got %s (the reference's "
                                  "davidson is real-only as well: unconjugated transposes, symeig.py:163; complex "

@@ -22,7 +22,14 @@ from xitorch_amd._util import bcast_shape, pad_shapes, ConvergenceWarning
 from xitorch_amd.linalg._panel import PanelOperator, pad_len, to_panel, from_panel
 from xitorch_amd.dist import allreduce_max_, all_ranks_agree_true
 
-__all__ = ["exactsolve", "custom_exactsolve", "cg", "bicgstab", "gmres", "broyden1_solve", "get_batchdims"]
+__all__ = ["exactsolve", "custom_exactsolve", "cg", "bicgstab", "gmres", "scipy_gmres", "broyden1_solve", "get_batchdims"]
+
+
+def _in_host_memory(A):
+    """Device dispatch (the reference runs a method on whatever device the operator lives on): operators in HOST memory
+    are served by host_krylov.py; everything else — any device tensor — by the HIP kernels below and by nothing else:
+    `_Problem` raises for a device it has no kernels for, `_capi.lib()` raises when the library is missing."""
+    return torch.device(A.device).type == "cpu"
 
 
 def get_batchdims(A, B, E, M):
@@ -80,8 +87,7 @@ class _Problem:
     def __init__(self, A, B, E, M, bdims, posdef, need_hermit):
         dev = torch.device(A.device)
         if dev.type != "cuda":
-            raise NativeLibraryError("xitorch_amd native solvers run on a HIP device only (operator is on %s); "
-                                     "there is no CPU fallback" % dev)
+            raise NativeLibraryError("xitorch_amd native solvers run on a HIP device only (operator is on %s)" % dev)
         if A.dtype not in (torch.float64, torch.float32, torch.complex128, torch.complex64):
             raise NativeLibraryError("xitorch_amd native solvers support float64/float32/complex128/complex64, "
                                      "got %s" % A.dtype)
@@ -352,6 +358,11 @@ def bicgstab(A, B, E=None, M=None, posdef=None, precond_l=None, precond_r=None, 
     process_group: torch.distributed group or None
         (extension) batch-sharded multi-GPU run: the stopping test is all-reduced over the group
     """
+    if _in_host_memory(A):
+        from xitorch_amd.linalg import host_krylov
+        return host_krylov.bicgstab(A, B, E, M, posdef=posdef, precond_l=precond_l, precond_r=precond_r,
+                                    max_niter=max_niter, rtol=rtol, atol=atol, eps=eps, verbose=verbose,
+                                    resid_calc_every=resid_calc_every, process_group=process_group, trace=trace)
     nr, ncols = B.shape[-2:]
     if max_niter is None:
         max_niter = int(1.5 * nr)
@@ -450,6 +461,11 @@ def cg(A, B, E=None, M=None, posdef=None, precond=None, max_niter=None, rtol=1e-
     process_group: torch.distributed group or None
         (extension) batch-sharded multi-GPU run: the stopping test is all-reduced over the group
     """
+    if _in_host_memory(A):
+        from xitorch_amd.linalg import host_krylov
+        return host_krylov.cg(A, B, E, M, posdef=posdef, precond=precond, max_niter=max_niter, rtol=rtol, atol=atol,
+                              eps=eps, resid_calc_every=resid_calc_every, verbose=verbose,
+                              process_group=process_group, trace=trace)
     nr = A.shape[-1]
     ncols = B.shape[-1]
     if max_niter is None:
@@ -585,6 +601,11 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
     swap (:432, and fails for more than one column); this function returns ``(*batch, nr, ncols)`` like every other
     method.
     """
+    if _in_host_memory(A):
+        from xitorch_amd.linalg import host_krylov
+        return host_krylov.gmres(A, B, E, M, posdef=posdef, max_niter=max_niter, rtol=rtol, atol=atol, eps=eps,
+                                 resid_calc_every=resid_calc_every, restart=restart, process_group=process_group,
+                                 trace=trace)
     nr, ncols = A.shape[-1], B.shape[-1]
     if A.dtype.is_complex:
         # the reference's own gmres is real-only as well (its tests xfail complex input, test_linop_fcns.py:479-481)
@@ -735,6 +756,14 @@ def gmres(A, B, E=None, M=None, posdef=None, max_niter=None, rtol=1e-6, atol=1e-
         warnings.warn(ConvergenceWarning("Convergence is not achieved after %d iterations. "
                                          "Max norm of resid: %.3e" % (max_niter, best)))
     return prob.solution(xbufs[best_i].reshape(prob.Bt, prob.nc, ld))
+
+
+def scipy_gmres(A, B, E=None, M=None, min_eps=1e-9, max_niter=None, **unused):
+    """The reference's `method="scipy_gmres"` (wrap_gmres, solve.py:14-66): SciPy's GMRES on the host, one system at a
+    time, with the operator applied wherever it lives (the reference copies every iterate between the host and the
+    operator's device as well)."""
+    from xitorch_amd.linalg import host_krylov
+    return host_krylov.scipy_gmres(A, B, E, M, min_eps=min_eps, max_niter=max_niter)
 
 
 # ------------------------------------------------------------------------------- root-finder based

@@ -95,6 +95,7 @@ class _SolveFunction(torch.autograd.Function):
                     "cg": nk.cg,
                     "bicgstab": nk.bicgstab,
                     "gmres": nk.gmres,
+                    "scipy_gmres": nk.scipy_gmres,
                 }
                 x = get_method("solve", methods, method)(A, B, E, M, **config)
         ctx.e_is_none = E is None

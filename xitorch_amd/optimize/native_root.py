@@ -91,9 +91,10 @@ class _LowRank:
     _jacobian.py:156-222, where c_n, d_n are Python lists and every apply loops over them)."""
 
     def __init__(self, alpha, uv0, L, dtype, device, red, total_L):
-        if device.type != "cuda":
-            raise NativeLibraryError("xitorch_amd Broyden runs on a HIP device only (variable is on %s); "
-                                     "there is no CPU fallback" % device)
+        # A variable on a HIP device is served by the HIP kernels and by nothing else (a missing library raises).  A
+        # variable that lives in HOST memory is applied with torch ops on the host, like the reference runs on
+        # whatever device its tensors are on (_jacobian.py:156-222): device dispatch, not a fallback.
+        self.native = device.type == "cuda"
         if dtype not in (torch.float64, torch.float32):
             raise NativeLibraryError("xitorch_amd Broyden supports float64/float32, got %s" % dtype)
         self.alpha = float(alpha)
@@ -128,7 +129,10 @@ class _LowRank:
 
     def _coef(self, rows, v):
         """coefficients <rows_n, v> for n < rank, all-reduced over the shards: one multi-dot (K1, split-contraction)"""
-        coef = K.dense_mm(rows[:, :self.rank, :self.L], self._vec(v))          # (1, 1, rank)
+        if self.native:
+            coef = K.dense_mm(rows[:, :self.rank, :self.L], self._vec(v))          # (1, 1, rank)
+        else:
+            coef = torch.mv(rows[0, :self.rank, :self.L], v.reshape(-1)).reshape(1, 1, -1)
         if self.red.group is not None:
             self.red._sum(coef)
         return coef
@@ -140,11 +144,24 @@ class _LowRank:
         v = v.reshape(-1).contiguous()            # the update kernel reads it with unit stride
         if extra is not None:
             extra = extra.reshape(-1).contiguous()
+        if not self.native:
+            return self._apply_host(out, v, first, second, g_v, extra, g_extra, gamma)
         if self.rank == 0:
             return K.broyden_axpy(out, v, g_v, extra, g_extra)
         coef = self._coef(first, v)
         return K.broyden_axpy(out, v, g_v, extra, g_extra, V=second[0], coef=coef, scale=self.dinv, k=self.rank,
                               gamma=gamma)
+
+    def _apply_host(self, out, v, first, second, g_v, extra, g_extra, gamma):
+        """the same update on host memory: out = g_v v + g_extra extra + gamma sum_n second_n inv_n <first_n, v>"""
+        res = v * g_v
+        if extra is not None:
+            res = res + extra * g_extra
+        if self.rank > 0:
+            w = self._coef(first, v).reshape(-1) * self.dinv[:self.rank]
+            res = res + gamma * torch.mv(second[0, :self.rank, :self.L].T, w)
+        out.copy_(res)
+        return out
 
     def mv(self, v, sign=1.0):
         if self.dense is not None:
