@@ -34,19 +34,27 @@ def test_library_exports_every_declared_symbol():
     assert not untyped, untyped
 
 
-def test_native_paths_refuse_cpu_tensors():
-    A = LinearOperator.m(torch.eye(8, dtype=f64), True)
+def test_kernels_refuse_host_tensors_and_methods_dispatch_on_the_device():
+    """The C-ABI wrappers (kernels.py) take device memory only — handing them a host tensor raises, there is no detour;
+    the METHOD functions dispatch on the operator's device like the reference (r06): host memory -> linalg/host_*.py."""
+    A = LinearOperator.m(torch.diag(torch.arange(1.0, 9.0, dtype=f64)), True)
     from xitorch_amd.linalg.native_eig import davidson
-    from xitorch_amd.linalg import native_krylov as nk
+    from xitorch_amd.linalg import native_krylov as nk, host_eig, host_krylov
     from xitorch_amd import kernels as K
-    with pytest.raises(RuntimeError):
-        davidson(A, 2, "lowest")
-    with pytest.raises(RuntimeError):
-        nk.cg(A, torch.ones(8, 1, dtype=f64))
     with pytest.raises(RuntimeError):
         K.dense_mm(torch.eye(4, dtype=f64), torch.ones(1, 1, 4, dtype=f64))
     with pytest.raises(RuntimeError):
-        symeig(A, 2, method="davidson")
+        K.dense_symm(torch.eye(4, dtype=f64), torch.ones(1, 1, 4, dtype=f64))
+    with pytest.raises(RuntimeError):
+        K.vec_dots([(torch.ones(4, dtype=f64), torch.ones(4, dtype=f64))])
+    n0, n1 = host_eig.calls["davidson"], host_krylov.calls["cg"]
+    ev, _ = davidson(A, 2, "lowest")
+    assert torch.allclose(ev, torch.tensor([1.0, 2.0], dtype=f64), atol=1e-8)
+    x = nk.cg(A, torch.ones(8, 1, dtype=f64))
+    assert torch.allclose(x.squeeze(-1), 1.0 / torch.arange(1.0, 9.0, dtype=f64), atol=1e-6)
+    ev2, _ = symeig(A, 2, method="davidson")
+    assert torch.allclose(ev2, ev)
+    assert host_eig.calls["davidson"] == n0 + 2 and host_krylov.calls["cg"] == n1 + 1
 
 
 # ----------------------------------------------------------------------------- operator contract
