@@ -260,3 +260,94 @@ def test_row_block_sharded_operator_gloo(world):
         assert err < 1e-11 and abs(it_s - it_f) <= 1 and resid < 1e-7, r["eig"]
         assert r["evals"] == results[0]["evals"]             # every rank holds the same replicated answer
     assert covered[0][0] == 0 and covered[-1][1] == 101 and all(covered[i][1] == covered[i + 1][0] for i in range(world - 1))
+
+
+def _worker_host_solvers(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import xitorch_amd as xa
+        from xitorch_amd import dist as xd, synthetic
+        from xitorch_amd.linalg import native_krylov as nk
+        from xitorch_amd.linalg.native_eig import davidson
+        from xitorch_amd.optimize import native_root as nr
+        grp = dist.group.WORLD
+        out = {}
+        # ---- Davidson, NO V0: every rank draws the start block of the whole batch and keeps its members
+        B, N, neig = 3, 160, 3                                     # 3 members over 2 ranks: 2 + 1
+        mat = synthetic.dense_symmetric(B, N, "S1") * torch.linspace(1.0, 1.5, B, dtype=torch.float64).reshape(B, 1, 1)
+        lo, hi = xd.shard_range(B, world, rank)
+        trf, trs = {}, {}
+        ev_f, _ = davidson(xa.LinearOperator.m(mat, True), neig, "lowest", min_eps=1e-8, trace=trf)
+        ev_s, X_s = davidson(xa.LinearOperator.m(mat[lo:hi].contiguous(), True), neig, "lowest", min_eps=1e-8, trace=trs,
+                             process_group=grp)
+        R = torch.matmul(mat[lo:hi], X_s) - X_s * ev_s.unsqueeze(-2)
+        out["davidson"] = dict(niter=(trs["niter"], trf["niter"]), err=(ev_s - ev_f[lo:hi]).abs().max().item(),
+                               resid=R.abs().max().item(),
+                               hist=max(abs(a - b) for a, b in zip(trs["resid_history"], trf["resid_history"])))
+        # ---- Krylov solves: the stopping test and the best-iterate rule are global decisions
+        g = torch.Generator().manual_seed(21)
+        nb, n = 3, 64
+        Rm = torch.rand(nb, n, n, dtype=torch.float64, generator=g)
+        Amat = (0.1 * Rm + torch.diag(torch.linspace(1.0, 4.0, n, dtype=torch.float64)))
+        Amat = Amat * torch.linspace(1.0, 3.0, nb, dtype=torch.float64).reshape(nb, 1, 1)
+        Bm = torch.rand(nb, n, 2, dtype=torch.float64, generator=g)
+        l2, h2 = xd.shard_range(nb, world, rank)
+        kry = {}
+        for meth in ("bicgstab", "cg", "gmres"):
+            herm = meth == "cg"
+            Am = (Amat + Amat.transpose(-2, -1)) * 0.5 if herm else Amat
+            kw = dict(rtol=1e-10, atol=1e-12, posdef=True)
+            tf, ts = {}, {}
+            Xf = getattr(nk, meth)(xa.LinearOperator.m(Am, herm), Bm, trace=tf, **kw)
+            Xs = getattr(nk, meth)(xa.LinearOperator.m(Am[l2:h2].contiguous(), herm), Bm[l2:h2].contiguous(), trace=ts,
+                                   process_group=grp, **kw)
+            kry[meth] = dict(niter=(ts["niter"], tf["niter"]), err=(Xs - Xf[l2:h2]).abs().max().item())
+        out["krylov"] = kry
+        # a rank whose right-hand sides are all zero stays in the collectives
+        Bz = Bm.clone()
+        Bz[:2] = 0.0
+        Xz = nk.bicgstab(xa.LinearOperator.m(Amat[l2:h2].contiguous(), False), Bz[l2:h2].contiguous(), process_group=grp,
+                         rtol=1e-10, atol=1e-12, posdef=True)
+        out["zero_shard"] = (Xz - torch.linalg.solve(Amat[l2:h2], Bz[l2:h2])).abs().max().item()
+        # ---- Broyden: the whole batch is ONE flat system
+        fcn, y0, (Ar,) = cases.root_inputs(dict(kind="tanh", nbatch=3, n=32))
+        tf, ts = {}, {}
+        yf = nr.broyden1(fcn, y0, (Ar,), alpha=-1.0, f_tol=1e-9, trace=tf)
+        ys = nr.broyden1(fcn, y0[l2:h2], (Ar[l2:h2],), alpha=-1.0, f_tol=1e-9, trace=ts, process_group=grp)
+        out["broyden"] = dict(niter=(ts["niter"], tf["niter"]), nfev=(ts["nfev"], tf["nfev"]),
+                              err=(ys - yf[l2:h2]).abs().max().item())
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_solvers_in_host_memory_two_ranks_gloo():
+    """(r06) The batch-sharded PRODUCT drivers end to end on CPU ranks: with the host-memory drivers
+    (xitorch_amd/linalg/host_*.py, the host branch of the Broyden model) davidson / cg / bicgstab / gmres / broyden1 run
+    under gloo exactly as they run under RCCL on device tensors — same process-group plumbing (`dist.allreduce_*`), same
+    global decisions.  3 members over 2 ranks (2 + 1): sharded == unsharded, same iteration counts, the Davidson start
+    block WITHOUT `V0=` (slice of the global draw)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    results = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_host_solvers, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+        assert p.exitcode == 0
+    for rank in range(world):
+        r = results[rank]["davidson"]
+        assert r["niter"][0] == r["niter"][1] and r["err"] < 1e-10 * 160 and r["resid"] < 1e-7 and r["hist"] < 1e-6, r
+        for meth, k in results[rank]["krylov"].items():
+            assert k["niter"][0] == k["niter"][1] and k["err"] < 1e-9, (meth, k)
+        assert results[rank]["zero_shard"] < 1e-8
+        b = results[rank]["broyden"]
+        assert b["niter"][0] == b["niter"][1] and b["nfev"][0] == b["nfev"][1] and b["err"] < 1e-9, b

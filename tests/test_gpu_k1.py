@@ -551,6 +551,32 @@ def test_dense_symm_wide_mfma_vs_oracle(dev, B, N, P, form, monkeypatch):
     assert torch.equal(out2[:, :, :N], Y)
 
 
+@pytest.mark.parametrize("B,N,P", [(2, 1152, 9), (1, 2624, 16), (3, 1024, 11)])
+def test_dense_symm_wide_r06_form_padded_storage_and_forms_agree(dev, B, N, P, monkeypatch):
+    """(r06) the shipped K1sw form (opts 9): operators with a padded leading dimension and a batch stride that is not
+    N * lda give the bits of the contiguous copy (the band descriptor spans 64 rows of `lda`), two launches are
+    `torch.equal`, and the three cooperative forms agree to fp32 rounding (different summation orders)."""
+    g = torch.Generator().manual_seed(7 * N + P)
+    R = torch.randn(B, N, N, dtype=torch.float32, generator=g)
+    A = (R + R.transpose(1, 2)).contiguous().to(dev)
+    X = torch.randn(B, P, N, dtype=torch.float32, generator=g).to(dev)
+    big = torch.full((B, N + 3, N + 64), float("nan"), dtype=torch.float32, device=dev)
+    big[:, :N, :N] = A
+    Apad = big[:, :N, :N]
+    assert Apad.stride(-2) == N + 64 and not Apad.is_contiguous() and K.symm_wide_ok(Apad, X)
+    outs = {}
+    for form in (1, 3, 9):
+        monkeypatch.setattr(K, "K1SW_OPTS", form)
+        outs[form] = K.dense_symm_wide(A, X).clone()
+        assert torch.equal(K.dense_symm_wide(A, X), outs[form])
+        assert torch.equal(K.dense_symm_wide(Apad, X), outs[form]), form
+    ref = torch.matmul(X.double().cpu(), A.double().cpu())
+    scale = ref.abs().max().item()
+    for form in (1, 3, 9):
+        assert (outs[form].cpu().double() - ref).abs().max().item() <= 3e-6 * N ** 0.5 * scale
+    assert (outs[9] - outs[3]).abs().max().item() <= 2e-6 * N ** 0.5 * scale
+
+
 @pytest.mark.parametrize("B,N,P", [(2, 2048, 16), (1, 4096, 9), (3, 1088, 12)])
 def test_dense_symm_wide_resident_launch_is_bit_identical(dev, B, N, P, monkeypatch):
     """(r05) the resident form of the cooperative K1sw launch (opts bit 2: workgroups take the super-tiles from a queue,
