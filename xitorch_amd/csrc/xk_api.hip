@@ -17,7 +17,8 @@ extern "C" int xk_abi_version(void) { return 1; }
 // driver deals the linear mask out over the XCDs bit by bit, so pattern 0 takes reserve / 8 units from every XCD, pattern 1
 // all of them from one XCD — and a mask that leaves an XCD without any unit is not honoured (all units stay usable).
 extern "C" int xk_stream_create_cu_masked_pattern(int device, int reserve_cus, int pattern, void** stream_out) {
-  if (!stream_out || reserve_cus < 0 || pattern < 0 || pattern > 1) return XK_ERR_ARG;
+  if (!stream_out || reserve_cus < 0 || pattern < 0 || pattern > 2) return XK_ERR_ARG;
+  if (pattern == 2 && reserve_cus == 0) return XK_ERR_ARG;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) return (int)e;
@@ -27,7 +28,12 @@ extern "C" int xk_stream_create_cu_masked_pattern(int device, int reserve_cus, i
   uint32_t mask[64];
   if (nwords > 64) return XK_ERR_UNSUPPORTED;
   for (int w = 0; w < nwords; ++w) mask[w] = 0;
-  if (pattern == 0 || reserve_cus == 0) {
+  if (pattern == 2) {
+    // the COMPLEMENT of pattern 0 (r06): only the `reserve_cus` units that a pattern-0 stream leaves free — for the chain
+    // of a batch group whose panel kernel does not fill the register file of its units (K1sw r06 form: 2 x 202 of 512
+    // registers), so that chain workgroups do not move in beside the panel kernel's
+    for (int cu = ncu - reserve_cus; cu < ncu; ++cu) mask[cu >> 5] |= (1u << (cu & 31));
+  } else if (pattern == 0 || reserve_cus == 0) {
     for (int cu = 0; cu < ncu - reserve_cus; ++cu) mask[cu >> 5] |= (1u << (cu & 31));
   } else {
     const int step = ncu / reserve_cus;                       // clear bit step-1, 2*step-1, ... (reserve_cus of them)

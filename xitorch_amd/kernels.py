@@ -578,7 +578,7 @@ _MASKED_STREAMS = {}
 CU_MASK_PATTERN = int(os.environ.get("XITORCH_AMD_CU_MASK_PATTERN", "0"))
 
 
-def masked_stream(device, reserve_cus=64, slot=0):
+def masked_stream(device, reserve_cus=64, slot=0, only_reserved=False):
     """A process-lifetime HIP stream on `device` that leaves `reserve_cus` compute units unused
     (hipExtStreamCreateWithCUMask), wrapped as a torch stream.  The HBM-bound panel product runs at full
     speed on 192-224 CUs; the CUs it leaves free serve the latency-bound kernels of the other batch half.
@@ -588,8 +588,9 @@ def masked_stream(device, reserve_cus=64, slot=0):
     product" barrier is serialised with it."""
     import ctypes
     device = torch.device(device)
+    # only_reserved (r06): the complement — a stream that may use ONLY the `reserve_cus` units a plain masked stream leaves
     key = (device.index if device.index is not None else torch.cuda.current_device(), int(reserve_cus), int(slot),
-           int(CU_MASK_PATTERN))
+           2 if only_reserved else int(CU_MASK_PATTERN))
     if key not in _MASKED_STREAMS:
         out = ctypes.c_void_p()
         rc = fn("xk_stream_create_cu_masked_pattern")(key[0], key[1], key[3], ctypes.byref(out))
@@ -599,7 +600,7 @@ def masked_stream(device, reserve_cus=64, slot=0):
             atexit.register(_destroy_masked_streams)
         _MASKED_STREAMS[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key[0]))
         total = torch.cuda.get_device_properties(key[0]).multi_processor_count
-        _STREAM_CUS[(key[0], out.value)] = max(1, total - key[1])
+        _STREAM_CUS[(key[0], out.value)] = max(1, key[1] if key[3] == 2 else total - key[1])
     return _MASKED_STREAMS[key]
 
 

@@ -38,6 +38,8 @@ __all__ = ["davidson", "exacteig", "take_eigpairs", "tallqr_extend", "native_par
 _PRELAUNCH = True          # enqueue the next group's chain early (module attribute: measurement scripts flip it for A/B)
 # largest basis the global-memory Rayleigh-Ritz solver (K3g, tridiagonalisation spread over several workgroups per
 # matrix: xk_eigh_big.hip) serves before the library takes over (>= 16 matrices per group, fewer)
+CHAIN_CUS = "all"             # units of the chain streams in the two-group pipeline: "all" | "reserved" (only the units the
+                              # panel stream's mask leaves) | "auto" (measurement knob, scripts/timeline_gaps.py)
 K3G_MAX_K = [1024, 1024]      # (the library decides: small_eigh_big_ok)
 
 
@@ -697,7 +699,14 @@ def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, 
     grp_streams, k1_streams, k1_sched = None, [None], None
     if two:
         try:
-            grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
+            chain_reserved = CHAIN_CUS == "reserved" or (CHAIN_CUS == "auto" and wide_symm and bool(K.K1SW_OPTS & 8))
+            if chain_reserved and reserve_cus > 0:
+                # (r06) the K1sw r06 form leaves ~100 registers per lane and 58 KB of LDS free on its units: chain
+                # workgroups that move in beside it cost the panel kernel more than they gain — the chain streams get
+                # the units the panel stream leaves, and only those
+                grp_streams = [K.masked_stream(device, reserve_cus, slot=1 + g, only_reserved=True) for g in range(ngrp)]
+            else:
+                grp_streams = [K.masked_stream(device, 0, slot=1 + g) for g in range(ngrp)]
             k1_stream = K.masked_stream(device, reserve_cus)
             # Resident K1s launches (kernels.K1S_PERSIST): every group's panel product gets its own CU-masked stream.
             # A resident launch holds every workgroup slot of the masked units until its run queue is empty, so the
