@@ -502,7 +502,10 @@ __global__ __launch_bounds__(256, 3) void dense_symm_wide7_kernel(
 #ifndef XK_SW8_PRIO
 #define XK_SW8_PRIO 0      // 1: s_setprio 1 around the MFMA blocks (trial builds, scripts/k1sw_r06.py)
 #endif
-constexpr int SW8_RING = 4;                        // blocks (16 rows x 64 columns, four 1 KB loads) in flight per wave
+// blocks (16 rows x 64 columns, four 1 KB loads) in flight per wave.  (A ring of 6 — 24 KB per wave — was built in r06 with
+// the band body instantiated three times, a band having 8 blocks and the ring index having to be static: 256 registers
+// and 346 spills inside the stream; not kept.)
+constexpr int SW8_RING = 4;
 constexpr int SW8_PITCH = XK_SW8_SWZ ? 256 : 272;  // bytes per LDS row of a block (16 slots of 16 B)
 constexpr int SW8_BUF = 16 * 272;                  // 4352 B: one block in row layout
 constexpr int SW8_PARK = 4 * 64 * 16;              // the band's four row-sum blocks of this wave (4096 B)
@@ -600,13 +603,15 @@ __global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
   auto live_of = [&](int row0, int g) { const int c0 = cg0 + 256 * g; return (c0 >= row0) && (c0 < N); };
   auto both_of = [&](int row0, int g) { const int c0 = cg0 + 256 * g; return (c0 >= row0 + SW_ROWS) && (c0 < N); };
 
-  sw_f32x4 ring[SW8_RING][4];
-  sw_f32x4 xi[4], xin[4];
+  constexpr int RING = SW8_RING;
+  static_assert(8 % RING == 0, "a band has 8 blocks: the ring index must be static");
+  sw_f32x4 ring[RING][4];
+  sw_f32x4 xi[4];
   {
     const SwRsrc r0 = band_rsrc(r_begin);
     load_xi(xi, r_begin);
 #pragma unroll
-    for (int j = 0; j < SW8_RING; ++j)
+    for (int j = 0; j < RING; ++j)
       issue(ring[j], r0, live_of(r_begin, j & 1) ? lane_off : POISON, j);
   }
   for (int row0 = r_begin; row0 < r_end; row0 += SW_ROWS) {
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
       }
       if (j < 8) {
         const int i = j >> 1, g = j & 1;
-        sw_f32x4(&blk)[4] = ring[j & (SW8_RING - 1)];
+        sw_f32x4(&blk)[4] = ring[j % RING];
         if (live[g]) {
           // ---- (2) block j into LDS: lane (n, q), load s -> row 4 q + s, slot n
           char* wb = wbase + (j & 1) * SW8_BUF;
@@ -669,10 +674,13 @@ __global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        // ---- (4) the ring slot is free: block j + 4 (of this band, or of the next one)
-        if (j + SW8_RING < 8) issue(blk, ra, vo[(j + SW8_RING) & 1], j + SW8_RING);
-        else issue(blk, rn, von[(j + SW8_RING) & 1], j + SW8_RING - 8);
-        if (j == 3 && more) load_xi(xin, rown);      // (before the next band's blocks enter the in-order queue)
+        // ---- (4) the ring slot is free: block j + RING (of this band, or of the next one)
+        if (j + RING < 8) issue(blk, ra, vo[(j + RING) & 1], j + RING);
+        else issue(blk, rn, von[(j + RING) & 1], j + RING - 8);
+        // x_I of row block i is dead after the column MFMAs of its second block: the next band's goes straight into the
+        // same registers.  In the in-order load queue it sits before the next band's block 2 i (issued RING - 2 steps from
+        // now), which is the block that needs it: no wait is added, no second buffer needed.
+        if (g == 1) xi[i] = *reinterpret_cast<const sw_f32x4*>(Xc + rown + 16 * i + 4 * kq);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- (5) row part of block j - 1: k-steps (u, e), two alternating accumulator chains
@@ -721,8 +729,6 @@ __global__ __launch_bounds__(256, 2) void dense_symm_wide8_kernel(
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xi[i] = xin[i];
   }
   // ---- the tile's column sums: lane (n, q), accumulator e, register r = panel 4 q + r, column cg + 4 n + e
 #pragma unroll
