@@ -457,6 +457,55 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
                 assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
 
 
+@pytest.mark.parametrize("B,k,p,uppest,dtype", [(2, 8, 3, False, torch.float64), (2, 35, 4, False, torch.float64),
+                                                (3, 130, 6, False, torch.float64), (2, 200, 6, True, torch.float64),
+                                                (2, 256, 6, False, torch.float64), (2, 257, 6, False, torch.float64),
+                                                (2, 333, 4, False, torch.float64), (1, 400, 6, True, torch.float64),
+                                                (2, 128, 16, False, torch.float32), (2, 384, 6, False, torch.float32),
+                                                (1, 500, 6, False, torch.float32), (33, 150, 6, False, torch.float64),
+                                                (2, 192, 40, True, torch.float64), (1, 64, 6, False, torch.float64)])
+def test_small_eigh_big_persistent_vs_lapack(dev, B, k, p, uppest, dtype):
+    """K3g in its persistent form (r06, algo = 3: the trailing block of order <= 256 (fp64) / 384 (fp32) in the registers
+    of ONE workgroup per matrix, one launch for the whole Householder reduction; larger orders start with step launches
+    and hand over) against LAPACK like the other forms: eigenvalues, residual, orthonormality, bit-reproducible; orders
+    around the register limit, the hand-over with several workgroup counts of the step launches."""
+    assert K.small_eigh_big_ok(k, p, dtype)
+    g = torch.Generator().manual_seed(k + p)
+    cap = k + 5
+    limit = 256 if dtype == torch.float64 else 384
+    for kind in ("ritz", "random"):
+        if kind == "ritz":
+            Q, _ = torch.linalg.qr(torch.randn(B, k, k, dtype=torch.float64, generator=g))
+            d = torch.cat([torch.arange(1.0, 9.0, dtype=torch.float64)[:min(8, k - 1)],
+                           50.0 + 50.0 * torch.arange(k - min(8, k - 1), dtype=torch.float64) / (k - 8 if k > 8 else 1)])
+            Tm = Q @ torch.diag_embed(d.expand(B, k)) @ Q.transpose(-2, -1)
+        else:
+            R = torch.randn(B, k, k, dtype=torch.float64, generator=g)
+            Tm = R + R.transpose(-2, -1)
+        Tm = (Tm + Tm.transpose(-2, -1)) * 0.5
+        lam_ref = torch.linalg.eigvalsh(Tm)
+        buf = torch.full((B, cap, cap), float("nan"), dtype=dtype)
+        buf[:, :k, :k] = torch.tril(Tm).to(dtype) + torch.triu(torch.full((k, k), float("nan"), dtype=dtype), 1)
+        dbuf = buf.to(dev)
+        for W in ((0,) if k <= limit else (0, 3, 8)):
+            tag = (kind, W)
+            lam, Y, info = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, algo=3)
+            lam2, Y2, _ = K.small_eigh_big(dbuf, k, p, uppest=uppest, wg=W, algo=3)
+            assert torch.equal(lam, lam2) and torch.equal(Y, Y2), tag
+            assert int(info.max()) == 0, tag
+            lam, Y = lam.cpu().double(), Y.cpu().double()
+            sl = slice(k - p, k) if uppest else slice(0, p)
+            tol = 1e-12 if dtype == torch.float64 else 3e-5
+            scale = lam_ref.abs().max().item()
+            assert (lam - lam_ref[:, sl]).abs().max().item() < tol * scale * 10, tag
+            assert torch.all(lam[:, 1:] >= lam[:, :-1])
+            Yc = Y.transpose(-2, -1)
+            res = torch.matmul(Tm, Yc) - Yc * lam.unsqueeze(-2)
+            assert res.abs().max().item() < tol * scale * 100, tag
+            G = torch.matmul(Yc.transpose(-2, -1), Yc)
+            assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
+
+
 @pytest.mark.parametrize("B,k,p,uppest,dtype", [(2, 35, 4, False, torch.float64), (3, 130, 6, False, torch.float64),
                                                 (2, 200, 6, True, torch.float64), (2, 333, 4, False, torch.float64),
                                                 (2, 512, 6, False, torch.float64), (1, 582, 6, False, torch.float64),

@@ -32,6 +32,7 @@
 // (8 -> 7.4 ms at 582).  Inside the Davidson pipeline the step kernels share the chip with the panel stream (64 CUs
 // left): 15.6 ms at order 582 there (scripts/s2_timeline.py).
 #include "xk_common.h"
+#include "xk_tridiag.h"
 
 namespace xk {
 
@@ -71,19 +72,6 @@ __device__ __forceinline__ T dist_get(const T (&v)[NT], int r) {
   return out;
 }
 
-template <typename T>
-__device__ __forceinline__ int big_sturm(const T* __restrict__ dd, const T* __restrict__ e2, int n, T sigma, T pivmin) {
-  T q = dd[0] - sigma;
-  if (fabs(q) < pivmin) q = -pivmin;
-  int cnt = q < T(0) ? 1 : 0;
-  for (int i = 1; i < n; ++i) {
-    q = dd[i] - sigma - e2[i - 1] * big_rcp(q);
-    if (fabs(q) < pivmin) q = -pivmin;
-    cnt += q < T(0) ? 1 : 0;
-  }
-  return cnt;
-}
-
 __device__ __forceinline__ unsigned big_hash(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
@@ -119,7 +107,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     const T* ab = aux + (long)b * aux_stride;
     for (int i = tid; i < n; i += nt) {
       T d = ab[i], e = ab[n + i], tv = mode == 1 ? T(0) : ab[2 * n + i];
-      if (mode != 1) {
+      if (mode == 0) {                                  // (mode 2, the persistent kernel: d, e, tau are complete)
         if (i == n - 1) { d = S[(long)(n - 1) * n + (n - 1)]; e = T(0); tv = T(0); }
         if (i == n - 2) { e = ab[3 * n + (long)((n - 2) & 1) * n + (n - 1)]; tv = T(0); }
       }
@@ -129,6 +117,15 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     __syncthreads();
   }
 
+#ifdef XK_FINAL_DBG
+  long long tph[6]; int iph = 0; tph[iph++] = __builtin_readcyclecounter();
+#define XK_FSTAMP() { __syncthreads(); tph[iph++] = __builtin_readcyclecounter(); }
+  long long tLU = 0, tSOL = 0, tGS = 0, ti0 = 0;
+#define XK_ISTAMP(acc) { const long long t1_ = __builtin_readcyclecounter(); acc += t1_ - ti0; ti0 = t1_; }
+#else
+#define XK_FSTAMP()
+#define XK_ISTAMP(acc)
+#endif
   // ---- 2. bisection: wave w -> wanted eigenvalue number w (ascending) ---------------------------------
   T gl = T(INFINITY), gu = T(-INFINITY), emax = T(0);
   for (int i = lane; i < n; i += 64) {
@@ -144,27 +141,16 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   const T pivmin = BigEps<T>::tiny * fmax(T(1), emax);
   for (int w = wave; w < p; w += nw) {
     const int target = (uppest ? n - p + w : w) + 1;
-    T lo = gl - (T(2) * eps * tnorm * n + T(2) * pivmin);
-    T hi = gu + (T(2) * eps * tnorm * n + T(2) * pivmin);
-    for (int round = 0; round < 24; ++round) {
-      const T width = hi - lo;
-      if (!(width > T(2) * eps * fmax(fabs(lo), fabs(hi)) + T(2) * pivmin)) break;
-      const T sig = lo + width * (T(lane + 1) / T(65));
-      const int c = big_sturm(dd, e2, n, sig, pivmin);
-      const unsigned long long ge = __ballot(c >= target);
-      const int f = ge ? __ffsll((long long)ge) - 1 : 64;
-      const T sig_f = __shfl(sig, f < 64 ? f : 63, 64);
-      const T sig_fm = __shfl(sig, f > 0 ? f - 1 : 0, 64);
-      const T nlo = f > 0 ? sig_fm : lo;
-      const T nhi = f < 64 ? sig_f : hi;
-      if (!(nhi > nlo)) break;
-      lo = nlo; hi = nhi;
-    }
-    if (lane == 0) lamv[w] = T(0.5) * (lo + hi);
+    const T lamw = tri_bisect_wave<T>(dd, e2, n, target, gl, gu, tnorm, pivmin, eps, lane);   // (xk_tridiag.h)
+    if (lane == 0) lamv[w] = lamw;
   }
   if (tid == 0) red[15] = T(0);                       // "an iterate was annihilated / non-finite" flag of step 3
   __syncthreads();
   if (stop_after == 2) return;                        // (measurement hook: results are wrong by construction)
+  XK_FSTAMP()
+#ifdef XK_FINAL_DBG
+  ti0 = __builtin_readcyclecounter();
+#endif
 
   // ---- 3. inverse iteration (dstein), vectors in order, pb shifts factorised at a time -----------------
   // One thread per shift runs the sequential recurrences; what they cost is LDS round trips, so (a) the LU streams:
@@ -187,24 +173,32 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       T* du2 = lu + ((long)3 * n) * pb + jl;
       T* sw = lu + ((long)4 * n) * pb + jl;           // 1 = rows i, i + 1 were swapped
       T dcur = dd[0] - shift, ucur = n > 1 ? ee[0] : T(0);
-      for (int i = 0; i + 1 < n; ++i) {               // LU with partial pivoting (dgttrf), row i in (dcur, ucur)
-        const T li = ee[i];
-        const T dn = dd[i + 1] - shift;
-        const T un = (i + 2 < n) ? ee[i + 1] : T(0);
-        if (fabs(dcur) >= fabs(li)) {
-          if (fabs(dcur) < pfloor) dcur = dcur < T(0) ? -pfloor : pfloor;
-          const T inv = big_rcp(dcur);
-          const T fact = li * inv;
-          AT(dl, i) = fact; AT(dg, i) = inv; AT(du, i) = ucur; AT(du2, i) = T(0); AT(sw, i) = T(0);
-          dcur = dn - fact * ucur;
-          ucur = un;
-        } else {
-          const T inv = big_rcp(li);
-          const T fact = dcur * inv;
-          AT(dl, i) = fact; AT(dg, i) = inv; AT(du, i) = dn; AT(du2, i) = un; AT(sw, i) = T(1);
-          dcur = ucur - fact * dn;
-          ucur = -fact * un;
+      // LU with partial pivoting (dgttrf), row i in (dcur, ucur); the (d, e) of eight rows are fetched before their chain
+      // (branch-free: the lanes of the shifts take different pivots, and a divergent branch runs both sides)
+      auto lu_row = [&](int i, T li, T dn, T un) {
+        const bool keep = fabs(dcur) >= fabs(li);       // no interchange
+        T piv = keep ? dcur : li;
+        if (keep && fabs(piv) < pfloor) piv = piv < T(0) ? -pfloor : pfloor;
+        const T inv = big_rcp(piv);
+        const T fact = (keep ? li : dcur) * inv;
+        const T up = keep ? ucur : dn;                  // row i of U: (1 / inv, up, up2)
+        AT(dl, i) = fact; AT(dg, i) = inv; AT(du, i) = up; AT(du2, i) = keep ? T(0) : un; AT(sw, i) = keep ? T(0) : T(1);
+        dcur = (keep ? dn : ucur) - fact * up;
+        ucur = keep ? un : -fact * un;
+      };
+      {
+        constexpr int LU = 8;
+        int i = 0;
+        for (; i + LU + 1 < n; i += LU) {                 // rows i .. i + 7 read e[i .. i + 8], d[i + 1 .. i + 8]
+          T ev[LU + 1], dv[LU];
+#pragma unroll
+          for (int u = 0; u <= LU; ++u) ev[u] = ee[i + u];
+#pragma unroll
+          for (int u = 0; u < LU; ++u) dv[u] = dd[i + 1 + u] - shift;
+#pragma unroll
+          for (int u = 0; u < LU; ++u) lu_row(i + u, ev[u], dv[u], ev[u + 1]);
         }
+        for (; i + 1 < n; ++i) lu_row(i, ee[i], dd[i + 1] - shift, (i + 2 < n) ? ee[i + 1] : T(0));
       }
       if (fabs(dcur) < pfloor) dcur = dcur < T(0) ? -pfloor : pfloor;
       AT(dg, n - 1) = big_rcp(dcur);
@@ -215,6 +209,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
       }
     }
     __syncthreads();
+    XK_ISTAMP(tLU)
     for (int it = 0; it < 3; ++it) {
       if (tid < nb) {
         const int jl = tid;
@@ -272,38 +267,62 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
         }
       }
       __syncthreads();
+      XK_ISTAMP(tSOL)
       // scaling by the largest entry, modified Gram–Schmidt against ALL earlier vectors (finished batches and this
       // batch) and normalisation: wave 0, vectors in order
       if (wave == 0) {
+        // (the vector stays in registers, lane l <-> elements l + 64 t: one LDS read and one write per vector instead of
+        // one pass through LDS per operation)
         for (int j = j0; j < j0 + nb; ++j) {
           T* zj = Zb + (long)(j - j0) * n;
+          T zr[NT];
           T mx = T(0);
-          for (int i = lane; i < n; i += 64) mx = fmax(mx, fabs(zj[i]));
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int i = lane + 64 * t;
+            zr[t] = i < n ? zj[i] : T(0);
+            mx = fmax(mx, fabs(zr[t]));
+          }
           mx = wave_max(mx);
           const T sc = (mx > T(0) && mx < T(INFINITY)) ? T(1) / mx : T(1);
-          for (int i = lane; i < n; i += 64) zj[i] *= sc;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) zr[t] *= sc;
           for (int q = j - 1; q >= 0; --q) {
             const T* zq = q >= j0 ? Zb + (long)(q - j0) * n : Yg + (long)q * n;
+            T qv[NT];
             T dp = T(0);
-            for (int i = lane; i < n; i += 64) dp += zq[i] * zj[i];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const int i = lane + 64 * t;
+              qv[t] = i < n ? zq[i] : T(0);
+              dp += qv[t] * zr[t];
+            }
             dp = wave_sum_dpp(dp);
-            for (int i = lane; i < n; i += 64) zj[i] -= dp * zq[i];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) zr[t] -= dp * qv[t];
           }
           T nn = T(0);
-          for (int i = lane; i < n; i += 64) nn += zj[i] * zj[i];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) nn += zr[t] * zr[t];
           nn = wave_sum_dpp(nn);
           const T inv = nn > T(0) ? rsqrt(nn) : T(0);
           if (lane == 0 && it == 2 && !(nn > T(0) && nn < T(INFINITY))) red[15] = T(1);
-          for (int i = lane; i < n; i += 64) zj[i] *= inv;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int i = lane + 64 * t;
+            if (i < n) zj[i] = zr[t] * inv;
+          }
         }
       }
       __syncthreads();
+      XK_ISTAMP(tGS)
     }
     for (int idx = tid; idx < nb * n; idx += nt) Yg[(long)j0 * n + idx] = Zb[idx];     // rows j0 .. j0 + nb - 1
     __syncthreads();
   }
 #undef AT
   if (stop_after == 3) return;
+  XK_FSTAMP()
 
   // ---- 5. checks on the tridiagonal level ----------------------------------------------------------------
   if (wave == 0) {
@@ -342,6 +361,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   __syncthreads();
 
   if (stop_after == 5) return;
+  XK_FSTAMP()
   if (mode == 1) {                                    // the vectors of (d, e) stay in the rows of Y_out
     for (int j = tid; j < p; j += nt) lam_out[(long)b * p + j] = lamv[j];
     return;
@@ -349,42 +369,76 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
   // ---- 4. back-transformation y = H_0 ... H_{n-3} z, one wave per vector, next reflector prefetched -------
   for (int j = wave; j < p; j += nw) {
     const T* zj = Yg + (long)j * n;
-    T y[NT], vn[NT];
+    T y[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int i = lane + 64 * t;
       y[t] = i < n ? zj[i] : T(0);
     }
+    // the reflectors of the next DEPTH steps are in flight while one is applied (each is a trip to L2).  The loads are
+    // UNCONDITIONAL (clamped addresses, the mask applied where the value is used): a load under a lane mask makes the
+    // compiler wait for vmcnt(0) at every use, i.e. for the reflector just requested — 1500 cycles per reflector
+    // whatever the depth (profiles/r06_k3_final_phases.json)
+    constexpr int DEPTH = NT <= 8 ? 4 : 2;                  // (registers: DEPTH x NT values per lane)
+    T vq[DEPTH][NT];
+    int ic[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ic[t] = lane + 64 * t < n ? lane + 64 * t : n - 1;
+    auto fetch = [&](int rr, T (&dst)[NT]) {
+      const T* row = S + (long)(rr < 0 ? 0 : rr) * n;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dst[t] = row[ic[t]];
+    };
     int r = n - 3;
-    if (r >= 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int i = lane + 64 * t;
-        vn[t] = (i < n && i > r + 1) ? S[(long)r * n + i] : T(0);
-      }
-    }
-    for (; r >= 0; --r) {
-      T vc[NT];
+    for (int u = 0; u < DEPTH; ++u) fetch(r - u, vq[u]);
+    // Two reflectors per trip: the dots of both with y and their mutual dot go through the wave reduction TOGETHER
+    // (d_b = v_b.y - tau_a (v_a.y) (v_a.v_b)), so the dependent chain  dot -> reduction -> update  is paid once per pair
+    for (; r >= 0; r -= DEPTH) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int i = lane + 64 * t;
-        vc[t] = (i == r + 1) ? T(1) : vn[t];        // v_r: rows <= r are 0, row r+1 is 1, rows > r+1 parked in row r
-      }
-      if (r > 0) {
+      for (int u = 0; u < DEPTH; u += 2) {
+        const int ra = r - u, rb = ra - 1;
+        // v_r: rows <= r are 0, row r+1 is 1, rows > r+1 parked in row r.  Column slots entirely at or below row r are
+        // skipped (uniform), slots entirely above row r+1 and inside the matrix need no mask
+        T va[NT], vb[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+          va[t] = T(0); vb[t] = T(0);
           const int i = lane + 64 * t;
-          vn[t] = (i < n && i > r) ? S[(long)(r - 1) * n + i] : T(0);
+          if (64 * t + 63 > ra) {
+            if (64 * t > ra + 1 && 64 * t + 63 < n) va[t] = vq[u][t];
+            else va[t] = (i == ra + 1) ? T(1) : ((i > ra + 1 && i < n) ? vq[u][t] : T(0));
+          }
+          if (64 * t + 63 > rb) {
+            if (64 * t > rb + 1 && 64 * t + 63 < n) vb[t] = vq[u + 1][t];
+            else vb[t] = (i == rb + 1) ? T(1) : ((i > rb + 1 && i < n) ? vq[u + 1][t] : T(0));
+          }
         }
+        fetch(ra - DEPTH, vq[u]);
+        fetch(rb - DEPTH, vq[u + 1]);
+        const T ta = ra >= 0 ? tau[ra] : T(0);
+        const T tb = rb >= 0 ? tau[rb] : T(0);
+        T da = T(0), db = T(0), cc = T(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (64 * t + 63 > rb) {                            // (slots dead for b are dead for a)
+            da += va[t] * y[t];
+            db += vb[t] * y[t];
+            cc += va[t] * vb[t];
+          }
+        }
+        T red3[4] = {da, db, cc, T(0)};
+        wave_reduce_scatter<T, 4>(red3, lane);               // lane groups by bits 5, 4 hold the total of index 0 .. 3
+        const T tot = red3[0];
+        da = big_readlane(tot, 0);                           // index = bit5 + 2 bit4 of the lane
+        db = big_readlane(tot, 32);
+        cc = big_readlane(tot, 16);
+        const T fa = ta * da;
+        const T fb = tb * (db - fa * cc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (64 * t + 63 > rb) y[t] -= fa * va[t] + fb * vb[t];
       }
-      const T tr = tau[r];
-      if (tr == T(0)) continue;
-      T dp = T(0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) dp += vc[t] * y[t];
-      dp = wave_sum_dpp(dp);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) y[t] -= tr * dp * vc[t];
     }
     T* Yb = Y_out + ((long)b * p + j) * n;
 #pragma unroll
@@ -394,6 +448,12 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     }
     if (lane == 0) lam_out[(long)b * p + j] = lamv[j];
   }
+#ifdef XK_FINAL_DBG
+  XK_FSTAMP()
+  if (b == 0 && tid == 0)
+    printf("final n=%d p=%d pb=%d cycles: bisect %lld inviter %lld (LU %lld solves %lld GS %lld) check %lld backtr %lld\n", n, p, pb,
+           tph[1] - tph[0], tph[2] - tph[1], tLU, tSOL, tGS, tph[3] - tph[2], tph[4] - tph[3]);
+#endif
 }
 
 
@@ -659,6 +719,9 @@ extern "C" int xk_debug_small_eigh_big(int what, int value) {
 #define XK_BIG_SKIP 0
 #endif
 
+#ifndef XK_PERSIST_EXTRA
+#define XK_PERSIST_EXTRA 128          // orders up to this far beyond the register-resident limit start with step launches
+#endif
 namespace xk {
 // the two-stage form (xk_eigh_band.hip)
 long band_ws_elems(int k);
@@ -667,10 +730,25 @@ template <typename T>
 int band_tridiag(const T* Tin, T* S, T* aux, long aux_stride, T* bws, int B, int k, long ldt, long sT, hipStream_t st);
 template <typename T>
 int band_back(T* Y, T* bws, int B, int k, int p, hipStream_t st);
+// the persistent one-workgroup form (xk_eigh_persist.hip)
+int persist_max_order(int elem_size);
+int persist_base(int k, int elem_size);
+template <typename T>
+int persist_tridiag(const T* Tin, T* S, T* aux, long aux_stride, int B, int k, int base, int W, long ldt, long sT,
+                    hipStream_t st);
 
-// which form serves order k (algo: 0 = the measured choice, 1 = one launch per Householder step, 2 = two-stage)
+// which form serves order k (algo: 0 = the measured choice, 1 = one launch per Householder step, 2 = two-stage,
+// 3 = step launches down to the order the persistent kernel holds in registers, then that kernel)
+static bool big_persist(int B, int k, int elem_size, int algo) {
+  if (algo == 3) return true;
+  if (algo != 0) return false;
+  // measured (profiles/r06_k3p_orders.jsonl; fp64, 1 / 4 / 32 matrices): ahead of both other forms up to the register limit
+  // (256 / 384) at every batch; beyond it, where the first steps are step launches, up to +128 for a few matrices (order
+  // 384: 3.31 vs 3.39 ms two-stage at 1 matrix, 4.19 vs 3.76 at 32) and up to +64 for many (order 330 x 32: 3.06 vs 3.08)
+  return k <= persist_max_order(elem_size) + (B <= 8 ? XK_PERSIST_EXTRA : XK_PERSIST_EXTRA / 2);
+}
 static bool big_two_stage(int k, int elem_size, int algo) {
-  if (algo == 1 || !band_supported(k, elem_size)) return false;
+  if (algo == 1 || algo == 3 || !band_supported(k, elem_size)) return false;
   // measured (profiles/r04_k3g_two_stage.jsonl): ahead from order 192 on for 1 .. 32 matrices, fp64 and fp32
   return algo == 2 || k >= 192;
 }
@@ -724,6 +802,18 @@ static int big_launch_final(T* ws, const T* aux, long aux_stride, T* lam, T* Y, 
   return XK_OK;
 }
 
+// the final kernel with the fewest 64-column slots that hold order k (its back-transformation is priced in slots)
+template <typename T>
+static int big_launch_final_nt(T* ws, const T* aux, long aux_stride, T* lam, T* Y, int* info, int B, int k, int p, int pb,
+                               int uppest, long lds, int mode, hipStream_t st) {
+  if (k <= 128) return big_launch_final<T, 2>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+  if (k <= 256) return big_launch_final<T, 4>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+  if (k <= 384) return big_launch_final<T, 6>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+  if (k <= 512) return big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+  if (k <= 768) return big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+  return big_launch_final<T, 16>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+}
+
 template <typename T>
 static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k, int p, int uppest,
                    long ldt, long sT, int wg, int nt, int algo, hipStream_t st) {
@@ -735,12 +825,29 @@ static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, 
   const long aux_stride = (long)k * (7 + 2 * W);
   if (ws == nullptr || ws_elems < (long)B * k * k + (long)B * aux_stride) return XK_ERR_ARG;
   T* aux = ws + (long)B * k * k;
+  if (big_persist(B, k, (int)sizeof(T), algo)) {
+    const int base = persist_base(k, (int)sizeof(T));
+    for (int j = -1; j <= base - 2; ++j) {
+      const int m2 = k - (j + 2);
+      if (m2 <= 128) big_launch_step<T, 2>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+      else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+      else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+      else if (m2 <= 768) big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+      else big_launch_step<T, 16>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    }
+    int rc = persist_tridiag<T>(Tin, ws, aux, aux_stride, B, k, base, W, ldt, sT, st);
+    if (rc != XK_OK) return rc;
+    rc = big_launch_final_nt<T>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 2, st);
+    if (rc != XK_OK) return rc;
+    XK_LAUNCH_CHECK();
+    return XK_OK;
+  }
   if (big_two_stage(k, (int)sizeof(T), algo)) {
     if (ws_elems < (long)B * k * k + (long)B * aux_stride + (long)B * band_ws_elems(k)) return XK_ERR_ARG;
     T* bws = aux + (long)B * aux_stride;
     int rc = band_tridiag<T>(Tin, ws, aux, aux_stride, bws, B, k, ldt, sT, st);
     if (rc != XK_OK) return rc;
-    rc = big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 1, st);
+    rc = big_launch_final_nt<T>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 1, st);
     if (rc != XK_OK) return rc;
     XK_LAUNCH_CHECK();
     return band_back<T>(Y, bws, B, k, p, st);
@@ -753,9 +860,7 @@ static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, 
     else if (m2 <= 768) big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
     else big_launch_step<T, 16>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
   }
-  const int rc = k <= 512 ? big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st)
-                 : k <= 768 ? big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st)
-                            : big_launch_final<T, 16>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st);
+  const int rc = big_launch_final_nt<T>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st);
   if (rc != XK_OK) return rc;
   XK_LAUNCH_CHECK();
   return XK_OK;
@@ -788,7 +893,7 @@ long xk_small_eigh_big_workspace_elems(int B, int k, int wg) {
                               void* stream) {                                                                 \
     if (B < 0 || k < 8 || k > 1024 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                  \
     if (wg < 0 || wg > 32 || (threads != 0 && threads != 256 && threads != 512)) return XK_ERR_ARG;           \
-    if (algo < 0 || algo > 2) return XK_ERR_ARG;                                                              \
+    if (algo < 0 || algo > 3) return XK_ERR_ARG;                                                              \
     if (B == 0) return XK_OK;                                                                                 \
     return xk::big_run<T>(Tin, lam, Y, ws, ws_elems, info, B, k, p, uppest, ldt, sT, wg,                      \
                           threads ? threads : 512, algo, (hipStream_t)stream);                                \

@@ -21,6 +21,7 @@
 //
 // Eigenvalues ascending, lowest / uppermost p selected exactly like `_take_eigpairs` (symeig.py:255-264).
 #include "xk_common.h"
+#include "xk_tridiag.h"
 
 namespace xk {
 
@@ -51,19 +52,6 @@ __device__ __forceinline__ float fast_rcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   r = fmaf(fmaf(-x, r, 1.0f), r, r);
   return r;
-}
-
-template <typename T>
-__device__ __forceinline__ int sturm_count(const T* __restrict__ dd, const T* __restrict__ e2, int n, T sigma, T pivmin) {
-  T q = dd[0] - sigma;
-  if (fabs(q) < pivmin) q = -pivmin;
-  int cnt = q < T(0) ? 1 : 0;
-  for (int i = 1; i < n; ++i) {
-    q = dd[i] - sigma - e2[i - 1] * fast_rcp(q);
-    if (fabs(q) < pivmin) q = -pivmin;
-    cnt += q < T(0) ? 1 : 0;
-  }
-  return cnt;
 }
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -211,23 +199,8 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
   const T pivmin = EpsT<T>::tiny * fmax(T(1), emax);
   for (int w = wave; w < p; w += nw) {
     const int target = (uppest ? n - p + w : w) + 1;       // smallest sigma with count(sigma) >= target
-    T lo = gl - (T(2) * eps * tnorm * n + T(2) * pivmin);
-    T hi = gu + (T(2) * eps * tnorm * n + T(2) * pivmin);
-    for (int round = 0; round < 24; ++round) {
-      const T width = hi - lo;
-      if (!(width > T(2) * eps * fmax(fabs(lo), fabs(hi)) + T(2) * pivmin)) break;
-      const T sig = lo + width * (T(lane + 1) / T(65));
-      const int c = sturm_count(dd, e2, n, sig, pivmin);
-      const unsigned long long ge = __ballot(c >= target);
-      const int f = ge ? __ffsll((long long)ge) - 1 : 64;         // first lane whose shift is >= the eigenvalue
-      const T sig_f = __shfl(sig, f < 64 ? f : 63, 64);
-      const T sig_fm = __shfl(sig, f > 0 ? f - 1 : 0, 64);
-      const T nlo = f > 0 ? sig_fm : lo;
-      const T nhi = f < 64 ? sig_f : hi;
-      if (!(nhi > nlo)) break;
-      lo = nlo; hi = nhi;
-    }
-    if (lane == 0) lamv[w] = T(0.5) * (lo + hi);
+    const T lamw = tri_bisect_wave<T>(dd, e2, n, target, gl, gu, tnorm, pivmin, eps, lane);   // (xk_tridiag.h)
+    if (lane == 0) lamv[w] = lamw;
   }
   __syncthreads();
 

@@ -304,7 +304,8 @@ SMALL_EIGH_BIG_MAX_P = 64
 # the PYTHON layer, for measurement scripts; the C ABI itself has no state
 K3G_WG = 0
 K3G_THREADS = 0
-K3G_ALGO = 0          # 0: the library's choice; 1: one launch per Householder step; 2: two-stage (band + bulge chasing)
+K3G_ALGO = 0          # 0: the library's choice; 1: one launch per Householder step; 2: two-stage (band + bulge chasing);
+                      # 3: persistent register-resident kernel (r06; step launches first beyond order 256 / 384)
 
 
 def small_eigh_big_ok(k, p, dtype):
