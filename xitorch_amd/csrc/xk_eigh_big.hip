@@ -400,24 +400,26 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
         const int ra = r - u, rb = ra - 1;
         // v_r: rows <= r are 0, row r+1 is 1, rows > r+1 parked in row r.  Column slots entirely at or below row r are
         // skipped (uniform), slots entirely above row r+1 and inside the matrix need no mask
+        // (a reflector with tau = 0 — none at all past row 0 — is skipped as a whole: its row of S may hold anything)
+        const T ta = ra >= 0 ? tau[ra] : T(0);
+        const T tb = rb >= 0 ? tau[rb] : T(0);
+        const bool la = ta != T(0), lb = tb != T(0);
         T va[NT], vb[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           va[t] = T(0); vb[t] = T(0);
           const int i = lane + 64 * t;
-          if (64 * t + 63 > ra) {
+          if (la && 64 * t + 63 > ra) {
             if (64 * t > ra + 1 && 64 * t + 63 < n) va[t] = vq[u][t];
             else va[t] = (i == ra + 1) ? T(1) : ((i > ra + 1 && i < n) ? vq[u][t] : T(0));
           }
-          if (64 * t + 63 > rb) {
+          if (lb && 64 * t + 63 > rb) {
             if (64 * t > rb + 1 && 64 * t + 63 < n) vb[t] = vq[u + 1][t];
             else vb[t] = (i == rb + 1) ? T(1) : ((i > rb + 1 && i < n) ? vq[u + 1][t] : T(0));
           }
         }
         fetch(ra - DEPTH, vq[u]);
         fetch(rb - DEPTH, vq[u + 1]);
-        const T ta = ra >= 0 ? tau[ra] : T(0);
-        const T tb = rb >= 0 ? tau[rb] : T(0);
         T da = T(0), db = T(0), cc = T(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

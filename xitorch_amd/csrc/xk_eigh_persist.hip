@@ -25,6 +25,7 @@
 // Outputs in the layout xk_eigh_big.hip's final kernel reads in mode 2: d, e, tau complete in the aux block, reflector r
 // parked in row r of the work copy S (columns > r + 1).
 #include "xk_common.h"
+#include <type_traits>
 
 namespace xk {
 
@@ -232,34 +233,51 @@ __global__ __launch_bounds__(512) void tridiag_persist_kernel(
 #pragma unroll
     for (int g = 0; g < NT; ++g) {
       const int ib = wave + 64 * g;                         // relative rows ib + 8 r of this group
-      if (ib + 56 < r2 || ib >= nrel) continue;             // (whole group dead or beyond the matrix: uniform)
+      // rows ib + 8 r >= r2 are alive: r >= rmin, entered through ONE scalar jump per group (rows past the matrix hold
+      // zeros and meet zero reflector entries: they cost instructions in the last group only and change nothing)
+      const int rmin = r2 > ib ? (r2 - ib + 7) >> 3 : 0;
+      if (rmin > 7 || ib >= nrel) continue;                 // (whole group dead or beyond the matrix: uniform)
       T rs[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int i = ib + 8 * r;
-        rs[r] = T(0);
-        if (i >= r2 && i < nrel) {                          // (uniform)
-          const int ln = wave + 8 * r;                      // lane of column i inside slot g
-          const T vi = per_readlane(v[g], ln), qi = per_readlane(q[g], ln), vNi = per_readlane(vN[g], ln);
-          T racc = T(0);
+      for (int r = 0; r < 8; ++r) rs[r] = T(0);
+      auto row = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const int ln = wave + 8 * r;                        // lane of column i inside slot g
+        const T vi = per_readlane(v[g], ln), qi = per_readlane(q[g], ln), vNi = per_readlane(vN[g], ln);
+        T racc = T(0);
+        if (lane >= ln) {                                   // the diagonal slot: columns left of the diagonal are not stored
+          T an = fma(-vi, q[g], A[g][r][g]);
+          an = fma(-qi, v[g], an);
+          A[g][r][g] = an;
+          acc[g] = fma(an, vNi, acc[g]);                    // column form: (A v)(c) += a(i, c) v(i), c >= i
+          if (lane > ln) racc = an * vN[g];                 // row form:    (A v)(i) += a(i, c) v(c), c > i
+        }
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (t >= g) {
-              T an = A[g][r][t] - (vi * q[t] + qi * v[t]);
-              if (t == g) an = lane >= ln ? an : T(0);      // (columns left of the diagonal are not stored)
-              A[g][r][t] = an;
-              acc[t] += an * vNi;                           // column form: (A v)(c) += a(i, c) v(i), c >= i
-              const T pr = an * vN[t];                      // row form:    (A v)(i) += a(i, c) v(c), c > i
-              racc += (t == g && lane == ln) ? T(0) : pr;
-            }
-          }
-          rs[r] = racc;
-          if (i == r2) {                                    // the next step's row j + 1
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-              if (t >= g) Srow[nxt][lane + 64 * t] = A[g][r][t];
+        for (int t = 0; t < NT; ++t) {
+          if (t > g) {
+            T an = fma(-vi, q[t], A[g][r][t]);
+            an = fma(-qi, v[t], an);
+            A[g][r][t] = an;
+            acc[t] = fma(an, vNi, acc[t]);
+            racc = fma(an, vN[t], racc);
           }
         }
+        rs[r] = racc;
+        if (ib + 8 * r == r2) {                             // the next step's row j + 1
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (t >= g) Srow[nxt][lane + 64 * t] = A[g][r][t];
+        }
+      };
+      switch (rmin) {
+        case 0: row(std::integral_constant<int, 0>{}); [[fallthrough]];
+        case 1: row(std::integral_constant<int, 1>{}); [[fallthrough]];
+        case 2: row(std::integral_constant<int, 2>{}); [[fallthrough]];
+        case 3: row(std::integral_constant<int, 3>{}); [[fallthrough]];
+        case 4: row(std::integral_constant<int, 4>{}); [[fallthrough]];
+        case 5: row(std::integral_constant<int, 5>{}); [[fallthrough]];
+        case 6: row(std::integral_constant<int, 6>{}); [[fallthrough]];
+        default: row(std::integral_constant<int, 7>{});
       }
       wave_reduce_scatter<T, 8>(rs, lane);
       if (wave_rs_is_writer<8>(lane)) Rl[nxt][ib + 8 * wave_rs_orig_index<8>(0, lane)] = rs[0];

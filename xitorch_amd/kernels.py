@@ -304,7 +304,8 @@ SMALL_EIGH_BIG_MAX_P = 64
 # the PYTHON layer, for measurement scripts; the C ABI itself has no state
 K3G_WG = 0
 K3G_THREADS = 0
-K3G_ALGO = 0          # 0: the library's choice; 1: one launch per Householder step; 2: two-stage (band + bulge chasing);
+K3G_ALGO = int(os.environ.get("XITORCH_K3G_ALGO", "0"))   # (the environment variable is a measurement knob)
+                      # 0: the library's choice; -1: the r05 choice; 1: one launch per Householder step; 2: two-stage (band + bulge chasing);
                       # 3: persistent register-resident kernel (r06; step launches first beyond order 256 / 384)
 
 
@@ -331,9 +332,13 @@ def small_eigh_big(T, k, p, uppest=False, wg=None, threads=None, algo=None):
     threads = K3G_THREADS if threads is None else int(threads)
     nws = fn("xk_small_eigh_big_workspace_elems")(B, k, wg)
     ws = _workspace(nws, T.dtype, T.device)
+    algo = K3G_ALGO if algo is None else int(algo)
+    if algo < 0:
+        # measurement knob: the r05 choice (two-stage from order 192 on where its band fits the LDS, else step launches)
+        algo = 2 if k >= 192 and (k <= 614 or T.dtype == torch.float32) else 1
     rc = fn("xk_small_eigh_big_" + suffix(T.dtype))(ptr(T), ptr(lam), ptr(Y), ptr(ws), nws, ptr(info), B, k, p,
                                                      1 if uppest else 0, T.stride(1), T.stride(0), wg, threads,
-                                                     K3G_ALGO if algo is None else int(algo), stream_ptr())
+                                                     algo, stream_ptr())
     check(rc, "xk_small_eigh_big")
     return lam, Y, info
 

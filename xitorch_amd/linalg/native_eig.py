@@ -26,6 +26,7 @@ All numerics run in libxitorch_amd.so (xk_dense_mm, xk_lincomb, xk_ritz_residual
 xk_panel_chol, xk_panel_transform); the only library call is the small k x k `eigh` of T.
 Operators that are not native dense matrices are applied through their own `.mm`.
 """
+import os
 import torch
 from xitorch_amd import kernels as K
 from xitorch_amd._capi import NativeLibraryError
@@ -41,6 +42,8 @@ _PRELAUNCH = True          # enqueue the next group's chain early (module attrib
 CHAIN_CUS = "all"             # units of the chain streams in the two-group pipeline: "all" | "reserved" (only the units the
                               # panel stream's mask leaves) | "auto" (measurement knob, scripts/timeline_gaps.py)
 K3G_MAX_K = [1024, 1024]      # (the library decides: small_eigh_big_ok)
+K3P_MIN_K = int(os.environ.get("XITORCH_K3P_MIN_K", "80"))   # from this order on K3p + K3g's final kernel replace K3t
+                              # (r06; the environment variable is a measurement knob: 129 restores K3t)
 
 
 def take_eigpairs(evals, evecs, neig, mode):
@@ -285,7 +288,19 @@ class _Group:
         due = self.restart is not None and k + p > self.restart and k > self.keep and k < N
         pk = min(self.keep, k) if due else p
         self._compress = None
-        if self.small_eigh in ("native", "jacobi", "tri") and k <= K.SMALL_EIGH_MAX_K and pk <= K.SMALL_EIGH_MAX_P:
+        # r06: from order K3P_MIN_K on — and wherever K3t does not fit the LDS (order 126 with 6 pairs used to fall to the
+        # Jacobi kernel: 2.8 ms against 0.45) — the persistent register-resident tridiagonalisation + K3g's final kernel
+        # are ahead of the LDS-resident K3t (profiles/r06_k3p_orders.jsonl: 0.36 vs 0.41 ms at order 96, 0.23 vs 0.24 at 64)
+        tri_fits = K.small_eigh_tri_ok(k, p, self.dtype) and K.small_eigh_tri_ok(k, pk, self.dtype)
+        # — where the solver is on the critical path (one batch group).  Beside a panel stream (two groups) K3t stays: the
+        # chain is hidden there and the configs[4] pipeline measured 1.4 % slower with K3p (85.5 / 86.2 / 85.4 against
+        # 83.8 / 85.1 / 84.2 ms, interleaved)
+        prefer_big = self.small_eigh == "native" and not force_jacobi and k <= K.SMALL_EIGH_MAX_K and \
+            pk <= K.SMALL_EIGH_MAX_P and ((k >= K3P_MIN_K and getattr(self, "chain_exposed", False)) or
+                                          (k >= K.SMALL_EIGH_TRI_MIN_K and not tri_fits)) and \
+            K.small_eigh_big_ok(k, pk, self.dtype)
+        if self.small_eigh in ("native", "jacobi", "tri") and k <= K.SMALL_EIGH_MAX_K and pk <= K.SMALL_EIGH_MAX_P \
+                and not prefer_big:
             end = self._mark("k3")
             # K3t (tridiagonalisation + bisection + inverse iteration) from order 16 on: the O(k^3) work is done
             # once instead of ~8 Jacobi sweeps; small orders and anything K3t cannot hold in LDS go to Jacobi
@@ -303,7 +318,7 @@ class _Group:
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)                                                        # (B, k, p) view
         elif self.small_eigh in ("native", "tri") and not force_jacobi and \
-                (k > K.SMALL_EIGH_MAX_K or pk > K.SMALL_EIGH_MAX_P) and \
+                (k > K.SMALL_EIGH_MAX_K or pk > K.SMALL_EIGH_MAX_P or prefer_big) and \
                 k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
             # K3g: bases of 129 .. 1024 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
             # wanted pairs at any order (wide eigen-blocks, thick restarts that keep 2 neig > 16 vectors): the same
@@ -984,6 +999,7 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
             grp = _Group(ops[g], opM, b1 - b0, N, Npad, p, nguess, dtype, device, mode, small_eigh, orth_passes,
                          precond=_pc_slice(pc_full, b0, b1), restart=restart, capacity=basis_capacity)
             grp.k1_stream = k1_streams[g]
+            grp.chain_exposed = not two          # one group: nothing hides the Rayleigh-Ritz solver
             if two and k1_sched is not None:
                 grp.k1_sched = [(kf, sts[g]) for (kf, sts) in k1_sched]
             grp.adaptive = adaptive
