@@ -343,7 +343,12 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  * algo: 1 = the form above; 2 = the TWO-STAGE form (xk_eigh_band.hip: dense -> band of 16 sub-diagonals by block
  * reflectors, two launches per 16 columns; band -> tridiagonal by bulge chasing in LDS, one workgroup per matrix, sweeps
  * pipelined three steps apart; eigenvectors back through both stages, one workgroup per vector), XK_ERR_UNSUPPORTED when
- * the band of order k does not fit the LDS (fp64: k <= 614); 0 = the measured choice. */
+ * the band of order k does not fit the LDS (fp64: k <= 614); 3 = the PERSISTENT form (r06, xk_eigh_persist.hip: the whole
+ * Householder reduction in ONE launch of one workgroup per matrix, the trailing block of order <= 256 (fp64) / 384 (fp32)
+ * resident in the registers of its eight waves, one barrier per step; larger orders start with k - 256 / k - 384 step
+ * launches of form 1 and hand over); 0 = the measured choice (form 3 up to 64 .. 128 orders beyond its register limit,
+ * by batch; the two-stage form beyond where it fits; else form 1).  Every form is bit-reproducible; the forms differ in
+ * rounding. */
 int xk_small_eigh_big_batch(int k, int p, int elem_size);
 long xk_small_eigh_big_workspace_elems(int B, int k, int wg);
 int xk_small_eigh_big_f64(const double* T, double* lam, double* Y, double* ws, long ws_elems, int* info, int B, int k,
