@@ -80,6 +80,8 @@ __global__ __launch_bounds__(512) void tridiag_persist_kernel(
   __shared__ T Srow[2][NC];                                 // row j + 1 as its owner left it (relative columns)
   __shared__ T Rl[2][NC];                                   // row-form sums of the product with the next reflector
   __shared__ T Pl[2][NW][NC];                               // column-form partial sums per wave
+  __shared__ T Ql[NC];                                      // q of the step, by relative column (row scalars are read from here)
+  __shared__ T VNl[2][NC];                                  // reflector j (cur) and j + 1 (nxt), by relative column
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,6 +155,10 @@ __global__ __launch_bounds__(512) void tridiag_persist_kernel(
     }
     if (tid == 0) { tau[j] = tj; ee[j] = beta; }
   }
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) VNl[0][lane + 64 * t] = v[t];
+  }
   __syncthreads();
 
   int cur = 0;
@@ -167,10 +173,14 @@ __global__ __launch_bounds__(512) void tridiag_persist_kernel(
     const int r1 = j + 1 - base, r2 = j + 2 - base;         // relative indices of row j + 1 and of the first live row
     const int nrel = n - base;
     // ---- A. w = A v_j from the partial sums, K, q -----------------------------------------------------------------
+    // (A and B on the four OLDER waves only, one per SIMD — the same numbers in each; the younger four would only compete
+    //  for the same vector ALUs: they wait at the barrier and fetch q and the new reflector from LDS)
     T q[NT];
     T q0 = T(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) q[t] = T(0);
+    T tauN = T(0), betaN = T(0);
+    if (wave < 4) {
     if (j >= 0) {
       T wsum[NT];
       T dot = T(0);
@@ -196,7 +206,6 @@ __global__ __launch_bounds__(512) void tridiag_persist_kernel(
     }
     XK_PSTAMP(tA)
     // ---- B. row j + 1 after update j, reflector j + 1 ----------------------------------------------------------------
-    T tauN, betaN;
     {
       T s1[NT], a[NT];
 #pragma unroll
@@ -224,6 +233,20 @@ __global__ __launch_bounds__(512) void tridiag_persist_kernel(
         if (wave == 0 && rc > r2 && rc < nrel) S[(long)(j + 1) * n + base + rc] = vN[t];     // parked for the back-transformation
       }
       if (tid == 0) { dd[j + 1] = dnext; ee[j + 1] = betaN; tau[j + 1] = tauN; }
+      if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (64 * (t + 1) > r1) { Ql[lane + 64 * t] = q[t]; VNl[nxt][lane + 64 * t] = vN[t]; }
+        }
+      }
+    }
+    }
+    __syncthreads();
+    if (wave >= 4) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (64 * (t + 1) > r1) { q[t] = Ql[lane + 64 * t]; vN[t] = VNl[nxt][lane + 64 * t]; }
+      }
     }
     XK_PSTAMP(tB)
     // ---- C. own rows i >= j + 2: update, product with reflector j + 1 ---------------------------------------------------
@@ -243,7 +266,8 @@ __global__ __launch_bounds__(512) void tridiag_persist_kernel(
       auto row = [&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const int ln = wave + 8 * r;                        // lane of column i inside slot g
-        const T vi = per_readlane(v[g], ln), qi = per_readlane(q[g], ln), vNi = per_readlane(vN[g], ln);
+        // (the row's three scalars as LDS broadcasts: six v_readlane less on the vector ALU, which is what bounds the loop)
+        const T vi = VNl[cur][ib + 8 * r], qi = Ql[ib + 8 * r], vNi = VNl[nxt][ib + 8 * r];
         T racc = T(0);
         if (lane >= ln) {                                   // the diagonal slot: columns left of the diagonal are not stored
           T an = fma(-vi, q[g], A[g][r][g]);
