@@ -707,7 +707,9 @@ def _plan_groups(A, whole, M, B, N, p, dtype, device, precond, overlap, groups, 
         # resident K1s launches of the two groups on two streams (below): the panel stream gains more from 32 further
         # units than the chain loses (configs[1]: 211.4 ms per call with 64 left to the chain, 209.9 with 48, 206.7 with
         # 32, 211.6 with 16 — profiles/r05_k1s_pipeline_ab.jsonl)
-        if can_two and K.K1S_OPTS is None and whole.kind == "dense" and whole.symm and whole.symm_narrow and p <= 6:
+        # (only where the per-group panel streams will be taken: on ONE stream 64 measured better — ADVICE r05)
+        if can_two and K.K1S_OPTS is None and whole.kind == "dense" and whole.symm and whole.symm_narrow and p <= 6 \
+                and (k1_streams_opt == "auto" or bool(k1_streams_opt)):
             total_cus = torch.cuda.get_device_properties(device).multi_processor_count
             if K.k1s_auto_opts(B // ngrp, N, dtype, max(1, total_cus - 32), pipelined=True) & K.K1S_PERSIST:
                 reserve_cus = 32
