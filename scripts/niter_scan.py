@@ -1,12 +1,14 @@
+"""iteration counts of the Davidson goldens by the order from which K3p replaces K3t (native_eig.K3P_MIN_K): the
+mixed-convergence cases are chaotic in the rounding, the others do not move.  GPU."""
 import os, sys, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests import cases
 import xitorch_amd as xa
 from xitorch_amd.linalg import native_eig
 from xitorch_amd.linalg.native_eig import davidson
 dev = torch.device("cuda:0")
-GOLD = "/root/repo/tests/golden"
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 for mk in (64, 72, 80, 96, 112, 129):
     native_eig.K3P_MIN_K = mk
     out = {}
