@@ -509,6 +509,66 @@ def test_small_eigh_big_persistent_vs_lapack(dev, B, k, p, uppest, dtype):
             assert (G - torch.eye(p, dtype=torch.float64)).abs().max().item() < tol * 200, tag
 
 
+@pytest.mark.parametrize("kind", ["diagonal", "int_diagonal", "identity", "zero", "block2", "tiny", "huge"])
+@pytest.mark.parametrize("k,p,dtype", [(40, 6, torch.float64), (150, 6, torch.float64), (300, 9, torch.float64),
+                                       (96, 16, torch.float32)])
+def test_small_eigh_edge_matrices(dev, kind, k, p, dtype):
+    """Matrices that stress the bisection of the Rayleigh-Ritz solvers (r06: product-form Sturm counts narrow the bracket,
+    the ratio form confirms it): decoupled (diagonal: every e = 0; integer diagonal: the multisection's shifts hit
+    eigenvalues exactly; two dense blocks), one cluster (identity), the zero matrix — all must come out right, unflagged,
+    eigenvalues ascending; and scales at which the Householder reduction / e^2 leave the floating-point range (1e-150 /
+    1e150 in fp64, 1e-30 / 1e30 in fp32) must be FLAGGED (the caller repeats those on the library, which rescales) —
+    never returned wrong.  Every form: K3t where it fits, K3g forms 0 / 1 / 2 / 3."""
+    g = torch.Generator().manual_seed(k + p)
+    B = 2
+    scale = 1.0
+    if kind == "diagonal":
+        Tm = torch.diag_embed(torch.randn(B, k, dtype=torch.float64, generator=g))
+    elif kind == "int_diagonal":
+        Tm = torch.diag_embed(torch.randint(-8, 9, (B, k), generator=g).double())
+    elif kind == "identity":
+        Tm = 3.0 * torch.eye(k, dtype=torch.float64).expand(B, k, k).clone()
+    elif kind == "zero":
+        Tm = torch.zeros(B, k, k, dtype=torch.float64)
+    else:
+        h = k // 2
+        Tm = torch.zeros(B, k, k, dtype=torch.float64)
+        R1 = torch.randn(B, h, h, dtype=torch.float64, generator=g)
+        R2 = torch.randn(B, k - h, k - h, dtype=torch.float64, generator=g)
+        Tm[:, :h, :h] = R1 + R1.transpose(1, 2)
+        Tm[:, h:, h:] = R2 + R2.transpose(1, 2)
+        if kind == "tiny":
+            scale = 1e-150 if dtype == torch.float64 else 1e-30
+        elif kind == "huge":
+            scale = 1e150 if dtype == torch.float64 else 1e30
+        Tm = Tm * scale
+    ref = torch.linalg.eigvalsh(Tm)[:, :p]
+    Tq = Tm.to(dtype).double()
+    Td = torch.tril(Tm).to(dtype).to(dev)
+    forms = [("big", a) for a in (0, 1, 3)] + ([("big", 2)] if k >= 35 else [])
+    if K.small_eigh_tri_ok(k, p, dtype):
+        forms.append(("tri", None))
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    for name, algo in forms:
+        K._workspace(1 << 22, dtype, dev).fill_(float("nan"))
+        if name == "tri":
+            lam, Y, info = K.small_eigh(Td, k, p, method="tri")
+        else:
+            lam, Y, info = K.small_eigh_big(Td, k, p, algo=algo)
+        tag = (kind, name, algo)
+        if kind in ("tiny", "huge"):
+            assert int(info.min()) != 0, tag                   # flagged: never a wrong answer
+            continue
+        assert int(info.max()) == 0, tag
+        lam, Y = lam.cpu().double(), Y.cpu().double()
+        nrm = max(float(ref.abs().max()), 1.0)
+        assert torch.all(lam[:, 1:] >= lam[:, :-1]), tag
+        assert (lam - ref).abs().max().item() < 10 * tol * nrm, tag
+        Yc = Y.transpose(1, 2)
+        assert (Tq @ Yc - Yc * lam.unsqueeze(1)).abs().max().item() < 100 * tol * nrm, tag
+        assert (Yc.transpose(1, 2) @ Yc - torch.eye(p, dtype=torch.float64)).abs().max().item() < 200 * tol, tag
+
+
 @pytest.mark.parametrize("B,k,p,uppest,dtype", [(2, 35, 4, False, torch.float64), (3, 130, 6, False, torch.float64),
                                                 (2, 200, 6, True, torch.float64), (2, 333, 4, False, torch.float64),
                                                 (2, 512, 6, False, torch.float64), (1, 582, 6, False, torch.float64),

@@ -145,6 +145,10 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     if (lane == 0) lamv[w] = lamw;
   }
   if (tid == 0) red[15] = T(0);                       // "an iterate was annihilated / non-finite" flag of step 3
+  // (each wanted eigenvalue was bracketed on its own: inside a cluster two results may sit an ulp out of order)
+  __syncthreads();
+  if (tid == 0)
+    for (int j = 1; j < p; ++j) lamv[j] = fmax(lamv[j], lamv[j - 1]);
   __syncthreads();
   if (stop_after == 2) return;                        // (measurement hook: results are wrong by construction)
   XK_FSTAMP()
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(512) void tridiag_eigh_big_kernel(
     }
     nonfinite = __any(nonfinite) ? 1 : 0;
     if (!(tnorm < T(INFINITY))) nonfinite = 1;
+    if (!tri_scale_in_range(tnorm)) nonfinite = 1;        // (xk_tridiag.h: outside the range the reduction is safe in)
     if (red[15] != T(0)) nonfinite = 1;
     if (lane == 0) {
       const T tol = T(100) * eps * tnorm * T(n > 128 ? 4 : 1) + T(8) * pivmin;

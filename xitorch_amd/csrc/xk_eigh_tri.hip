@@ -206,6 +206,11 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
 
   XK_TRI_STAMP(2)
   if (tid == 0) red[15] = T(0);                              // "an iterate was annihilated" flag of step 3
+  // (each wanted eigenvalue was bracketed on its own: inside a cluster two results may sit an ulp out of order)
+  __syncthreads();
+  if (tid == 0)
+    for (int j = 1; j < p; ++j) lamv[j] = fmax(lamv[j], lamv[j - 1]);
+  __syncthreads();
   // ---- 3. inverse iteration (dstein): lane j of wave 0 owns eigenvalue j ---------------------------------
   // coincident eigenvalues get distinct shifts so that their factorizations (and iterates) differ
   const T pfloor = eps * tnorm + pivmin;                     // floor of a pivot's magnitude
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(1024) void tridiag_eigh_kernel(
     }
     nonfinite = __any(nonfinite) ? 1 : 0;
     if (!(tnorm < T(INFINITY))) nonfinite = 1;
+    if (!tri_scale_in_range(tnorm)) nonfinite = 1;          // (xk_tridiag.h: outside the range the reduction is safe in)
     if (red[15] != T(0)) nonfinite = 1;                      // zero / non-finite iterate in the last normalisation
     if (lane == 0) {
       const T tol = T(100) * eps * tnorm + T(8) * pivmin;

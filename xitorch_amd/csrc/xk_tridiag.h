@@ -33,6 +33,21 @@ __device__ __forceinline__ float tri_scale_down(float x, int e) { return ldexpf(
 __device__ __forceinline__ int tri_exponent(double x) { return __builtin_amdgcn_frexp_exp(x); }
 __device__ __forceinline__ int tri_exponent(float x) { return __builtin_amdgcn_frexp_expf(x); }
 
+// Is the scale of the matrix (|T| = its Gershgorin bound) inside the range in which neither the Householder reduction
+// (alpha^2 + sigma) nor the Sturm counts (e^2) nor the pivot floor leave the floating-point range?  Outside it the solver
+// flags its result and the caller repeats the call on the library, which rescales (dsyevx's rmin / rmax): fp64
+// 2^-450 .. 2^450 (1e-135 .. 1e135), fp32 2^-50 .. 2^50 (1e-15 .. 1e15).  A zero matrix is in range.
+__device__ __forceinline__ bool tri_scale_in_range(double tnorm) {
+  if (tnorm == 0.0) return true;
+  const int ex = __builtin_amdgcn_frexp_exp(tnorm);
+  return ex >= -450 && ex <= 450;
+}
+__device__ __forceinline__ bool tri_scale_in_range(float tnorm) {
+  if (tnorm == 0.0f) return true;
+  const int ex = __builtin_amdgcn_frexp_expf(tnorm);
+  return ex >= -50 && ex <= 50;
+}
+
 // ratio form; the operands of eight steps are requested from LDS before their chain, the next eight while it runs
 template <typename T>
 __device__ __forceinline__ int tri_sturm_ratio(const T* __restrict__ dd, const T* __restrict__ e2, int n, T sigma,
