@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("XITORCH_AMD_LIB") or os.path.join(_HERE, "csrc", "lib
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "xitorch_amd.h")
 
 _lib = None
+ABI_VERSION = 1          # xk_abi_version() of the library this package was written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -34,7 +35,20 @@ def lib():
             raise NativeLibraryError(
                 "xitorch_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback." % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        if os.environ.get("XITORCH_AMD_LIB"):
+            # a measurement build stands in for the shipped library: say so, and refuse one of another ABI
+            # (version entry point + every function the header declares)
+            import warnings
+            if not hasattr(L, "xk_abi_version") or int(L.xk_abi_version()) != ABI_VERSION:
+                raise NativeLibraryError("xitorch_amd: XITORCH_AMD_LIB=%s does not report ABI version %d"
+                                         % (LIB_PATH, ABI_VERSION))
+            missing = [n for n in header_symbols() if not hasattr(L, n)]
+            if missing:
+                raise NativeLibraryError("xitorch_amd: XITORCH_AMD_LIB=%s lacks %d of the declared entry points (%s ...)"
+                                         % (LIB_PATH, len(missing), ", ".join(missing[:3])))
+            warnings.warn("xitorch_amd: native library overridden by XITORCH_AMD_LIB=%s (measurement build)" % LIB_PATH)
+        _lib = L
         _declare(_lib)
     return _lib
 
