@@ -196,3 +196,31 @@ def test_guard_failure_without_a_rollback_point_reruns_then_raises(dev, monkeypa
     monkeypatch.setitem(native_eig.GUARD_BAD, torch.float64, 1e-29)
     with pytest.raises(RuntimeError, match="lost its orthonormality"):
         davidson(A, 4, "lowest", min_eps=1e-8)
+
+
+def test_roll_back_on_the_last_allowed_iteration_returns_the_best_iterate_recorded_before(dev):
+    """ `rollback()` keeps the best iterate: a guard failure on the LAST allowed iteration must return the block
+    that was best before the void step — with its own eigenvalues and residual — like the reference returns its best
+    iterate with a warning (symeig.py:196-200); nothing of the void step may leak into it."""
+    N, p = 900, 8
+    mat = synthetic.dense_symmetric(2, N, "S1", dtype=torch.float64, device=dev)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    tr = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        davidson(A, p, "lowest", min_eps=1e-8, orth_passes=1, trace=tr, max_niter=600)
+    assert len(tr["orth_redo"]) >= 1
+    it_void = tr["orth_redo"][0]["iter"]                     # the iteration whose step the guard voided
+    # the same run, stopped right after that step (max_niter counts Rayleigh-Ritz steps) and one step earlier
+    tr_a, tr_b = {}, {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev_a, X_a = davidson(A, p, "lowest", min_eps=1e-8, orth_passes=1, trace=tr_a, max_niter=it_void)
+        ev_b, X_b = davidson(A, p, "lowest", min_eps=1e-8, orth_passes=1, trace=tr_b, max_niter=it_void - 1)
+    assert tr_a["stop_reason"] != "converged" and tr_b["stop_reason"] != "converged"
+    # what comes back after the void last step is the best block of the steps before it
+    assert torch.equal(ev_a, ev_b) and torch.equal(X_a, X_b)
+    G = X_a.transpose(1, 2) @ X_a
+    assert (G - torch.eye(p, dtype=G.dtype, device=dev)).abs().max().item() <= native_eig.GUARD_BAD[torch.float64]
+    R = mat @ X_a - X_a * ev_a.unsqueeze(-2)
+    assert abs(R.abs().max().item() - tr_a["best_resid"]) <= 1e-12 * max(1.0, tr_a["best_resid"]) + 1e-10
