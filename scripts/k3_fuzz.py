@@ -1,5 +1,5 @@
 """randomised scan of the Rayleigh-Ritz solvers (K3t, K3g forms 1 / 2 / 3 and the library's choice) against LAPACK: orders
-8 .. 520, 1 .. 64 pairs, fp64 / fp32, lowest / uppest, 1 .. 5 matrices, matrix kinds that stress the bisection (diagonal =
+8 .. 520, 1 .. 256 pairs, fp64 / fp32, lowest / uppest, 1 .. 5 matrices, matrix kinds that stress the bisection (diagonal =
 decoupled, identity = one cluster, zero, clusters, graded, huge / tiny scale, Ritz-like) — with the workspace poisoned.
 Prints failing cases and a summary line.  GPU."""
 import os, sys, json, math
@@ -53,7 +53,7 @@ nflag = {}
 for case in range(ncase):
     dtype = torch.float64 if ri(0, 2) else torch.float32
     k = ri(8, 520) if ri(0, 3) else ri(8, 140)
-    p = min(k, ri(1, 64) if ri(0, 3) == 0 else ri(1, 16))
+    p = min(k, ri(1, 256) if ri(0, 3) == 0 else ri(1, 16))
     B = ri(1, 5)
     uppest = bool(ri(0, 1))
     kind = kinds[ri(0, len(kinds) - 1)]

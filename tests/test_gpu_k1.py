@@ -463,7 +463,10 @@ def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
                                                 (2, 333, 4, False, torch.float64), (1, 400, 6, True, torch.float64),
                                                 (2, 128, 16, False, torch.float32), (2, 384, 6, False, torch.float32),
                                                 (1, 500, 6, False, torch.float32), (33, 150, 6, False, torch.float64),
-                                                (2, 192, 40, True, torch.float64), (1, 64, 6, False, torch.float64)])
+                                                (2, 192, 40, True, torch.float64), (1, 64, 6, False, torch.float64),
+                                                # r06: up to 256 wanted pairs (was 64)
+                                                (1, 300, 100, False, torch.float64), (2, 200, 200, False, torch.float64),
+                                                (1, 420, 256, True, torch.float32)])
 def test_small_eigh_big_persistent_vs_lapack(dev, B, k, p, uppest, dtype):
     """K3g in its persistent form (r06, algo = 3: the trailing block of order <= 256 (fp64) / 384 (fp32) in the registers
     of ONE workgroup per matrix, one launch for the whole Householder reduction; larger orders start with step launches

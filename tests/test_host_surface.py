@@ -525,7 +525,7 @@ def test_rayleigh_ritz_solver_limits_by_order_and_precision():
     for k in (8, 600, 768, 769, 1024):
         assert batch(k, 6, 4) > 0, k
     assert batch(1025, 6, 4) == 0 and batch(7, 6, 4) == 0
-    assert batch(100, 65, 8) == 0 and batch(100, 64, 8) > 0           # at most 64 wanted pairs
+    assert batch(300, 257, 8) == 0 and batch(300, 256, 8) > 0         # at most 256 wanted pairs (r06; 64 before)
     # work copy + hand-over blocks of the one-stage form + the two-stage form's V / T / R / W / Z / reflector blocks
     k, B = 582, 32
     assert ws(B, k, 0) > B * k * k * 3

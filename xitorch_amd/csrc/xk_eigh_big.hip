@@ -40,7 +40,7 @@ template <typename T> struct BigEps;
 template <> struct BigEps<double> { static constexpr double eps = 2.220446049250313e-16; static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct BigEps<float> { static constexpr float eps = 1.1920929e-07f; static constexpr float tiny = 1.17549435e-38f; };
 
-constexpr int BIG_MAXP = 64;
+constexpr int BIG_MAXP = 256;                             // (r06: was 64; the LU batches and the finished vectors' rows in Y scale with p)
 
 __device__ __forceinline__ double big_readlane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
