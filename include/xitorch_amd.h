@@ -328,7 +328,7 @@ int xk_kry_status_f64(const double* Prr, const double* stop, double* rnorm, doub
 int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double* status, int S, int nblk,
                       void* stream);
 
-/* ---- K3g: the same p wanted eigenpairs for Rayleigh-Ritz matrices of order 129 .. 1024 (xk_eigh_big.hip) ---------
+/* ---- K3g: the same p wanted eigenpairs for Rayleigh-Ritz matrices of order 129 .. 1536 (xk_eigh_big.hip) ---------
  * torch.linalg.eigh + _take_eigpairs (symeig.py:174-175, 255-264) once the un-restarted basis (symeig.py:132-135) has
  * outgrown the LDS-resident kernels: Householder tridiagonalisation of the upper triangle of a work copy in global
  * memory, k - 1 launches (one per step, look-ahead form) over several workgroups per matrix; then bisection / inverse
@@ -338,7 +338,7 @@ int xk_kry_status_f32(const float* Prr, const float* stop, float* rnorm, double*
  * wg: workgroups per matrix of the step kernels, 0 = automatic (by batch and order), 1 .. 32; threads: 0 = 512, or 256.
  * lam (B, p) ascending, Y (B, p, k) eigenvectors, info[b] != 0 -> redo that call on the library solver.
  * xk_small_eigh_big_batch(k, p, elem_size): shifts factorised at a time (> 0) when the problem fits the 160 KiB of
- * LDS, 0 when it does not.  8 <= k <= 1024 (r05: beyond 768 with 16 column slots per lane in 256-thread workgroups, or the two-stage form below where its band fits: fp32), p <= 256 (r06; 64 before) (also the solver for MORE THAN 16 wanted pairs at any order: wide
+ * LDS, 0 when it does not.  8 <= k <= 1536 (r06: beyond 1024 with 24 column slots per lane; r05: beyond 768 with 16 column slots per lane in 256-thread workgroups, or the two-stage form below where its band fits: fp32), p <= 256 (r06; 64 before) (also the solver for MORE THAN 16 wanted pairs at any order: wide
  * eigen-blocks, thick restarts; the batch of vectors in work lives in LDS, finished ones in the rows of Y).
  * algo: 1 = the form above; 2 = the TWO-STAGE form (xk_eigh_band.hip: dense -> band of 16 sub-diagonals by block
  * reflectors, two launches per 16 columns; band -> tridiagonal by bulge chasing in LDS, one workgroup per matrix, sweeps

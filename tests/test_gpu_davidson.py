@@ -684,6 +684,32 @@ def test_unrestarted_run_to_900_vectors_makes_no_library_eigh_call(dev, monkeypa
     assert abs(R.abs().max().item() - tr["best_resid"]) <= 1e-6 * max(1.0, tr["best_resid"])
 
 
+def test_unrestarted_run_to_1500_vectors_makes_no_library_eigh_call(dev, monkeypatch):
+    """(r06) the same beyond 1024 vectors: K3g's one-launch-per-step form with 24 column slots serves the
+    orders 1025 .. 1536; a run stopped by max_niter at a basis of 1500+ vectors makes no torch.linalg.eigh call."""
+    from xitorch_amd import synthetic
+    import warnings
+    B, N, p = 1, 4096, 6
+    mat = synthetic.dense_symmetric(B, N, "S3", dtype=torch.float64, device=dev)
+    A = xa.LinearOperator.m(mat, is_hermitian=True)
+    calls = []
+    real_eigh = torch.linalg.eigh
+    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **k: (calls.append(1), real_eigh(*a, **k))[1])
+    tr = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, X = davidson(A, p, "lowest", min_eps=1e-12, max_niter=252, trace=tr)
+    monkeypatch.undo()
+    assert tr["basis_size"] >= 1500, tr["basis_size"]
+    assert not calls and tr["k3_fallbacks"] == 0, (len(calls), tr["k3_fallbacks"])
+    exact = synthetic.spectrum("S3", N, device=dev)[:p]
+    assert (ev - exact).min().item() >= -1e-9 and (ev - exact).abs().max().item() <= 0.5
+    G = X.transpose(-2, -1) @ X
+    assert (G - torch.eye(p, dtype=torch.float64, device=dev)).abs().max().item() <= 1e-9
+    R = mat @ X - X * ev.unsqueeze(-2)
+    assert abs(R.abs().max().item() - tr["best_resid"]) <= 1e-6 * max(1.0, tr["best_resid"])
+
+
 @pytest.mark.parametrize("N,p", [(900, 8), (900, 10), (2048, 12)])
 def test_default_orthonormalisation_survives_mixed_convergence(dev, N, p):
     """Regression (round 3): with some wanted pairs long converged and others (inside the dense part of the S1

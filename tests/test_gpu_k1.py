@@ -412,7 +412,10 @@ def test_group_status_kernel(dev, dtype, B):
                                                 # r05: fp64 orders 769 .. 1024 (one launch per Householder step with
                                                 # 16 column slots, 256-thread workgroups)
                                                 (2, 800, 6, False, torch.float64), (1, 1024, 6, True, torch.float64),
-                                                (1, 900, 20, False, torch.float64), (1, 769, 3, False, torch.float64)])
+                                                (1, 900, 20, False, torch.float64), (1, 769, 3, False, torch.float64),
+                                                # r06: orders 1025 .. 1536 (24 column slots)
+                                                (1, 1200, 6, False, torch.float64), (1, 1536, 4, True, torch.float64),
+                                                (1, 1500, 6, False, torch.float32), (2, 1025, 3, False, torch.float64)])
 def test_small_eigh_big_vs_lapack(dev, B, k, p, uppest, dtype):
     """K3g in its one-launch-per-Householder-step form (algo = 1; orders 129 .. 768, matrix in global memory) against
     LAPACK: eigenvalues, residual, orthonormality, on

@@ -519,12 +519,12 @@ def test_rayleigh_ritz_solver_limits_by_order_and_precision():
     (torch.linalg.eigh of the whole T in the reference: xitorch/_impls/linalg/symeig.py:174-175)."""
     batch = _capi.fn("xk_small_eigh_big_batch")
     ws = _capi.fn("xk_small_eigh_big_workspace_elems")
-    for k in (8, 129, 614, 615, 768, 769, 1024):
+    for k in (8, 129, 614, 615, 768, 769, 1024, 1025, 1536):
         assert batch(k, 6, 8) > 0, k
-    assert batch(1025, 6, 8) == 0
-    for k in (8, 600, 768, 769, 1024):
+    assert batch(1537, 6, 8) == 0
+    for k in (8, 600, 768, 769, 1024, 1536):
         assert batch(k, 6, 4) > 0, k
-    assert batch(1025, 6, 4) == 0 and batch(7, 6, 4) == 0
+    assert batch(1537, 6, 4) == 0 and batch(7, 6, 4) == 0
     assert batch(300, 257, 8) == 0 and batch(300, 256, 8) > 0         # at most 256 wanted pairs (r06; 64 before)
     # work copy + hand-over blocks of the one-stage form + the two-stage form's V / T / R / W / Z / reflector blocks
     k, B = 582, 32

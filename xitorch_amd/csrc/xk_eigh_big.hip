@@ -40,6 +40,7 @@ template <typename T> struct BigEps;
 template <> struct BigEps<double> { static constexpr double eps = 2.220446049250313e-16; static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct BigEps<float> { static constexpr float eps = 1.1920929e-07f; static constexpr float tiny = 1.17549435e-38f; };
 
+constexpr int BIG_MAXK = 1536;                            // (r06: was 1024; one launch per Householder step with 24 column slots)
 constexpr int BIG_MAXP = 256;                             // (r06: was 64; the LU batches and the finished vectors' rows in Y scale with p)
 
 __device__ __forceinline__ double big_readlane(double v, int l) {
@@ -818,7 +819,8 @@ static int big_launch_final_nt(T* ws, const T* aux, long aux_stride, T* lam, T* 
   if (k <= 384) return big_launch_final<T, 6>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
   if (k <= 512) return big_launch_final<T, 8>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
   if (k <= 768) return big_launch_final<T, 12>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
-  return big_launch_final<T, 16>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+  if (k <= 1024) return big_launch_final<T, 16>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
+  return big_launch_final<T, 24>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, mode, st);
 }
 
 template <typename T>
@@ -840,7 +842,8 @@ static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, 
       else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
       else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
       else if (m2 <= 768) big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
-      else big_launch_step<T, 16>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+      else if (m2 <= 1024) big_launch_step<T, 16>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+      else big_launch_step<T, 24>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
     }
     int rc = persist_tridiag<T>(Tin, ws, aux, aux_stride, B, k, base, W, ldt, sT, st);
     if (rc != XK_OK) return rc;
@@ -865,7 +868,8 @@ static int big_run(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, 
     else if (m2 <= 256) big_launch_step<T, 4>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
     else if (m2 <= 512) big_launch_step<T, 8>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
     else if (m2 <= 768) big_launch_step<T, 12>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
-    else big_launch_step<T, 16>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    else if (m2 <= 1024) big_launch_step<T, 16>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
+    else big_launch_step<T, 24>(Tin, ws, aux, aux_stride, B, k, j, W, ldt, sT, nt, st);
   }
   const int rc = big_launch_final_nt<T>(ws, aux, aux_stride, lam, Y, info, B, k, p, pb, uppest, lds, 0, st);
   if (rc != XK_OK) return rc;
@@ -881,7 +885,7 @@ extern "C" {
 int xk_small_eigh_big_batch(int k, int p, int elem_size) {
   // orders 769 .. 1024 (r05): the two-stage form where its band fits the LDS (fp32), else one launch per Householder step
   // with 16 column slots
-  if (k < 8 || p < 1 || p > xk::BIG_MAXP || p > k || k > 1024) return 0;
+  if (k < 8 || p < 1 || p > xk::BIG_MAXP || p > k || k > xk::BIG_MAXK) return 0;
   for (int pb = p; pb >= 1; --pb)
     if (xk::big_lds_elems(k, p, pb) * elem_size + 64 <= 160 * 1024) return pb;
   return 0;
@@ -898,7 +902,7 @@ long xk_small_eigh_big_workspace_elems(int B, int k, int wg) {
   int xk_small_eigh_big_##SUF(const T* Tin, T* lam, T* Y, T* ws, long ws_elems, int* info, int B, int k,      \
                               int p, int uppest, long ldt, long sT, int wg, int threads, int algo,            \
                               void* stream) {                                                                 \
-    if (B < 0 || k < 8 || k > 1024 || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                  \
+    if (B < 0 || k < 8 || k > xk::BIG_MAXK || p < 1 || p > k || p > xk::BIG_MAXP) return XK_ERR_ARG;                  \
     if (wg < 0 || wg > 32 || (threads != 0 && threads != 256 && threads != 512)) return XK_ERR_ARG;           \
     if (algo < 0 || algo > 3) return XK_ERR_ARG;                                                              \
     if (B == 0) return XK_OK;                                                                                 \

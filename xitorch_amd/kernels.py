@@ -298,7 +298,8 @@ def small_eigh_tri_ok(k, p, dtype):
     return fn("xk_small_eigh_tri_lds_bytes")(k, p, esize) <= 160 * 1024
 
 
-SMALL_EIGH_BIG_MAX_K = 1024          # (fp64 beyond 614 and fp32 where the band does not fit: one launch per Householder step)
+SMALL_EIGH_BIG_MAX_K = 1536          # (r06: was 1024; fp64 beyond 614 and fp32 where the band does not fit: one launch per
+                                     #  Householder step, 24 column slots per lane beyond order 1024)
 SMALL_EIGH_BIG_MAX_P = 256          # (r06: was 64)
 # launch shape of K3g's step kernels handed to every call (0 = the library's measured defaults).  Module attributes of
 # the PYTHON layer, for measurement scripts; the C ABI itself has no state
@@ -318,7 +319,7 @@ def small_eigh_big_ok(k, p, dtype):
 
 def small_eigh_big(T, k, p, uppest=False, wg=None, threads=None, algo=None):
     """K3g: lowest / uppermost p eigenpairs of the symmetric (B, k, k) matrices T[:, :k, :k] (lower triangle read) for
-    orders beyond the LDS-resident kernels (129 .. 1024) or more than 16 wanted pairs (p <= 256, k >= 8): lam (B, p) ascending, Y (B, p, k), failure flags (B,) int32
+    orders beyond the LDS-resident kernels (129 .. 1536) or more than 16 wanted pairs (p <= 256, k >= 8): lam (B, p) ascending, Y (B, p, k), failure flags (B,) int32
     (nonzero -> redo with the library).  Replaces torch.linalg.eigh + _take_eigpairs (symeig.py:174-175) on the large
     bases of an un-restarted run."""
     require_device(T, "projected matrix")

@@ -41,7 +41,7 @@ _PRELAUNCH = True          # enqueue the next group's chain early (module attrib
 # matrix: xk_eigh_big.hip) serves before the library takes over (>= 16 matrices per group, fewer)
 CHAIN_CUS = "all"             # units of the chain streams in the two-group pipeline: "all" | "reserved" (only the units the
                               # panel stream's mask leaves) | "auto" (measurement knob, scripts/timeline_gaps.py)
-K3G_MAX_K = [1024, 1024]      # (the library decides: small_eigh_big_ok)
+K3G_MAX_K = [1536, 1536]      # (the library decides: small_eigh_big_ok)
 K3P_MIN_K = int(os.environ.get("XITORCH_K3P_MIN_K", "80"))   # from this order on K3p + K3g's final kernel replace K3t
                               # (r06; the environment variable is a measurement knob: 129 restores K3t)
 
@@ -320,7 +320,7 @@ class _Group:
         elif self.small_eigh in ("native", "tri") and not force_jacobi and \
                 (k > K.SMALL_EIGH_MAX_K or pk > K.SMALL_EIGH_MAX_P or prefer_big) and \
                 k <= K3G_MAX_K[0 if self.B >= 16 else 1] and K.small_eigh_big_ok(k, pk, self.dtype):
-            # K3g: bases of 129 .. 1024 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
+            # K3g: bases of 129 .. 1536 vectors (the un-restarted iteration on slowly converging spectra) or 17 .. 64
             # wanted pairs at any order (wide eigen-blocks, thick restarts that keep 2 neig > 16 vectors): the same
             # tridiagonalisation route with the matrix in global memory: from order 192 on (fp64 to 614) the two-stage
             # form (band by block reflectors, bulge chasing in LDS: xk_eigh_band.hip), else one launch per Householder
@@ -335,7 +335,7 @@ class _Group:
                 lam, Yt = lam[:, sl].contiguous(), Yt[:, sl]
             Y = Yt.transpose(1, 2)
         else:
-            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 256 pairs, > 1024 vectors
+            lam_all, Y_all = torch.linalg.eigh(self.T[:, :k, :k])                         # library eigh: > 256 pairs, > 1536 vectors
             if due:
                 lk, Yk = take_eigpairs(lam_all, Y_all, pk, self.mode)
                 self._compress = (Yk.transpose(1, 2).contiguous(), lk.contiguous())
@@ -859,11 +859,11 @@ def _davidson(A, neig, mode, M=None, max_niter=1000, nguess=None, v_init="randn"
         (extension) ``"native"`` (default): the wanted eigenpairs of the Rayleigh–Ritz matrix come from native
         kernels — up to 128 basis vectors LDS-resident: Householder tridiagonalisation + bisection + inverse
         iteration (K3t) from order 16 on, parallel Jacobi (K3) below that and as the fallback when K3t's self-check
-        flags a result; from 129 to 1024 vectors, or 17 to 256 wanted / kept pairs at any order, the same
+        flags a result; from 129 to 1536 vectors, or 17 to 256 wanted / kept pairs at any order, the same
         route with the matrix in global memory (K3g: from order 192 on — fp64 to 614 — a two-stage reduction, band by
         block reflectors then bulge chasing in LDS; else one launch per Householder step over several workgroups per
         matrix; 3.5x / 2.4x the library at order 582, measured; fallback: the library);
-        ``torch.linalg.eigh`` beyond 1024 vectors or 256 pairs; ``"jacobi"`` / ``"tri"`` force one of
+        ``torch.linalg.eigh`` beyond 1536 vectors or 256 pairs; ``"jacobi"`` / ``"tri"`` force one of
         the LDS kernels; ``"library"``: always ``torch.linalg.eigh``
     overlap: str or bool
         (extension) a batch of native dense operators can be processed as two groups: the operator-panel
@@ -1154,7 +1154,7 @@ def _native_dense_ok(mat, neig):
 def native_partial_eigh(mat, neig, mode):
     """Lowest / uppermost ``neig`` eigenpairs of the dense symmetric matrices ``mat (*B, n, n)`` on the native HIP
     eigensolvers — Householder tridiagonalisation, bisection, inverse iteration, back-transformation: K3t (LDS-resident,
-    n <= 128, neig <= 16) or K3g (global-memory work matrix, n <= 1024, neig <= 256).  Only the wanted pairs are computed
+    n <= 128, neig <= 16) or K3g (global-memory work matrix, n <= 1536, neig <= 256).  Only the wanted pairs are computed
     (the reference's exacteig computes all n and slices, symeig.py:22-24,255-264).  Returns ``evals (*B, neig)``
     ascending and ``evecs (*B, n, neig)``; members whose self-check flags the result are redone on
     ``torch.linalg.eigh``."""
@@ -1210,7 +1210,7 @@ class _NativeEigh(torch.autograd.Function):
 
 def exacteig(A, neig, mode, M=None):
     """Eigendecomposition by building the full matrix (reference: exacteig, symeig.py:11-44).  On a HIP device, for real
-    matrices of order 8 .. 1024 and up to 256 wanted pairs — the reference's own benchmark shapes, n in {100, 350, 700} with
+    matrices of order 8 .. 1536 and up to 256 wanted pairs — the reference's own benchmark shapes, n in {100, 350, 700} with
     neig = 10 (benchmarks/benchmarks_solve.py:37-59) — the eigenpairs come from the native dense eigensolver
     (`native_partial_eigh`: only the wanted pairs are computed); everything else (CPU tensors, complex Hermitian, larger
     orders) is `torch.linalg.eigh` like the reference.  Both carry the degeneracy-aware backward of degen_symeig."""
