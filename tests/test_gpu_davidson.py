@@ -686,10 +686,12 @@ def test_unrestarted_run_to_900_vectors_makes_no_library_eigh_call(dev, monkeypa
 
 def test_unrestarted_run_to_1500_vectors_makes_no_library_eigh_call(dev, monkeypatch):
     """(r06) the same beyond 1024 vectors: K3g's one-launch-per-step form with 24 column slots serves the
-    orders 1025 .. 1536; a run stopped by max_niter at a basis of 1500+ vectors makes no torch.linalg.eigh call."""
+    orders 1025 .. 1536 for 16 and more matrices per batch group (for fewer the library is faster there and stays:
+    native_eig.K3G_MAX_K); a run of 16 operators stopped by max_niter at a basis of 1500+ vectors makes no
+    torch.linalg.eigh call."""
     from xitorch_amd import synthetic
     import warnings
-    B, N, p = 1, 4096, 6
+    B, N, p = 16, 4096, 8                     # (8 pairs: 6 reach 1e-12 at 1338 vectors, before the basis gets there)
     mat = synthetic.dense_symmetric(B, N, "S3", dtype=torch.float64, device=dev)
     A = xa.LinearOperator.m(mat, is_hermitian=True)
     calls = []
@@ -698,7 +700,7 @@ def test_unrestarted_run_to_1500_vectors_makes_no_library_eigh_call(dev, monkeyp
     tr = {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        ev, X = davidson(A, p, "lowest", min_eps=1e-12, max_niter=252, trace=tr)
+        ev, X = davidson(A, p, "lowest", min_eps=1e-12, max_niter=190, trace=tr)
     monkeypatch.undo()
     assert tr["basis_size"] >= 1500, tr["basis_size"]
     assert not calls and tr["k3_fallbacks"] == 0, (len(calls), tr["k3_fallbacks"])

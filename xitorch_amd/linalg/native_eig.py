@@ -41,7 +41,9 @@ _PRELAUNCH = True          # enqueue the next group's chain early (module attrib
 # matrix: xk_eigh_big.hip) serves before the library takes over (>= 16 matrices per group, fewer)
 CHAIN_CUS = "all"             # units of the chain streams in the two-group pipeline: "all" | "reserved" (only the units the
                               # panel stream's mask leaves) | "auto" (measurement knob, scripts/timeline_gaps.py)
-K3G_MAX_K = [1536, 1536]      # (the library decides: small_eigh_big_ok)
+K3G_MAX_K = [1536, 1024]      # largest basis K3g serves before the library takes over, [>= 16 matrices per group, fewer]:
+                              # measured r06 (order 1200 / 1536, ms): 1 matrix 44.5 / 83.1 native against 28.2 / 37.1 library,
+                              # 4: 45.6 / 85.1 against 34.8 / 50.5, 32: 76.2 / 150.4 against 111.8 / 198.6; at 1024: 26.6 / 24.0, 44.2 / 75.1
 K3P_MIN_K = int(os.environ.get("XITORCH_K3P_MIN_K", "80"))   # from this order on K3p + K3g's final kernel replace K3t
                               # (r06; the environment variable is a measurement knob: 129 restores K3t)
 
