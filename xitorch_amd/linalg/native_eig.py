@@ -1148,7 +1148,10 @@ EXACTEIG_NATIVE_MAX_P = K.SMALL_EIGH_BIG_MAX_P
 
 def _native_dense_ok(mat, neig):
     n = mat.shape[-1]
+    nb = mat.numel() // max(1, n * n)
+    # (beyond order 1024 the native form is ahead of the library from 16 matrices on only: K3G_MAX_K)
     return (mat.is_cuda and mat.dtype in (torch.float64, torch.float32) and 8 <= n <= EXACTEIG_NATIVE_MAX_N
+            and n <= K3G_MAX_K[0 if nb >= 16 else 1]
             and 1 <= neig <= min(EXACTEIG_NATIVE_MAX_P, n) and mat.numel() > 0
             and K.small_eigh_big_ok(n, neig, mat.dtype))
 
