@@ -12,13 +12,17 @@
 // Layout (all indices relative to `base`, the first row / column still alive when the kernel starts):
 //   wave w (of 8) owns rows i = w + 8 u; lane l of column slot t holds column c = l + 64 t; only c >= i is stored, so row
 //   u lives in slots t >= u >> 3 — a STATIC register index: A[g][r][t], u = 8 g + r, t >= g  (NT = 4: 80 values per lane).
-// One step = the look-ahead step of xk_eigh_big.hip's tridiag_step_kernel with the kernel boundary replaced by ONE
-// __syncthreads: every wave redundantly (same data, same operations -> same bits)
-//   A. folds the eight waves' partial products of the previous step into w = A v_j, forms K = tau/2 w.v and q = tau w - K v
-//   B. updates row j + 1 (published by its owner in the previous step) and builds reflector j + 1 from it
-//   C. own rows i >= j + 2: rank-2 update in registers and, in the same pass, the product of the UPDATED row with
-//      reflector j + 1 — column form into per-lane accumulators, row form through a transposing wave reduction of eight
-//      rows at a time; the owner of row j + 2 publishes it for the next step
+// One step = the look-ahead step of xk_eigh_big.hip's tridiag_step_kernel with the kernel boundary replaced by two
+// __syncthreads:
+//   A. the four OLDER waves (one per SIMD; same data, same operations -> the same bits in each) fold the eight waves'
+//      partial products of the previous step into w = A v_j, form K = tau/2 w.v and q = tau w - K v,
+//   B. update row j + 1 (published by its owner in the previous step) and build reflector j + 1 from it; q and the
+//      reflector go to LDS; barrier; the younger four waves fetch them (measured: this part is one dependent chain —
+//      its four SIMD partners taken away, it takes as long: profiles/r06_k3_final_phases.json)
+//   C. every wave, own rows i >= j + 2: rank-2 update in registers and, in the same pass, the product of the UPDATED row
+//      with reflector j + 1 — column form into per-lane accumulators, row form through a transposing wave reduction of
+//      eight rows at a time; the row's three scalars (v_i, q_i, v'_i) are LDS broadcasts; the owner of row j + 2 publishes
+//      it for the next step
 //   D. partial column sums to LDS (double-buffered), barrier.
 // Orders beyond 64 NT columns: the first `base` steps are K3g step launches (matrix in global memory), the kernel takes
 // over their hand-over blocks (row X, row-form sums R, column partials P[W]) when the trailing block fits.
